@@ -1,0 +1,193 @@
+"""ctypes binding of the CPU oracle (oracle/libasdr_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under audiosdr_amd/ imports this module.
+
+`OracleSDR` mirrors the reference class surface (AudioSDR.h:88-156): same method names, same
+argument meaning, one instance == one reference `AudioSDR` object.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libasdr_oracle.so")
+
+BLOCK = 128
+LSBmode, USBmode, CW_LSBmode, CW_USBmode, AMmode, SAMmode, WSPRmode = range(7)
+(audioAM, audioCW, audioWSPR, audio2100, audio2300, audio2500, audio2700, audio2900, audio3100, audio3300,
+ audioBypass) = range(11)
+AGCoff, AGCfast, AGCmedium, AGCslow = range(4)
+
+TAPS = ["SCALED_I", "SCALED_Q", "NB_I", "NB_Q", "IF_I", "IF_Q", "MIX_I", "MIX_Q", "DEMOD", "AUDIO_FILT", "AGC", "ALS"]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "asdr_oracle.c")
+    deps = [src, os.path.join(_HERE, "asdr_oracle.h"),
+            os.path.join(_HERE, "..", "audiosdr_amd", "csrc", "asdr_tables.h")]
+    if not force and os.path.exists(_LIB_PATH) and all(
+            os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libasdr_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    vp, f32, i32, u16, i16p = C.c_void_p, C.c_float, C.c_int, C.c_uint16, C.POINTER(C.c_int16)
+    fp = C.POINTER(C.c_float)
+    L.ao_create.restype = vp
+    L.ao_destroy.argtypes = [vp]
+    L.ao_enable_taps.argtypes = [vp, i32]
+    L.ao_tap.argtypes = [vp, i32]
+    L.ao_tap.restype = fp
+    L.ao_update.argtypes = [vp, i16p, i16p, i16p]
+
+    def sig(name, args, res=None):
+        fn = getattr(L, name)
+        fn.argtypes = [vp] + args
+        fn.restype = res
+
+    for n in ["init", "enableAudioFilter", "disableAudioFilter", "enableALSfilter", "disableALSfilter",
+              "setALSfilterNotch", "setALSfilterPeak", "setALSfilterAdaptive", "setALSfilterStatic", "enableAGC",
+              "disableAGC", "enableNoiseBlanker", "disableNoiseBlanker"]:
+        sig("ao_" + n, [])
+    for n in ["setInputGain", "setIQgainBalance", "setOutputGain", "setAGCthreshold", "setAGCslope", "setAGCkneeWidth",
+              "setAGCattackTime", "setAGCreleaseTime", "setAGChangTime", "setAGCstaticGain", "setNoiseBlankerThreshold",
+              "setNoiseBlankerThresholdDb"]:
+        sig("ao_" + n, [f32])
+    for n in ["setMute", "setAudioFilter", "setAGCmode"]:
+        sig("ao_" + n, [i32])
+    sig("ao_setDemodMode", [i32], f32)
+    sig("ao_setALSfilterParams", [C.c_uint, f32, f32])
+    for n in ["getTuningOffset", "getBPFlower", "getBPFupper", "getAGCthreshold", "getAGCslope", "getAGCkneeWidth",
+              "getAGCattack", "getAGCrelease", "getAAGalphaAttack", "getAGCbetaAttack", "getAGCalphaRelease",
+              "getAGCbetaRelease", "getAGCstaticGain", "getAMcarrierLevel", "getSAMfrequency"]:
+        sig("ao_" + n, [], f32)
+    sig("ao_getAGClookup", [i32], f32)
+    sig("ao_getAGChangCount", [], C.c_uint32)
+    sig("ao_getDemodMode", [], C.c_int16)
+    for n in ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNotch", "ALSfilterIsPeak",
+              "ALSfilterIsAdaptive", "AGCisEnabled", "AGCisActive", "NoiseBlankerisEnabled", "NoiseBlankerDetection",
+              "getSAMphaseLockStatus"]:
+        sig("ao_" + n, [], i32)
+    # stage-level
+    L.ao_sin_f32.argtypes = [f32]; L.ao_sin_f32.restype = f32
+    L.ao_cos_f32.argtypes = [f32]; L.ao_cos_f32.restype = f32
+    L.ao_sin_index.argtypes = [f32]; L.ao_sin_index.restype = u16
+    L.ao_sin_from_index.argtypes = [u16]; L.ao_sin_from_index.restype = f32
+    L.ao_approx_atan2_f32.argtypes = [f32, f32]; L.ao_approx_atan2_f32.restype = f32
+    L.ao_fast_sqrt_f32.argtypes = [f32, i32]; L.ao_fast_sqrt_f32.restype = f32
+    L.ao_log2_approx_f32.argtypes = [f32]; L.ao_log2_approx_f32.restype = f32
+    L.ao_biquad_cascade_df1.argtypes = [fp, fp, i32, fp, fp, i32]
+    L.ao_freq_shifter.argtypes = [fp, fp, f32, f32]; L.ao_freq_shifter.restype = f32
+    L.ao_scale_sample.argtypes = [C.c_int16, f32]; L.ao_scale_sample.restype = C.c_double
+    L.ao_agc_static_compressor.argtypes = [fp, u16]; L.ao_agc_static_compressor.restype = f32
+    L.ao_hilbert_taps.restype = fp
+    L.ao_sine_table.restype = fp
+    L.ao_biquad_table.argtypes = [i32]; L.ao_biquad_table.restype = fp
+    L.ao_bench_run.argtypes = [i32, i32, i32, i16p, i16p, i16p, i32]
+    L.ao_bench_run.restype = C.c_double
+    _lib = L
+    return L
+
+
+def _i16p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int16))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OracleSDR:
+    """One reference-equivalent AudioSDR instance on the host CPU."""
+
+    def __init__(self, taps=False):
+        self._L = lib()
+        self._h = self._L.ao_create()
+        if taps:
+            self._L.ao_enable_taps(self._h, 1)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.ao_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __getattr__(self, name):
+        # every other reference method maps to ao_<name>(handle, ...)
+        fn = getattr(self._L, "ao_" + name)
+        return lambda *a: fn(self._h, *a)
+
+    def update(self, I, Q):
+        """I, Q: int16 arrays of n*128 samples -> int16 mono audio, n*128 samples."""
+        I = np.ascontiguousarray(I, dtype=np.int16).reshape(-1, BLOCK)
+        Q = np.ascontiguousarray(Q, dtype=np.int16).reshape(-1, BLOCK)
+        out = np.empty_like(I)
+        for b in range(I.shape[0]):
+            self._L.ao_update(self._h, _i16p(I[b]), _i16p(Q[b]), _i16p(out[b]))
+        return out.reshape(-1)
+
+    def tap(self, name):
+        p = self._L.ao_tap(self._h, TAPS.index(name))
+        return np.ctypeslib.as_array(p, shape=(BLOCK,)).copy()
+
+
+def run_channels(configure, I, Q):
+    """I, Q: int16 [channels][blocks][128].  `configure(sdr, channel)` applies setters.
+    Returns (out int16 [channels][blocks][128], list of OracleSDR)."""
+    I = np.ascontiguousarray(I, dtype=np.int16)
+    Q = np.ascontiguousarray(Q, dtype=np.int16)
+    out = np.empty_like(I)
+    sdrs = []
+    for c in range(I.shape[0]):
+        s = OracleSDR()
+        configure(s, c)
+        out[c] = s.update(I[c], Q[c]).reshape(I.shape[1], BLOCK)
+        sdrs.append(s)
+    return out, sdrs
+
+
+def bench_run(config, I, Q, n_threads=1):
+    """Time `config` (0 = C2 USB chain, 1 = AM, 2 = SAM) on I/Q [ch][blk][128]; seconds + output."""
+    I = np.ascontiguousarray(I, dtype=np.int16)
+    Q = np.ascontiguousarray(Q, dtype=np.int16)
+    out = np.empty_like(I)
+    t = lib().ao_bench_run(config, I.shape[0], I.shape[1], _i16p(I), _i16p(Q), _i16p(out), n_threads)
+    return t, out
+
+
+# --- numpy views of the data tables (for independent cross-checks) ---
+def hilbert_taps():
+    return np.ctypeslib.as_array(lib().ao_hilbert_taps(), shape=(64,)).copy()
+
+
+def sine_table():
+    return np.ctypeslib.as_array(lib().ao_sine_table(), shape=(257,)).copy()
+
+
+def biquad_table(i):
+    return np.ctypeslib.as_array(lib().ao_biquad_table(i), shape=(4, 5)).copy()
+
+
+def biquad_cascade(coefs, state, x):
+    coefs = np.ascontiguousarray(coefs, dtype=np.float32).reshape(-1)
+    state = np.ascontiguousarray(state, dtype=np.float32).reshape(-1)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().ao_biquad_cascade_df1(_fp(coefs), _fp(state), coefs.size // 5, _fp(x), _fp(y), x.size)
+    return y, state
