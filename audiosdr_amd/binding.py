@@ -1,0 +1,207 @@
+"""ctypes binding of libasdr_hip.so (include/asdr.h).  Host-side mirror of the reference's
+`class AudioSDR` (SRC/AudioSDRlib/AudioSDR.h:75-156) for a batch of channels.
+
+Every reference method `sdr.foo(args)` becomes `batch.foo(args, ch=ALL)`; getters take `ch`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+BLOCK = 128
+ALL = -1
+LSBmode, USBmode, CW_LSBmode, CW_USBmode, AMmode, SAMmode, WSPRmode = range(7)       # AudioSDR.h:44-50
+(audioAM, audioCW, audioWSPR, audio2100, audio2300, audio2500, audio2700, audio2900, audio3100, audio3300,
+ audioBypass) = range(11)                                                             # AudioSDR.h:56-66
+AGCoff, AGCfast, AGCmedium, AGCslow = range(4)                                        # AudioSDR.h:68-71
+TAPS = ["SCALED_I", "SCALED_Q", "NB_I", "NB_Q", "IF_I", "IF_Q", "MIX_I", "MIX_Q", "DEMOD", "AUDIO_FILT", "AGC", "ALS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class AsdrError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libasdr_hip.so")
+
+
+# name -> (extra argtypes after (batch, ch), restype)
+_f, _i, _u = C.c_float, C.c_int, C.c_uint
+_SETTERS_VOID = ["init", "enableAudioFilter", "disableAudioFilter", "enableALSfilter", "disableALSfilter",
+                 "setALSfilterNotch", "setALSfilterPeak", "setALSfilterAdaptive", "setALSfilterStatic", "enableAGC",
+                 "disableAGC", "enableNoiseBlanker", "disableNoiseBlanker"]
+_SETTERS_F = ["setInputGain", "setIQgainBalance", "setOutputGain", "setAGCthreshold", "setAGCslope", "setAGCkneeWidth",
+              "setAGCattackTime", "setAGCreleaseTime", "setAGChangTime", "setAGCstaticGain", "setNoiseBlankerThreshold",
+              "setNoiseBlankerThresholdDb"]
+_SETTERS_I = ["setMute", "setAudioFilter", "setAGCmode"]
+_GETTERS_F = ["getTuningOffset", "getBPFlower", "getBPFupper", "getAGCthreshold", "getAGCslope", "getAGCkneeWidth",
+              "getAGCattack", "getAGCrelease", "getAAGalphaAttack", "getAGCbetaAttack", "getAGCalphaRelease",
+              "getAGCbetaRelease", "getAGCstaticGain", "getAMcarrierLevel", "getSAMfrequency"]
+_GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNotch", "ALSfilterIsPeak",
+              "ALSfilterIsAdaptive", "AGCisEnabled", "AGCisActive", "NoiseBlankerisEnabled", "NoiseBlankerDetection",
+              "getSAMphaseLockStatus"]
+
+# every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
+EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
+            "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
+            "asdr_read_status", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version"] +
+           ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libasdr_hip.so.  Raises AsdrError (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or library_path()
+    if not os.path.exists(p):
+        raise AsdrError("%s not found: build it with `python -m audiosdr_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback." % p)
+    L = C.CDLL(p)
+    vp, i16p = C.c_void_p, C.POINTER(C.c_int16)
+    L.asdr_create.argtypes = [_i, _i]; L.asdr_create.restype = vp
+    L.asdr_destroy.argtypes = [vp]; L.asdr_destroy.restype = None
+    L.asdr_last_error.restype = C.c_char_p
+    L.asdr_version.restype = C.c_char_p
+    L.asdr_n_channels.argtypes = [vp]; L.asdr_n_channels.restype = _i
+    L.asdr_update.argtypes = [vp, i16p, i16p, i16p, _i]; L.asdr_update.restype = _i
+    L.asdr_update_device.argtypes = [vp, vp, vp, vp, _i, vp]; L.asdr_update_device.restype = _i
+    L.asdr_synchronize.argtypes = [vp]; L.asdr_synchronize.restype = _i
+    L.asdr_last_kernel_ms.argtypes = [vp]; L.asdr_last_kernel_ms.restype = _f
+    for n in _SETTERS_VOID:
+        fn = getattr(L, "asdr_" + n); fn.argtypes = [vp, _i]; fn.restype = None
+    for n in _SETTERS_F:
+        fn = getattr(L, "asdr_" + n); fn.argtypes = [vp, _i, _f]; fn.restype = None
+    for n in _SETTERS_I:
+        fn = getattr(L, "asdr_" + n); fn.argtypes = [vp, _i, _i]; fn.restype = None
+    for n in _GETTERS_F:
+        fn = getattr(L, "asdr_" + n); fn.argtypes = [vp, _i]; fn.restype = _f
+    for n in _GETTERS_I:
+        fn = getattr(L, "asdr_" + n); fn.argtypes = [vp, _i]; fn.restype = _i
+    L.asdr_setDemodMode.argtypes = [vp, _i, _i]; L.asdr_setDemodMode.restype = _f
+    L.asdr_getDemodMode.argtypes = [vp, _i]; L.asdr_getDemodMode.restype = C.c_int16
+    L.asdr_setALSfilterParams.argtypes = [vp, _i, _u, _f, _f]; L.asdr_setALSfilterParams.restype = None
+    L.asdr_getAGClookup.argtypes = [vp, _i, _i]; L.asdr_getAGClookup.restype = _f
+    i32p, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    L.asdr_read_status.argtypes = [vp, i32p, i32p, i32p, fp, fp]; L.asdr_read_status.restype = _i
+    L.asdr_enable_taps.argtypes = [vp, _i]; L.asdr_enable_taps.restype = _i
+    L.asdr_read_taps.argtypes = [vp, fp]; L.asdr_read_taps.restype = _i
+    if path is None:
+        _lib = L
+    return L
+
+
+class AudioSDRBatch:
+    """N independent AudioSDR channels on one MI355X.  Method names follow the reference class."""
+
+    def __init__(self, n_channels, device=0):
+        self._L = load_library()
+        self._h = self._L.asdr_create(int(n_channels), int(device))
+        if not self._h:
+            raise AsdrError("asdr_create failed: " + self._L.asdr_last_error().decode())
+        self.n_channels = int(n_channels)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.asdr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AsdrError(self._L.asdr_last_error().decode())
+
+    # ---- hot path ----
+    def update(self, I, Q):
+        """I, Q: int16 [channels][blocks][128] (host).  Returns int16 audio of the same shape."""
+        I = np.ascontiguousarray(I, dtype=np.int16)
+        Q = np.ascontiguousarray(Q, dtype=np.int16)
+        assert I.shape == Q.shape and I.size % (self.n_channels * BLOCK) == 0
+        n_blocks = I.size // (self.n_channels * BLOCK)
+        out = np.empty((self.n_channels, n_blocks, BLOCK), dtype=np.int16)
+        p = C.POINTER(C.c_int16)
+        self._chk(self._L.asdr_update(self._h, I.ctypes.data_as(p), Q.ctypes.data_as(p), out.ctypes.data_as(p), n_blocks))
+        return out
+
+    def update_device(self, dI, dQ, dOut, n_blocks, stream=0):
+        """Raw device pointers (ints), asynchronous on `stream` (a hipStream_t handle as int)."""
+        self._chk(self._L.asdr_update_device(self._h, C.c_void_p(dI), C.c_void_p(dQ), C.c_void_p(dOut), int(n_blocks),
+                                             C.c_void_p(stream)))
+
+    def synchronize(self):
+        self._chk(self._L.asdr_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        return float(self._L.asdr_last_kernel_ms(self._h))
+
+    # ---- batch-only helpers ----
+    def read_status(self):
+        n = self.n_channels
+        a = [np.zeros(n, dtype=np.int32) for _ in range(3)]
+        f = [np.zeros(n, dtype=np.float32) for _ in range(2)]
+        ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        self._chk(self._L.asdr_read_status(self._h, a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip), a[2].ctypes.data_as(ip),
+                                           f[0].ctypes.data_as(fp), f[1].ctypes.data_as(fp)))
+        return {"agc_active": a[0], "nb_detected": a[1], "sam_locked": a[2], "sam_frequency": f[0], "am_carrier": f[1]}
+
+    def enable_taps(self, on=True):
+        self._chk(self._L.asdr_enable_taps(self._h, 1 if on else 0))
+
+    def read_taps(self):
+        t = np.zeros((len(TAPS), self.n_channels, BLOCK), dtype=np.float32)
+        self._chk(self._L.asdr_read_taps(self._h, t.ctypes.data_as(C.POINTER(C.c_float))))
+        return {name: t[i] for i, name in enumerate(TAPS)}
+
+    # ---- reference control surface ----
+    def setDemodMode(self, mode, ch=ALL):
+        return float(self._L.asdr_setDemodMode(self._h, ch, int(mode)))
+
+    def getDemodMode(self, ch=0):
+        return int(self._L.asdr_getDemodMode(self._h, ch))
+
+    def setALSfilterParams(self, m, Lambda, Delay, ch=ALL):
+        self._L.asdr_setALSfilterParams(self._h, ch, int(m), float(Lambda), float(Delay))
+
+    def getAGClookup(self, i, ch=0):
+        return float(self._L.asdr_getAGClookup(self._h, ch, int(i)))
+
+
+def _add_methods():
+    def mk_void(n):
+        def f(self, ch=ALL):
+            getattr(self._L, "asdr_" + n)(self._h, ch)
+        return f
+
+    def mk_set(n, conv):
+        def f(self, v, ch=ALL):
+            getattr(self._L, "asdr_" + n)(self._h, ch, conv(v))
+        return f
+
+    def mk_get(n, conv):
+        def f(self, ch=0):
+            return conv(getattr(self._L, "asdr_" + n)(self._h, ch))
+        return f
+
+    for n in _SETTERS_VOID:
+        setattr(AudioSDRBatch, n, mk_void(n))
+    for n in _SETTERS_F:
+        setattr(AudioSDRBatch, n, mk_set(n, float))
+    for n in _SETTERS_I:
+        setattr(AudioSDRBatch, n, mk_set(n, int))
+    for n in _GETTERS_F:
+        setattr(AudioSDRBatch, n, mk_get(n, float))
+    for n in _GETTERS_I:
+        setattr(AudioSDRBatch, n, mk_get(n, int))
+
+
+_add_methods()

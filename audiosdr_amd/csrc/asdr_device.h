@@ -1,0 +1,112 @@
+/* asdr_device.h -- data layout shared by the host control plane (asdr_host.cpp) and the HIP
+ * kernels (asdr_kernels.hip).  Everything here is plain-old-data living in HBM.
+ *
+ * HBM layout (one row per channel in every array; rows of bulk history are 512 B multiples so
+ * that a 64-lane wave reading "8 lanes x 16 floats" per channel issues 64-B-per-lane dwordx4
+ * loads, fully coalesced within each row):
+ *
+ *   params   ChanParams  [C+1]            96 B  read-only per launch (row C = dummy channel)
+ *   small    ChanSmall   [C+1]           448 B  biquad states, phases, AGC/PLL/NB scalars, ring slots
+ *   nb_hist  float       [C+1][2][2][128]  2 KiB  noise-blanker ring: slot x {I,Q} x sample
+ *   nb_mask  float       [C+1][144]        576 B  mask of (middle block + 10 look-ahead), 138 used
+ *   hil_q    float       [C+1][2][128]     1 KiB  Hilbert Q history ring (2 previous shifted blocks)
+ *   hil_i    float       [C+1][128]        512 B  previous shifted I block (the 128-sample delay)
+ *   als_x    float       [C+1][128]        512 B  previous ALS input block
+ *   als_w    float       [C+1][128]        512 B  ALS coefficients
+ *   agc_tab  float       [T][132]                 pool of distinct AGC gain tables (130 used)
+ */
+#ifndef ASDR_DEVICE_H_
+#define ASDR_DEVICE_H_
+
+#include <stdint.h>
+
+#define ASDR_N 128
+
+/* ChanParams.flags */
+#define ASDR_F_NB_EN        (1u << 0)
+#define ASDR_F_AF_EN        (1u << 1)
+#define ASDR_F_AGC_EN       (1u << 2)
+#define ASDR_F_ALS_EN       (1u << 3)
+#define ASDR_F_ALS_NOTCH    (1u << 4)
+#define ASDR_F_ALS_ADAPTIVE (1u << 5)
+#define ASDR_F_MUTED        (1u << 6)
+
+/* ChanParams.reset: state to re-initialise before the next block (set by setters, consumed by
+ * the reset kernel) */
+#define ASDR_R_IF   (1u << 0) /* IF biquad state -> 0        (setDemodMode, AudioSDR.cpp:191-218) */
+#define ASDR_R_AF   (1u << 1) /* audio biquad state -> 0     (setAudioFilter, AudioSDR.cpp:300-309) */
+#define ASDR_R_NB   (1u << 2) /* NB buffers 0, mask 1        (initBlanker, AudioSDR.cpp:676-682) */
+#define ASDR_R_ALS  (1u << 3) /* ALS taps + history -> 0     (enableALSfilter, AudioSDR.cpp:384-391) */
+#define ASDR_R_IMG  (1u << 4) /* AM image biquad state -> 0  (init, AudioSDR.cpp:178-179) */
+#define ASDR_R_ALL  (1u << 5) /* everything to power-on state (asdr_create) */
+
+typedef struct {
+  uint32_t mode;        /* _mode (uint16 in the reference) */
+  uint32_t flags;
+  uint32_t reset;
+  int32_t if_table;     /* row of asdr_bq_pool for the IF band-pass */
+  int32_t audio_table;  /* row of asdr_bq_pool for the audio filter */
+  int32_t agc_table;    /* row of the AGC table pool */
+  float in_gain_i, in_gain_q;
+  float output_gain;
+  float freq_shift;
+  float nb_threshold;
+  float agc_alpha_att, agc_beta_att, agc_alpha_rel, agc_beta_rel, agc_static_gain;
+  uint32_t agc_hang_count;
+  int32_t als_m, als_delay;
+  float als_lambda;
+  uint32_t pad_[4];
+} ChanParams; /* 24 words = 96 B */
+
+typedef struct {
+  float if_state[2][16];  /* [I,Q][stage][x1,x2,y1,y2]   _IFfilterStateI/Q   AudioSDR.h:191-192 */
+  float img_state[2][16]; /*                             _AMimage_stateI/Q  AudioSDR.h:193-194 */
+  float af_state[16];     /*                             _audio_filter_state AudioSDR.h:195     */
+  float phase_ssb, phase_am;          /* AudioSDR.cpp:43-44 */
+  float nb_avg;                       /* _nb_AvgMag */
+  float am_carrier;                   /* _agc_AMcarrierLevel */
+  float agc_gain, agc_old_abs;        /* _agc_gain, _old_absVal */
+  uint32_t agc_hang_counter;
+  float pll_y_re, pll_y_im, pll_prev_filt;      /* AudioSDR.cpp:690-692 statics */
+  float pll_d0, pll_d1, pll_phase_est, pll_freq; /* delay0, delay1, phase_est, _PLLfreq */
+  uint32_t nb_slot, hil_slot;         /* ring positions (oldest slot) */
+  uint32_t status;                    /* ASDR_S_* bits */
+  uint32_t pad_[15];
+} ChanSmall; /* 80 + 17 + 15 = 112 words = 448 B */
+
+#define ASDR_S_AGC_ACTIVE  (1u << 0) /* _agc_is_active (in-class initialiser: true) */
+#define ASDR_S_NB_DETECTED (1u << 1) /* _nb_impulseDetected */
+#define ASDR_S_PLL_LOCKED  (1u << 2) /* _SAM_PLL_isLocked */
+
+#define ASDR_NB_MASK_ROW 144
+#define ASDR_NB_MASK_USED 138
+#define ASDR_AGC_TAB_ROW 132
+
+/* constants identical for every channel, evaluated once on the host exactly as the reference's
+ * in-class initialisers evaluate them (AudioSDR.h:164-168, 238-239, 249-284) */
+typedef struct {
+  float if_center;              /* 6890.0f */
+  float two_pi_f;               /* (float)(2.0*PI) */
+  float half_pi_f;              /* (float)(0.5*PI) */
+  float phase_inc_unit;         /* two_pi_f / 44100.0f : freq_shifter's twoPI/AUDIO_SAMPLE_RATE_EXACT */
+  float nb_alpha, nb_beta;
+  float pll_b0, pll_b1, pll_a1;
+  float pll_alpha_freq, pll_beta_freq, pll_f_conv, pll_lock_lo, pll_lock_hi;
+} ChainConsts;
+
+typedef struct {
+  const ChanParams *params;
+  ChanSmall *small;
+  float *nb_hist, *nb_mask, *hil_q, *hil_i, *als_x, *als_w;
+  const float *agc_tab;
+  const int32_t *sched;   /* channel index per wave slot, padded to a multiple of 8 with n_channels (dummy) */
+  int32_t n_sched;        /* multiple of 8 */
+  int32_t n_channels;
+  const int16_t *in_i, *in_q;
+  int16_t *out;
+  int32_t n_blocks;       /* blocks per channel in this call (row stride of I/Q/out = n_blocks*128) */
+  float *taps;            /* NULL or [ASDR_N_TAPS][n_channels][128] */
+  ChainConsts k;
+} UpdateArgs;
+
+#endif /* ASDR_DEVICE_H_ */

@@ -1,0 +1,613 @@
+// asdr_host.cpp -- host control plane + C ABI of libasdr_hip.so (see include/asdr.h).
+//
+// Mirrors the reference's `AudioSDR` class surface (SRC/AudioSDRlib/AudioSDR.h:88-156,
+// AudioSDR.cpp:174-757) for a batch of N channels: every setter is a field write on a host-side
+// per-channel record (plus the same derived-parameter arithmetic the reference performs, in the same
+// float/double types), and marks the device parameter block dirty; update() uploads what changed and
+// launches the HIP kernels of asdr_kernels.hip.  There is deliberately no CPU implementation of the
+// signal path here: without a HIP device asdr_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/asdr.h"
+#include "asdr_device.h"
+#include "asdr_tables.h"
+
+extern "C" int asdr_kernels_upload_tables(void);
+extern "C" int asdr_launch_update(const UpdateArgs *a, hipStream_t stream);
+extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int n_rows, hipStream_t stream);
+
+namespace {
+
+constexpr double kPI = 3.1415926535897932384626433832795;  // Arduino.h PI
+constexpr float kFs = 44100.0f;                            // AUDIO_SAMPLE_RATE_EXACT (Teensy 4.x)
+constexpr float kIFcenter = 6890.0f, kBWssb = 3000.0f, kBWcw = 1000.0f, kBWwspr = 1000.0f, kBWam = 8500.0f;  // .h:164-168
+
+thread_local std::string g_err;
+int fail(const std::string &m) { g_err = m; return -1; }
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+// One reference instance's control-plane members (AudioSDR.h:172-246), batch-side naming.
+struct Chan {
+  float in_gain = 1.0f, in_gain_i = 1.0f, in_gain_q = 1.0f, gain_balance = 1.0f;
+  float output_gain = 0.5f, out_gain = 1.0f, current_out_gain = 1.0f;
+  float freq_shift = 0.0f;
+  uint16_t mode = 0;
+  bool muted = true;
+  int16_t current_filter = 0;
+  bool af_en = false;
+  int if_table = ASDR_TBL_IF_SSB, audio_table = ASDR_TBL_AUDIO_BASE + ASDR_audio2700;
+  int16_t als_m = 55, als_delay = 3;
+  float als_lambda = 0.5f;
+  bool als_en = false, als_notch = true, als_adaptive = true;
+  float agc_alpha_att = 0, agc_beta_att = 0, agc_alpha_rel = 0, agc_beta_rel = 0;
+  float agc_attack_ms = 0, agc_release_ms = 0, agc_knee = 0, agc_slope = 0, agc_threshold = 0;
+  float agc_static_gain = 10.0f;
+  float agc_slot129 = 100.0f;  // _agc_hangTime, which is also _agc_gainLookup[129] (.h:219-220)
+  uint32_t agc_hang_count = 0;
+  bool agc_en = true;
+  int agc_table = 0;
+  float nb_threshold = 1.2f;
+  bool nb_en = true;
+};
+
+struct AgcTable {
+  float thr, slope, knee;
+  float v[ASDR_AGC_TAB_ROW];
+};
+
+// log2_approx_f32, AudioSDR.h:483-491
+float log2_approx(float input) {
+  int exponent;
+  float mantissa = frexpf(fabsf(input), &exponent);
+  return (((1.23149591368684f * mantissa - 4.11852516267426f) * mantissa + 6.02197014179219f) * mantissa -
+          3.13396450166353f) + exponent;
+}
+
+// agc_createLookupTable, AudioSDR.cpp:459-480 (130 entries: the loop bound is tableSize + 1)
+void build_agc_table(AgcTable &t) {
+  const float thr = t.thr, slope = t.slope, knee = t.knee;
+  const float lin_lo = expf((float)(2.3025 * ((double)thr - (double)knee / 2.0) / 20.0));
+  const float lin_hi = expf((float)(2.3025 * ((double)thr + (double)knee / 2.0) / 20.0));
+  for (int i = 0; i < 130; i++) {
+    const float input = (float)((double)(float)i / 128.0);
+    const float in_db = (float)(6.026 * (double)log2_approx(input));
+    if (input < lin_lo) {
+      t.v[i] = 1.0f;
+    } else if (input > lin_hi) {
+      const float out_db = thr + (in_db - thr) * slope;
+      t.v[i] = expf((float)(2.3025 * (double)(out_db - in_db) / 20.0));
+    } else {
+      const double u = (double)(in_db - thr) + (double)knee / 2.0;
+      const float out_db = (float)((double)in_db + (((double)slope - 1.0) * u * u) / (2.0 * (double)knee));
+      t.v[i] = expf((float)(2.3025 * (double)(out_db - in_db) / 20.0));
+    }
+  }
+  t.v[130] = t.v[131] = 0.0f;
+}
+
+float time_constant(float ms) {  // AudioSDR.cpp:448/553: exp(log(0.1) / (FS*ms/1000.0))
+  return (float)exp(log(0.1) / ((double)(kFs * ms) / 1000.0));
+}
+
+}  // namespace
+
+struct asdr_batch {
+  int n = 0, device = 0;
+  hipStream_t stream = nullptr;  // used by the host-pointer entry point and by getters
+  std::vector<Chan> ch;          // n + 1 (last = dummy channel used to pad the last wave)
+  std::vector<AgcTable> agc_pool;
+  std::vector<ChanParams> hp;
+  std::vector<uint32_t> reset;
+  std::vector<int32_t> sched;
+  bool params_dirty = true, reset_pending = true, agc_pool_dirty = true;
+  // device
+  ChanParams *d_params = nullptr;
+  ChanSmall *d_small = nullptr;
+  float *d_nb_hist = nullptr, *d_nb_mask = nullptr, *d_hil_q = nullptr, *d_hil_i = nullptr, *d_als_x = nullptr,
+        *d_als_w = nullptr, *d_agc_tab = nullptr, *d_taps = nullptr;
+  size_t agc_tab_cap = 0;
+  int32_t *d_sched = nullptr;
+  uint32_t *d_reset = nullptr;
+  int16_t *d_io[3] = {nullptr, nullptr, nullptr};
+  size_t io_cap = 0;
+  bool taps_on = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  hipStream_t last_stream = nullptr;
+  ChainConsts k{};
+};
+
+namespace {
+
+int find_agc_table(asdr_batch *b, float thr, float slope, float knee) {
+  for (size_t i = 0; i < b->agc_pool.size(); i++) {
+    const AgcTable &t = b->agc_pool[i];
+    if (memcmp(&t.thr, &thr, 4) == 0 && memcmp(&t.slope, &slope, 4) == 0 && memcmp(&t.knee, &knee, 4) == 0) return (int)i;
+  }
+  AgcTable t;
+  t.thr = thr; t.slope = slope; t.knee = knee;
+  build_agc_table(t);
+  b->agc_pool.push_back(t);
+  b->agc_pool_dirty = true;
+  return (int)b->agc_pool.size() - 1;
+}
+
+void rebuild_agc(asdr_batch *b, Chan &c) {  // agc_createLookupTable(): also clobbers _agc_hangTime's storage
+  c.agc_table = find_agc_table(b, c.agc_threshold, c.agc_slope, c.agc_knee);
+  c.agc_slot129 = b->agc_pool[c.agc_table].v[129];
+}
+
+// setDemodMode, AudioSDR.cpp:187-222
+float set_mode(asdr_batch *b, int idx, int new_mode) {
+  Chan &c = b->ch[idx];
+  c.mode = (uint16_t)new_mode;
+  int tbl = -1;
+  if (c.mode == ASDR_USBmode) { c.freq_shift = (float)((double)kIFcenter - (double)kBWssb / 2.0); tbl = ASDR_TBL_IF_SSB; }
+  else if (c.mode == ASDR_LSBmode) { c.freq_shift = (float)((double)kIFcenter + (double)kBWssb / 2.0); tbl = ASDR_TBL_IF_SSB; }
+  else if (c.mode == ASDR_WSPRmode) { c.freq_shift = (float)((double)kIFcenter - (double)kBWssb / 2.0); tbl = ASDR_TBL_IF_WSPR; }
+  else if (c.mode == ASDR_CW_USBmode) { c.freq_shift = (float)((double)kIFcenter - (double)kBWcw / 2.0); tbl = ASDR_TBL_IF_CW; }
+  else if (c.mode == ASDR_CW_LSBmode) { c.freq_shift = (float)((double)kIFcenter + (double)kBWcw / 2.0); tbl = ASDR_TBL_IF_CW; }
+  else if (c.mode == ASDR_AMmode || c.mode == ASDR_SAMmode) { c.freq_shift = kIFcenter; tbl = ASDR_TBL_IF_AM; }
+  if (tbl >= 0) { c.if_table = tbl; b->reset[idx] |= ASDR_R_IF; b->reset_pending = true; }
+  return c.freq_shift;
+}
+
+// agc_init, AudioSDR.cpp:439-457
+void agc_init(asdr_batch *b, Chan &c) {
+  c.agc_threshold = -60.0f; c.agc_slope = 0.1f; c.agc_knee = 2.0f;
+  c.agc_attack_ms = 5.0f; c.agc_release_ms = 500.0f;
+  c.agc_slot129 = 100.0f;
+  c.agc_hang_count = (uint32_t)((double)kFs * ((double)c.agc_slot129 / 1000.0));
+  c.agc_alpha_att = time_constant(c.agc_attack_ms);
+  c.agc_beta_att = (float)(1.0 - (double)c.agc_alpha_att);
+  c.agc_alpha_rel = time_constant(c.agc_release_ms);
+  c.agc_beta_rel = (float)(1.0 - (double)c.agc_alpha_rel);
+  c.agc_en = true;
+  rebuild_agc(b, c);
+}
+
+// init(), AudioSDR.cpp:174-185
+void chan_init(asdr_batch *b, int idx) {
+  Chan &c = b->ch[idx];
+  c.audio_table = ASDR_TBL_AUDIO_BASE + ASDR_audio2700;
+  c.if_table = ASDR_TBL_IF_SSB;
+  b->reset[idx] |= ASDR_R_AF | ASDR_R_IF | ASDR_R_IMG | ASDR_R_NB;
+  agc_init(b, c);
+  set_mode(b, idx, ASDR_LSBmode);
+  c.muted = false;
+  b->reset_pending = true;
+}
+
+void fill_params(const Chan &c, ChanParams &p) {
+  memset(&p, 0, sizeof p);
+  p.mode = c.mode;
+  p.flags = (c.nb_en ? ASDR_F_NB_EN : 0u) | (c.af_en ? ASDR_F_AF_EN : 0u) | (c.agc_en ? ASDR_F_AGC_EN : 0u) |
+            (c.als_en ? ASDR_F_ALS_EN : 0u) | (c.als_notch ? ASDR_F_ALS_NOTCH : 0u) |
+            (c.als_adaptive ? ASDR_F_ALS_ADAPTIVE : 0u) | (c.muted ? ASDR_F_MUTED : 0u);
+  p.if_table = c.if_table; p.audio_table = c.audio_table; p.agc_table = c.agc_table;
+  p.in_gain_i = c.in_gain_i; p.in_gain_q = c.in_gain_q; p.output_gain = c.output_gain;
+  p.freq_shift = c.freq_shift; p.nb_threshold = c.nb_threshold;
+  p.agc_alpha_att = c.agc_alpha_att; p.agc_beta_att = c.agc_beta_att;
+  p.agc_alpha_rel = c.agc_alpha_rel; p.agc_beta_rel = c.agc_beta_rel;
+  p.agc_static_gain = c.agc_static_gain; p.agc_hang_count = c.agc_hang_count;
+  p.als_m = c.als_m; p.als_delay = c.als_delay; p.als_lambda = c.als_lambda;
+}
+
+// Wave scheduling: channels with the same (mode, enables, tables) are grouped so that a wave's 8 channels
+// take the same branches.  Rows of I/Q/out and of every state array are per channel, so the grouping
+// costs nothing in coalescing.
+uint64_t sched_key(const ChanParams &p) {
+  return ((uint64_t)(p.mode & 0xFFFF) << 40) | ((uint64_t)(p.flags & 0xFF) << 32) | ((uint64_t)(p.if_table & 0xFF) << 24) |
+         ((uint64_t)(p.audio_table & 0xFF) << 16) | (uint64_t)(p.agc_table & 0xFFFF);
+}
+
+int flush(asdr_batch *b, hipStream_t stream) {
+  const int rows = b->n + 1;
+  if (b->agc_pool_dirty) {
+    const size_t need = b->agc_pool.size() * ASDR_AGC_TAB_ROW;
+    if (need > b->agc_tab_cap) {
+      HIPCHK(hipStreamSynchronize(stream));
+      if (b->d_agc_tab) HIPCHK(hipFree(b->d_agc_tab));
+      b->agc_tab_cap = need * 2;
+      HIPCHK(hipMalloc(&b->d_agc_tab, b->agc_tab_cap * sizeof(float)));
+    }
+    std::vector<float> flat(need);
+    for (size_t i = 0; i < b->agc_pool.size(); i++) memcpy(&flat[i * ASDR_AGC_TAB_ROW], b->agc_pool[i].v, sizeof(float) * ASDR_AGC_TAB_ROW);
+    HIPCHK(hipMemcpyAsync(b->d_agc_tab, flat.data(), need * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));  // `flat` is a temporary
+    b->agc_pool_dirty = false;
+  }
+  if (b->params_dirty) {
+    for (int i = 0; i < rows; i++) fill_params(b->ch[i], b->hp[i]);
+    std::vector<int32_t> order(b->n);
+    for (int i = 0; i < b->n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t x, int32_t y) { return sched_key(b->hp[x]) < sched_key(b->hp[y]); });
+    const int n_sched = ((b->n + 7) / 8) * 8;
+    b->sched.assign(n_sched, b->n);
+    std::copy(order.begin(), order.end(), b->sched.begin());
+    HIPCHK(hipMemcpyAsync(b->d_params, b->hp.data(), rows * sizeof(ChanParams), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(b->d_sched, b->sched.data(), n_sched * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));  // host vectors may be rewritten by the next setter
+    b->params_dirty = false;
+  }
+  return 0;
+}
+
+void fill_args(asdr_batch *b, UpdateArgs &a) {
+  memset(&a, 0, sizeof a);
+  a.params = b->d_params; a.small = b->d_small;
+  a.nb_hist = b->d_nb_hist; a.nb_mask = b->d_nb_mask; a.hil_q = b->d_hil_q; a.hil_i = b->d_hil_i;
+  a.als_x = b->d_als_x; a.als_w = b->d_als_w; a.agc_tab = b->d_agc_tab;
+  a.sched = b->d_sched; a.n_sched = ((b->n + 7) / 8) * 8; a.n_channels = b->n;
+  a.taps = b->taps_on ? b->d_taps : nullptr;
+  a.k = b->k;
+}
+
+int apply_resets(asdr_batch *b, hipStream_t stream) {
+  if (!b->reset_pending) return 0;
+  const int rows = b->n + 1;
+  HIPCHK(hipMemcpyAsync(b->d_reset, b->reset.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  UpdateArgs a;
+  fill_args(b, a);
+  if (asdr_launch_reset(&a, b->d_reset, rows, stream) != 0) return fail("reset kernel launch failed");
+  HIPCHK(hipStreamSynchronize(stream));
+  std::fill(b->reset.begin(), b->reset.end(), 0u);
+  b->reset_pending = false;
+  return 0;
+}
+
+template <typename F>
+void each(asdr_batch *b, int ch, F f) {
+  if (!b) return;
+  if (ch == ASDR_ALL) { for (int i = 0; i < b->n; i++) f(i, b->ch[i]); }
+  else if (ch >= 0 && ch < b->n) f(ch, b->ch[ch]);
+  else return;
+  b->params_dirty = true;
+}
+const Chan *get(asdr_batch *b, int ch) { return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr; }
+
+int read_small(asdr_batch *b, int ch, ChanSmall &s) {
+  if (!b || ch < 0 || ch >= b->n) return fail("bad channel");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (apply_resets(b, b->stream) != 0) return -1;
+  HIPCHK(hipMemcpy(&s, b->d_small + ch, sizeof s, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *asdr_last_error(void) { return g_err.c_str(); }
+const char *asdr_version(void) { return "asdr-hip 0.1 (gfx950, wave64, -ffp-contract=off)"; }
+
+asdr_batch_t *asdr_create(int n_channels, int device) {
+  if (n_channels <= 0) { fail("n_channels must be > 0"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fail("no HIP device: libasdr_hip has no CPU path"); return nullptr; }
+  if (device < 0 || device >= ndev) { fail("bad device ordinal"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+  asdr_batch *b = new asdr_batch();
+  b->n = n_channels; b->device = device;
+  const size_t rows = (size_t)n_channels + 1;
+  bool ok = true;
+  auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
+  alloc((void **)&b->d_params, rows * sizeof(ChanParams));
+  alloc((void **)&b->d_small, rows * sizeof(ChanSmall));
+  alloc((void **)&b->d_nb_hist, rows * 512 * sizeof(float));
+  alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(float));
+  alloc((void **)&b->d_hil_q, rows * 256 * sizeof(float));
+  alloc((void **)&b->d_hil_i, rows * 128 * sizeof(float));
+  alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
+  alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
+  alloc((void **)&b->d_sched, (rows + 8) * sizeof(int32_t));
+  alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
+  if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
+  if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
+  if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
+  if (ok && asdr_kernels_upload_tables() != 0) ok = false;
+  if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
+
+  // constants shared by all channels: in-class initialisers of AudioSDR.h:238-239, 249-284
+  ChainConsts &k = b->k;
+  k.if_center = kIFcenter;
+  k.two_pi_f = (float)(2.0 * kPI);
+  k.half_pi_f = (float)(0.5 * kPI);
+  k.phase_inc_unit = k.two_pi_f / kFs;
+  k.nb_alpha = 0.995f;
+  k.nb_beta = (float)(1.0 - (double)k.nb_alpha);
+  {
+    const float wn = 0.07f, zeta = 0.707f, Ka = 1000.f;
+    const float tau1 = Ka / (wn * wn);
+    const float tau2 = 2 * zeta / wn;
+    k.pll_b0 = (float)((double)(2 * Ka / tau1) * (1.0 + 2.0 * (double)tau2));
+    k.pll_b1 = (float)((double)(2 * Ka / tau1) * (1.0 - 2.0 * (double)tau2));
+    k.pll_a1 = -1.0f;
+  }
+  k.pll_alpha_freq = 0.995f;
+  k.pll_beta_freq = (float)(1.0 - (double)k.pll_alpha_freq);
+  k.pll_f_conv = kFs / k.two_pi_f;
+  k.pll_lock_lo = (float)((double)kIFcenter - 1000.0);
+  k.pll_lock_hi = (float)((double)kIFcenter + 1000.0);
+
+  b->ch.assign(rows, Chan());
+  b->hp.resize(rows);
+  b->reset.assign(rows, ASDR_R_ALL);
+  for (size_t i = 0; i < rows; i++) chan_init(b, (int)i);  // constructor -> init()
+  b->params_dirty = true; b->reset_pending = true;
+  return b;
+}
+
+void asdr_destroy(asdr_batch_t *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  hipDeviceSynchronize();
+  void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
+                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_io[0], b->d_io[1], b->d_io[2]};
+  for (void *p : ptrs) if (p) hipFree(p);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int asdr_n_channels(const asdr_batch_t *b) { return b ? b->n : 0; }
+
+int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks, void *stream_) {
+  if (!b) return fail("null batch");
+  if (!dI || !dQ) return 0;  // missing-input guard, AudioSDR.cpp:48-56
+  if (!dOut) return fail("null output");
+  if (n_blocks <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(hipSetDevice(b->device));
+  if (flush(b, stream) != 0) return -1;
+  if (apply_resets(b, stream) != 0) return -1;
+  UpdateArgs a;
+  fill_args(b, a);
+  a.in_i = dI; a.in_q = dQ; a.out = dOut; a.n_blocks = n_blocks;
+  HIPCHK(hipEventRecord(b->ev0, stream));
+  if (asdr_launch_update(&a, stream) != 0) return fail("update kernel launch failed");
+  HIPCHK(hipEventRecord(b->ev1, stream));
+  b->ev_valid = true;
+  b->last_stream = stream;
+  return 0;
+}
+
+int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
+  if (!b) return fail("null batch");
+  if (!I || !Q) return 0;
+  if (!out) return fail("null output");
+  if (n_blocks <= 0) return 0;
+  HIPCHK(hipSetDevice(b->device));
+  const size_t count = (size_t)b->n * n_blocks * ASDR_N;
+  if (count > b->io_cap) {
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int i = 0; i < 3; i++) {
+      if (b->d_io[i]) HIPCHK(hipFree(b->d_io[i]));
+      b->d_io[i] = nullptr;
+      HIPCHK(hipMalloc(&b->d_io[i], count * sizeof(int16_t)));
+    }
+    b->io_cap = count;
+  }
+  HIPCHK(hipMemcpyAsync(b->d_io[0], I, count * sizeof(int16_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_io[1], Q, count * sizeof(int16_t), hipMemcpyHostToDevice, b->stream));
+  if (asdr_update_device(b, b->d_io[0], b->d_io[1], b->d_io[2], n_blocks, b->stream) != 0) return -1;
+  HIPCHK(hipMemcpyAsync(out, b->d_io[2], count * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int asdr_synchronize(asdr_batch_t *b) {
+  if (!b) return fail("null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+float asdr_last_kernel_ms(asdr_batch_t *b) {
+  if (!b || !b->ev_valid) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0f;
+  if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+// ---- general ------------------------------------------------------------------------------------------
+void asdr_init(asdr_batch_t *b, int ch) { each(b, ch, [&](int i, Chan &) { chan_init(b, i); }); }
+void asdr_setMute(asdr_batch_t *b, int ch, int muted) {  // .cpp:249-253
+  each(b, ch, [&](int, Chan &c) { c.muted = muted != 0; c.current_out_gain = c.muted ? 0.0f : c.out_gain; });
+}
+int asdr_getMute(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->muted : 0; }
+void asdr_setInputGain(asdr_batch_t *b, int ch, float g) {  // .cpp:232-238
+  if (g > 10.0) g = 10.0f;
+  if (g < 0.0) g = 0.0f;
+  each(b, ch, [&](int, Chan &c) { c.in_gain = g; c.in_gain_i = c.in_gain * c.gain_balance; c.in_gain_q = c.in_gain; });
+}
+void asdr_setIQgainBalance(asdr_batch_t *b, int ch, float balance) {  // .cpp:240-244 (a local shadows _gainBalance)
+  const float gb = sqrtf(balance);
+  each(b, ch, [&](int, Chan &c) { c.in_gain_i = c.in_gain * gb; c.in_gain_q = c.in_gain / gb; });
+}
+void asdr_setOutputGain(asdr_batch_t *b, int ch, float g) { each(b, ch, [&](int, Chan &c) { c.output_gain = g; }); }
+float asdr_setDemodMode(asdr_batch_t *b, int ch, int mode) {
+  float r = 0.0f;
+  bool first = true;
+  each(b, ch, [&](int i, Chan &) { float v = set_mode(b, i, mode); if (first) { r = v; first = false; } });
+  return r;
+}
+int16_t asdr_getDemodMode(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? (int16_t)c->mode : 0; }
+float asdr_getTuningOffset(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->freq_shift : 0.0f; }
+float asdr_getBPFlower(asdr_batch_t *b, int ch) {  // .cpp:259-265
+  const Chan *c = get(b, ch);
+  if (!c) return 0.0f;
+  const uint16_t m = c->mode;
+  if (m == ASDR_USBmode || m == ASDR_LSBmode) return (float)((double)kIFcenter - (double)kBWssb / 2.0);
+  else if (m == ASDR_CW_USBmode || m == ASDR_CW_LSBmode) return (float)((double)kIFcenter - (double)kBWcw / 2.0);
+  else if (m == ASDR_AMmode || m == ASDR_SAMmode) return (float)((double)kIFcenter - (double)kBWam / 2.0);
+  else if (m == ASDR_WSPRmode) return (float)((double)kIFcenter - (double)kBWwspr / 2.0);
+  return 0.0f;
+}
+float asdr_getBPFupper(asdr_batch_t *b, int ch) {  // .cpp:267-273 (WSPR: `+-` at :271)
+  const Chan *c = get(b, ch);
+  if (!c) return 0.0f;
+  const uint16_t m = c->mode;
+  if (m == ASDR_USBmode || m == ASDR_LSBmode) return (float)((double)kIFcenter + (double)kBWssb / 2.0);
+  else if (m == ASDR_CW_USBmode || m == ASDR_CW_LSBmode) return (float)((double)kIFcenter + (double)kBWcw / 2.0);
+  else if (m == ASDR_AMmode || m == ASDR_SAMmode) return (float)((double)kIFcenter + (double)kBWam / 2.0);
+  else if (m == ASDR_WSPRmode) return (float)((double)kIFcenter + -((double)kBWwspr / 2.0));
+  return 0.0f;
+}
+
+// ---- audio filter ----------------------------------------------------------------------------------------
+void asdr_enableAudioFilter(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.af_en = true; }); }
+void asdr_disableAudioFilter(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.af_en = false; }); }
+void asdr_setAudioFilter(asdr_batch_t *b, int ch, int filter) {  // .cpp:298-311
+  each(b, ch, [&](int i, Chan &c) {
+    if (filter == ASDR_audioBypass) c.af_en = false;
+    else if (filter >= ASDR_audioAM && filter <= ASDR_audio3300) {
+      c.audio_table = ASDR_TBL_AUDIO_BASE + filter;
+      b->reset[i] |= ASDR_R_AF; b->reset_pending = true;
+    }
+    c.current_filter = (int16_t)filter;
+  });
+}
+int asdr_getAudioFilter(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->current_filter : 0; }
+
+// ---- ALS ---------------------------------------------------------------------------------------------------
+void asdr_enableALSfilter(asdr_batch_t *b, int ch) {  // .cpp:384-391
+  each(b, ch, [&](int i, Chan &c) { c.als_en = true; b->reset[i] |= ASDR_R_ALS; b->reset_pending = true; });
+}
+void asdr_disableALSfilter(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_en = false; }); }
+void asdr_setALSfilterNotch(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_notch = true; }); }
+void asdr_setALSfilterPeak(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_notch = false; }); }
+void asdr_setALSfilterAdaptive(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_adaptive = true; }); }
+void asdr_setALSfilterStatic(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_adaptive = false; }); }
+void asdr_setALSfilterParams(asdr_batch_t *b, int ch, unsigned int m, float lambda, float delay) {  // .cpp:393-398
+  each(b, ch, [&](int, Chan &c) {
+    c.als_m = (int16_t)m;
+    if (c.als_m >= ASDR_N) c.als_m = ASDR_N;
+    c.als_lambda = lambda;
+    c.als_delay = (int16_t)delay;
+  });
+}
+int asdr_ALSfilterIsEnabled(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->als_en : 0; }
+int asdr_ALSfilterIsNotch(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->als_notch : 0; }
+int asdr_ALSfilterIsPeak(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? !c->als_notch : 0; }
+int asdr_ALSfilterIsAdaptive(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->als_adaptive : 0; }
+
+// ---- AGC ---------------------------------------------------------------------------------------------------
+void asdr_enableAGC(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.agc_en = true; }); }
+void asdr_disableAGC(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.agc_en = false; }); }
+int asdr_AGCisEnabled(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->agc_en : 0; }
+void asdr_setAGCthreshold(asdr_batch_t *b, int ch, float v) { each(b, ch, [&](int, Chan &c) { c.agc_threshold = v; rebuild_agc(b, c); }); }
+void asdr_setAGCslope(asdr_batch_t *b, int ch, float v) { each(b, ch, [&](int, Chan &c) { c.agc_slope = v; rebuild_agc(b, c); }); }
+void asdr_setAGCkneeWidth(asdr_batch_t *b, int ch, float v) { each(b, ch, [&](int, Chan &c) { c.agc_knee = v; rebuild_agc(b, c); }); }
+void asdr_setAGCattackTime(asdr_batch_t *b, int ch, float ms) {  // .cpp:551-555
+  const float al = time_constant(ms), be = (float)(1.0 - (double)al);
+  each(b, ch, [&](int, Chan &c) { c.agc_attack_ms = ms; c.agc_alpha_att = al; c.agc_beta_att = be; });
+}
+void asdr_setAGCreleaseTime(asdr_batch_t *b, int ch, float ms) {  // .cpp:557-561
+  const float al = time_constant(ms), be = (float)(1.0 - (double)al);
+  each(b, ch, [&](int, Chan &c) { c.agc_release_ms = ms; c.agc_alpha_rel = al; c.agc_beta_rel = be; });
+}
+void asdr_setAGChangTime(asdr_batch_t *b, int ch, float ms) {  // .cpp:563-566: float product, then / 1000.0
+  const uint32_t cnt = (uint32_t)((double)(ms * kFs) / 1000.0);
+  each(b, ch, [&](int, Chan &c) { c.agc_slot129 = ms; c.agc_hang_count = cnt; });
+}
+void asdr_setAGCstaticGain(asdr_batch_t *b, int ch, float g) { each(b, ch, [&](int, Chan &c) { c.agc_static_gain = g; }); }
+void asdr_setAGCmode(asdr_batch_t *b, int ch, int mode) {  // .cpp:524-544
+  mode = (int16_t)mode;
+  if (mode == ASDR_AGCoff) asdr_disableAGC(b, ch);
+  else if (mode == ASDR_AGCfast) { asdr_setAGCattackTime(b, ch, 2.0f); asdr_setAGCreleaseTime(b, ch, 100.0f); asdr_setAGChangTime(b, ch, 100.0f); asdr_enableAGC(b, ch); }
+  else if (mode == ASDR_AGCmedium) { asdr_setAGCattackTime(b, ch, 5.0f); asdr_setAGCreleaseTime(b, ch, 250.0f); asdr_setAGChangTime(b, ch, 500.0f); asdr_enableAGC(b, ch); }
+  else if (mode == ASDR_AGCslow) { asdr_setAGCattackTime(b, ch, 10.0f); asdr_setAGCreleaseTime(b, ch, 500.0f); asdr_setAGChangTime(b, ch, 2000.0f); asdr_enableAGC(b, ch); }
+}
+#define GETF(name, field) float asdr_##name(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->field : 0.0f; }
+GETF(getAGCthreshold, agc_threshold)
+GETF(getAGCslope, agc_slope)
+GETF(getAGCkneeWidth, agc_knee)
+GETF(getAGCattack, agc_attack_ms)
+GETF(getAGCrelease, agc_release_ms)
+GETF(getAAGalphaAttack, agc_alpha_att)
+GETF(getAGCbetaAttack, agc_beta_att)
+GETF(getAGCalphaRelease, agc_alpha_rel)
+GETF(getAGCbetaRelease, agc_beta_rel)
+GETF(getAGCstaticGain, agc_static_gain)
+float asdr_getAGClookup(asdr_batch_t *b, int ch, int i) {
+  const Chan *c = get(b, ch);
+  if (!c || i < 0 || i > 129) return 0.0f;
+  return (i == 129) ? c->agc_slot129 : b->agc_pool[c->agc_table].v[i];
+}
+
+// ---- noise blanker ------------------------------------------------------------------------------------------
+void asdr_enableNoiseBlanker(asdr_batch_t *b, int ch) {
+  each(b, ch, [&](int i, Chan &c) { c.nb_en = true; b->reset[i] |= ASDR_R_NB; b->reset_pending = true; });
+}
+void asdr_disableNoiseBlanker(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.nb_en = false; }); }
+void asdr_setNoiseBlankerThreshold(asdr_batch_t *b, int ch, float r) {
+  each(b, ch, [&](int i, Chan &c) { c.nb_threshold = r; b->reset[i] |= ASDR_R_NB; b->reset_pending = true; });
+}
+void asdr_setNoiseBlankerThresholdDb(asdr_batch_t *b, int ch, float db) {  // .cpp:671-674
+  const float r = powf(10.0f, (float)((double)db / 20.0));
+  each(b, ch, [&](int i, Chan &c) { c.nb_threshold = r; b->reset[i] |= ASDR_R_NB; b->reset_pending = true; });
+}
+int asdr_NoiseBlankerisEnabled(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->nb_en : 0; }
+
+// ---- getters that read hot-path state ------------------------------------------------------------------------
+int asdr_AGCisActive(asdr_batch_t *b, int ch) { ChanSmall s; return read_small(b, ch, s) == 0 ? ((s.status & ASDR_S_AGC_ACTIVE) != 0) : 0; }
+int asdr_NoiseBlankerDetection(asdr_batch_t *b, int ch) { ChanSmall s; return read_small(b, ch, s) == 0 ? ((s.status & ASDR_S_NB_DETECTED) != 0) : 0; }
+int asdr_getSAMphaseLockStatus(asdr_batch_t *b, int ch) { ChanSmall s; return read_small(b, ch, s) == 0 ? ((s.status & ASDR_S_PLL_LOCKED) != 0) : 0; }
+float asdr_getSAMfrequency(asdr_batch_t *b, int ch) { ChanSmall s; return read_small(b, ch, s) == 0 ? s.pll_freq : 0.0f; }
+float asdr_getAMcarrierLevel(asdr_batch_t *b, int ch) { ChanSmall s; return read_small(b, ch, s) == 0 ? s.am_carrier : 0.0f; }
+
+int asdr_read_status(asdr_batch_t *b, int32_t *agc_active, int32_t *nb_detected, int32_t *sam_locked, float *sam_frequency,
+                     float *am_carrier) {
+  if (!b) return fail("null batch");
+  ChanSmall probe;
+  if (read_small(b, 0, probe) != 0) return -1;  // synchronises + applies pending resets
+  std::vector<ChanSmall> all(b->n);
+  HIPCHK(hipMemcpy(all.data(), b->d_small, (size_t)b->n * sizeof(ChanSmall), hipMemcpyDeviceToHost));
+  for (int i = 0; i < b->n; i++) {
+    if (agc_active) agc_active[i] = (all[i].status & ASDR_S_AGC_ACTIVE) != 0;
+    if (nb_detected) nb_detected[i] = (all[i].status & ASDR_S_NB_DETECTED) != 0;
+    if (sam_locked) sam_locked[i] = (all[i].status & ASDR_S_PLL_LOCKED) != 0;
+    if (sam_frequency) sam_frequency[i] = all[i].pll_freq;
+    if (am_carrier) am_carrier[i] = all[i].am_carrier;
+  }
+  return 0;
+}
+
+int asdr_enable_taps(asdr_batch_t *b, int on) {
+  if (!b) return fail("null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (on && !b->d_taps) {
+    const size_t bytes = (size_t)ASDR_N_TAPS * b->n * ASDR_N * sizeof(float);
+    HIPCHK(hipMalloc(&b->d_taps, bytes));
+    HIPCHK(hipMemset(b->d_taps, 0, bytes));
+  }
+  b->taps_on = on != 0;
+  return 0;
+}
+
+int asdr_read_taps(asdr_batch_t *b, float *dst) {
+  if (!b || !b->d_taps || !dst) return fail("taps not enabled");
+  if (asdr_synchronize(b) != 0) return -1;
+  HIPCHK(hipMemcpy(dst, b->d_taps, (size_t)ASDR_N_TAPS * b->n * ASDR_N * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

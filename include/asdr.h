@@ -1,0 +1,159 @@
+/* asdr.h -- C ABI of libasdr_hip.so: batched AudioSDR::update() on AMD Instinct MI355X (gfx950).
+ *
+ * One `asdr_batch_t` holds N independent channels; one channel == one instance of the reference's
+ * `class AudioSDR : public AudioStream` (/root/reference/SRC/AudioSDRlib/AudioSDR.h:75-156).
+ * Every entry point below names the reference interface it replaces.  Plain pointers and sizes
+ * only; no C++ or torch types.  There is NO CPU path: the library needs a HIP device.
+ *
+ * Conventions
+ *  - `ch` selects a channel 0..N-1; `ch == ASDR_ALL` (-1) applies a setter to every channel.
+ *    Getters need a real channel index.
+ *  - Setters take effect at the next asdr_update*() call (the reference's setters run in loop()
+ *    context between audio interrupts; SURVEY.md 5 "race detection").
+ *  - Enumerators keep the reference's integer values (AudioSDR.h:44-71).
+ *  - Status getters that read hot-path state (AGCisActive, NoiseBlankerDetection, SAM lock/frequency,
+ *    AM carrier level) synchronise with the batch's stream and read device memory.
+ *  - Return codes: 0 = ok, <0 = error (asdr_last_error() gives text).  Setters mirror the
+ *    reference's void/float returns and its (non-)clamping.
+ *  - Not thread-safe per batch; use one batch per GPU / per host thread.
+ */
+#ifndef ASDR_H_
+#define ASDR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASDR_BLOCK_SAMPLES 128 /* AUDIO_BLOCK_SAMPLES; AudioSDR.h:73 n_block */
+#define ASDR_ALL (-1)
+
+/* demodulation modes, AudioSDR.h:44-50 */
+enum { ASDR_LSBmode = 0, ASDR_USBmode = 1, ASDR_CW_LSBmode = 2, ASDR_CW_USBmode = 3, ASDR_AMmode = 4,
+       ASDR_SAMmode = 5, ASDR_WSPRmode = 6 };
+/* audio filters, AudioSDR.h:56-66 */
+enum { ASDR_audioAM = 0, ASDR_audioCW = 1, ASDR_audioWSPR = 2, ASDR_audio2100 = 3, ASDR_audio2300 = 4,
+       ASDR_audio2500 = 5, ASDR_audio2700 = 6, ASDR_audio2900 = 7, ASDR_audio3100 = 8, ASDR_audio3300 = 9,
+       ASDR_audioBypass = 10 };
+/* AGC presets, AudioSDR.h:68-71 */
+enum { ASDR_AGCoff = 0, ASDR_AGCfast = 1, ASDR_AGCmedium = 2, ASDR_AGCslow = 3 };
+
+typedef struct asdr_batch asdr_batch_t;
+
+/* ---- lifetime: replaces N x `AudioSDR sdr;` (constructor AudioSDR.h:77-79 -> init() AudioSDR.cpp:174-185).
+ * `device` is a HIP device ordinal.  Returns NULL on failure. */
+asdr_batch_t *asdr_create(int n_channels, int device);
+void asdr_destroy(asdr_batch_t *b);
+const char *asdr_last_error(void);
+int asdr_n_channels(const asdr_batch_t *b);
+
+/* ---- the hot path: replaces AudioSDR::update() (AudioSDR.cpp:39-168), called once per 128-sample
+ * block per instance by the Teensy audio interrupt with two int16 blocks in (receiveWritable(0/1),
+ * :46-47) and one mono int16 block out (transmit, :164-165).
+ * Layout of I, Q and out: [channel][block][128] int16, contiguous (row = 256 B).  n_blocks >= 1
+ * consecutive blocks per channel are processed in order in one call.
+ *  asdr_update        : host pointers; copies in, runs, copies out, synchronises.
+ *  asdr_update_device : device pointers (already resident in HBM); asynchronous on `stream`
+ *                       (a hipStream_t; NULL = the null stream).  Buffers must stay valid until
+ *                       the stream reaches this point.
+ * A NULL I or Q mirrors the reference's missing-input guard (AudioSDR.cpp:48-56): nothing is
+ * processed, no state advances, out is untouched, return 0. */
+int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks);
+int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
+                       void *stream);
+int asdr_synchronize(asdr_batch_t *b);
+
+/* ---- general (AudioSDR.h:88-97; AudioSDR.cpp:174-273) */
+void asdr_init(asdr_batch_t *b, int ch);                              /* init()            .cpp:174 */
+void asdr_setMute(asdr_batch_t *b, int ch, int muted);                /* setMute           .cpp:249 */
+int asdr_getMute(asdr_batch_t *b, int ch);                            /* getMute           .cpp:255 */
+void asdr_setInputGain(asdr_batch_t *b, int ch, float gain);          /* setInputGain      .cpp:232 */
+void asdr_setIQgainBalance(asdr_batch_t *b, int ch, float balance);   /* setIQgainBalance  .cpp:240 */
+void asdr_setOutputGain(asdr_batch_t *b, int ch, float gain);         /* setOutputGain     .cpp:245 */
+float asdr_setDemodMode(asdr_batch_t *b, int ch, int mode);           /* setDemodMode      .cpp:187; returns the
+                                                                         tuning offset (of channel 0 for ASDR_ALL) */
+int16_t asdr_getDemodMode(asdr_batch_t *b, int ch);                   /* getDemodMode      .cpp:228 */
+float asdr_getTuningOffset(asdr_batch_t *b, int ch);                  /* getTuningOffset   .cpp:224 */
+float asdr_getBPFlower(asdr_batch_t *b, int ch);                      /* getBPFlower       .cpp:259 */
+float asdr_getBPFupper(asdr_batch_t *b, int ch);                      /* getBPFupper       .cpp:267 */
+
+/* ---- IIR audio output filter (AudioSDR.h:100-104; AudioSDR.cpp:289-311) */
+void asdr_enableAudioFilter(asdr_batch_t *b, int ch);
+void asdr_disableAudioFilter(asdr_batch_t *b, int ch);
+void asdr_setAudioFilter(asdr_batch_t *b, int ch, int filter);
+int asdr_getAudioFilter(asdr_batch_t *b, int ch);
+
+/* ---- ALS notch/peak filter (AudioSDR.h:107-117; AudioSDR.cpp:356-398) */
+void asdr_enableALSfilter(asdr_batch_t *b, int ch);
+void asdr_disableALSfilter(asdr_batch_t *b, int ch);
+void asdr_setALSfilterNotch(asdr_batch_t *b, int ch);
+void asdr_setALSfilterPeak(asdr_batch_t *b, int ch);
+void asdr_setALSfilterAdaptive(asdr_batch_t *b, int ch);
+void asdr_setALSfilterStatic(asdr_batch_t *b, int ch);
+void asdr_setALSfilterParams(asdr_batch_t *b, int ch, unsigned int m, float lambda, float delay);
+int asdr_ALSfilterIsEnabled(asdr_batch_t *b, int ch);
+int asdr_ALSfilterIsNotch(asdr_batch_t *b, int ch);
+int asdr_ALSfilterIsPeak(asdr_batch_t *b, int ch);
+int asdr_ALSfilterIsAdaptive(asdr_batch_t *b, int ch);
+
+/* ---- AGC (AudioSDR.h:120-144; AudioSDR.cpp:495-600) */
+void asdr_enableAGC(asdr_batch_t *b, int ch);
+void asdr_disableAGC(asdr_batch_t *b, int ch);
+int asdr_AGCisEnabled(asdr_batch_t *b, int ch);
+int asdr_AGCisActive(asdr_batch_t *b, int ch);               /* reads device state */
+void asdr_setAGCthreshold(asdr_batch_t *b, int ch, float db);
+void asdr_setAGCslope(asdr_batch_t *b, int ch, float slope);
+void asdr_setAGCmode(asdr_batch_t *b, int ch, int mode);
+void asdr_setAGCkneeWidth(asdr_batch_t *b, int ch, float db);
+void asdr_setAGCattackTime(asdr_batch_t *b, int ch, float ms);
+void asdr_setAGCreleaseTime(asdr_batch_t *b, int ch, float ms);
+void asdr_setAGChangTime(asdr_batch_t *b, int ch, float ms);
+void asdr_setAGCstaticGain(asdr_batch_t *b, int ch, float gain);
+float asdr_getAGCthreshold(asdr_batch_t *b, int ch);
+float asdr_getAGCslope(asdr_batch_t *b, int ch);
+float asdr_getAGCkneeWidth(asdr_batch_t *b, int ch);
+float asdr_getAGCattack(asdr_batch_t *b, int ch);
+float asdr_getAGCrelease(asdr_batch_t *b, int ch);
+float asdr_getAAGalphaAttack(asdr_batch_t *b, int ch);       /* sic: AudioSDR.h:137 */
+float asdr_getAGCbetaAttack(asdr_batch_t *b, int ch);
+float asdr_getAGCalphaRelease(asdr_batch_t *b, int ch);
+float asdr_getAGCbetaRelease(asdr_batch_t *b, int ch);
+float asdr_getAGClookup(asdr_batch_t *b, int ch, int i);
+float asdr_getAGCstaticGain(asdr_batch_t *b, int ch);
+float asdr_getAMcarrierLevel(asdr_batch_t *b, int ch);       /* reads device state */
+/* getAGCmakeUpMode (AudioSDR.h:144) is declared but never defined upstream: not exported. */
+
+/* ---- impulse noise blanker (AudioSDR.h:147-152; AudioSDR.cpp:653-682) */
+void asdr_enableNoiseBlanker(asdr_batch_t *b, int ch);
+void asdr_disableNoiseBlanker(asdr_batch_t *b, int ch);
+void asdr_setNoiseBlankerThreshold(asdr_batch_t *b, int ch, float ratio);
+void asdr_setNoiseBlankerThresholdDb(asdr_batch_t *b, int ch, float db);
+int asdr_NoiseBlankerisEnabled(asdr_batch_t *b, int ch);
+int asdr_NoiseBlankerDetection(asdr_batch_t *b, int ch);     /* reads device state */
+
+/* ---- synchronous AM detector (AudioSDR.h:155-156; AudioSDR.cpp:752-757) */
+float asdr_getSAMfrequency(asdr_batch_t *b, int ch);         /* reads device state */
+int asdr_getSAMphaseLockStatus(asdr_batch_t *b, int ch);     /* reads device state */
+
+/* ---- batch-only additions (no reference analogue) ------------------------------------------- */
+/* Bulk status read-back after a batch: one int32/float per channel into caller arrays (any may be NULL). */
+int asdr_read_status(asdr_batch_t *b, int32_t *agc_active, int32_t *nb_detected, int32_t *sam_locked,
+                     float *sam_frequency, float *am_carrier);
+/* Debug taps: when enabled, the next asdr_update*() calls also record the float32 stage outputs of the
+ * LAST block processed, as [tap][channel][128]; tap order = ASDR_TAP_*.  Costs extra HBM traffic. */
+enum { ASDR_TAP_SCALED_I = 0, ASDR_TAP_SCALED_Q, ASDR_TAP_NB_I, ASDR_TAP_NB_Q, ASDR_TAP_IF_I, ASDR_TAP_IF_Q,
+       ASDR_TAP_MIX_I, ASDR_TAP_MIX_Q, ASDR_TAP_DEMOD, ASDR_TAP_AUDIO_FILT, ASDR_TAP_AGC, ASDR_TAP_ALS,
+       ASDR_N_TAPS };
+int asdr_enable_taps(asdr_batch_t *b, int on);
+int asdr_read_taps(asdr_batch_t *b, float *dst /* [ASDR_N_TAPS][n_channels][128] */);
+/* Kernel-only timing of the most recent asdr_update_device() in milliseconds (HIP events recorded on the
+ * launch stream around the kernel launches of that call); synchronises on the stop event. */
+float asdr_last_kernel_ms(asdr_batch_t *b);
+/* Library / build identification string (contains "gfx950"). */
+const char *asdr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASDR_H_ */
