@@ -46,7 +46,8 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 # every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
-            "asdr_read_status", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version"] +
+            "asdr_read_status", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
+            "asdr_kernel_timing_begin", "asdr_kernel_timing_end"] +
            ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
 
 _lib = None
@@ -90,6 +91,8 @@ def load_library(path=None):
     L.asdr_read_status.argtypes = [vp, i32p, i32p, i32p, fp, fp]; L.asdr_read_status.restype = _i
     L.asdr_enable_taps.argtypes = [vp, _i]; L.asdr_enable_taps.restype = _i
     L.asdr_read_taps.argtypes = [vp, fp]; L.asdr_read_taps.restype = _i
+    L.asdr_kernel_timing_begin.argtypes = [vp, _i]; L.asdr_kernel_timing_begin.restype = _i
+    L.asdr_kernel_timing_end.argtypes = [vp, fp, _i]; L.asdr_kernel_timing_end.restype = _i
     if path is None:
         _lib = L
     return L
@@ -143,6 +146,16 @@ class AudioSDRBatch:
 
     def last_kernel_ms(self):
         return float(self._L.asdr_last_kernel_ms(self._h))
+
+    def kernel_timing_begin(self, max_launches):
+        self._chk(self._L.asdr_kernel_timing_begin(self._h, int(max_launches)))
+
+    def kernel_timing_end(self, cap):
+        ms = np.zeros(int(cap), dtype=np.float32)
+        n = self._L.asdr_kernel_timing_end(self._h, ms.ctypes.data_as(C.POINTER(C.c_float)), int(cap))
+        if n < 0:
+            raise AsdrError(self._L.asdr_last_error().decode())
+        return ms[:n]
 
     # ---- batch-only helpers ----
     def read_status(self):

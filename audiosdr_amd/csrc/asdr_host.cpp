@@ -124,6 +124,8 @@ struct asdr_batch {
   bool taps_on = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  std::vector<hipEvent_t> tev;   // optional per-launch event pairs (asdr_kernel_timing_begin)
+  size_t tev_used = 0;
   hipStream_t last_stream = nullptr;
   ChainConsts k{};
 };
@@ -280,6 +282,7 @@ const Chan *get(asdr_batch *b, int ch) { return (b && ch >= 0 && ch < b->n) ? &b
 
 int read_small(asdr_batch *b, int ch, ChanSmall &s) {
   if (!b || ch < 0 || ch >= b->n) return fail("bad channel");
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -296,31 +299,33 @@ const char *asdr_last_error(void) { return g_err.c_str(); }
 const char *asdr_version(void) { return "asdr-hip 0.1 (gfx950, wave64, -ffp-contract=off)"; }
 
 asdr_batch_t *asdr_create(int n_channels, int device) {
-  if (n_channels <= 0) { fail("n_channels must be > 0"); return nullptr; }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fail("no HIP device: libasdr_hip has no CPU path"); return nullptr; }
-  if (device < 0 || device >= ndev) { fail("bad device ordinal"); return nullptr; }
-  if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+  if (n_channels <= 0 || n_channels > (1 << 20)) { fail("n_channels must be in 1..1048576"); return nullptr; }
   asdr_batch *b = new asdr_batch();
   b->n = n_channels; b->device = device;
   const size_t rows = (size_t)n_channels + 1;
-  bool ok = true;
-  auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
-  alloc((void **)&b->d_params, rows * sizeof(ChanParams));
-  alloc((void **)&b->d_small, rows * sizeof(ChanSmall));
-  alloc((void **)&b->d_nb_hist, rows * 512 * sizeof(float));
-  alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(float));
-  alloc((void **)&b->d_hil_q, rows * 256 * sizeof(float));
-  alloc((void **)&b->d_hil_i, rows * 128 * sizeof(float));
-  alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
-  alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
-  alloc((void **)&b->d_sched, (rows + 8) * sizeof(int32_t));
-  alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
-  if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
-  if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
-  if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
-  if (ok && asdr_kernels_upload_tables() != 0) ok = false;
-  if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
+  if (device != ASDR_NO_DEVICE) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete b; fail("no HIP device: libasdr_hip has no CPU path"); return nullptr; }
+    if (device < 0 || device >= ndev) { delete b; fail("bad device ordinal"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { delete b; fail("hipSetDevice failed"); return nullptr; }
+    bool ok = true;
+    auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
+    alloc((void **)&b->d_params, rows * sizeof(ChanParams));
+    alloc((void **)&b->d_small, rows * sizeof(ChanSmall));
+    alloc((void **)&b->d_nb_hist, rows * 512 * sizeof(float));
+    alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(float));
+    alloc((void **)&b->d_hil_q, rows * 256 * sizeof(float));
+    alloc((void **)&b->d_hil_i, rows * 128 * sizeof(float));
+    alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
+    alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
+    alloc((void **)&b->d_sched, (rows + 8) * sizeof(int32_t));
+    alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
+    if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
+    if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
+    if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
+    if (ok && asdr_kernels_upload_tables() != 0) ok = false;
+    if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
+  }
 
   // constants shared by all channels: in-class initialisers of AudioSDR.h:238-239, 249-284
   ChainConsts &k = b->k;
@@ -354,11 +359,13 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
 
 void asdr_destroy(asdr_batch_t *b) {
   if (!b) return;
+  if (b->device == ASDR_NO_DEVICE) { delete b; return; }
   hipSetDevice(b->device);
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_io[0], b->d_io[1], b->d_io[2]};
   for (void *p : ptrs) if (p) hipFree(p);
+  for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->stream) hipStreamDestroy(b->stream);
@@ -369,6 +376,7 @@ int asdr_n_channels(const asdr_batch_t *b) { return b ? b->n : 0; }
 
 int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks, void *stream_) {
   if (!b) return fail("null batch");
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the signal path needs a HIP device");
   if (!dI || !dQ) return 0;  // missing-input guard, AudioSDR.cpp:48-56
   if (!dOut) return fail("null output");
   if (n_blocks <= 0) return 0;
@@ -379,16 +387,19 @@ int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, in
   UpdateArgs a;
   fill_args(b, a);
   a.in_i = dI; a.in_q = dQ; a.out = dOut; a.n_blocks = n_blocks;
-  HIPCHK(hipEventRecord(b->ev0, stream));
+  hipEvent_t e0 = b->ev0, e1 = b->ev1;
+  if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
+  HIPCHK(hipEventRecord(e0, stream));
   if (asdr_launch_update(&a, stream) != 0) return fail("update kernel launch failed");
-  HIPCHK(hipEventRecord(b->ev1, stream));
-  b->ev_valid = true;
+  HIPCHK(hipEventRecord(e1, stream));
+  b->ev_valid = (e0 == b->ev0);
   b->last_stream = stream;
   return 0;
 }
 
 int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
   if (!b) return fail("null batch");
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the signal path needs a HIP device");
   if (!I || !Q) return 0;
   if (!out) return fail("null output");
   if (n_blocks <= 0) return 0;
@@ -413,6 +424,7 @@ int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *ou
 
 int asdr_synchronize(asdr_batch_t *b) {
   if (!b) return fail("null batch");
+  if (b->device == ASDR_NO_DEVICE) return 0;
   HIPCHK(hipSetDevice(b->device));
   if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -425,6 +437,28 @@ float asdr_last_kernel_ms(asdr_batch_t *b) {
   if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0f;
   if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0f;
   return ms;
+}
+
+int asdr_kernel_timing_begin(asdr_batch_t *b, int max_launches) {
+  if (!b) return fail("null batch");
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
+  HIPCHK(hipSetDevice(b->device));
+  for (hipEvent_t e : b->tev) hipEventDestroy(e);
+  b->tev.clear(); b->tev_used = 0;
+  for (int i = 0; i < 2 * max_launches; i++) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->tev.push_back(e); }
+  return 0;
+}
+
+int asdr_kernel_timing_end(asdr_batch_t *b, float *ms, int cap) {
+  if (!b) return fail("null batch");
+  const int n = (int)(b->tev_used / 2);
+  for (int i = 0; i < n && i < cap; i++) {
+    HIPCHK(hipEventSynchronize(b->tev[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms[i], b->tev[2 * i], b->tev[2 * i + 1]));
+  }
+  for (hipEvent_t e : b->tev) hipEventDestroy(e);
+  b->tev.clear(); b->tev_used = 0;
+  return n < cap ? n : cap;
 }
 
 // ---- general ------------------------------------------------------------------------------------------
@@ -593,6 +627,7 @@ int asdr_read_status(asdr_batch_t *b, int32_t *agc_active, int32_t *nb_detected,
 
 int asdr_enable_taps(asdr_batch_t *b, int on) {
   if (!b) return fail("null batch");
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   if (on && !b->d_taps) {
     const size_t bytes = (size_t)ASDR_N_TAPS * b->n * ASDR_N * sizeof(float);

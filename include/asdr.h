@@ -28,6 +28,7 @@ extern "C" {
 
 #define ASDR_BLOCK_SAMPLES 128 /* AUDIO_BLOCK_SAMPLES; AudioSDR.h:73 n_block */
 #define ASDR_ALL (-1)
+#define ASDR_NO_DEVICE (-1) /* asdr_create(): control plane only (setters/getters); every update fails */
 
 /* demodulation modes, AudioSDR.h:44-50 */
 enum { ASDR_LSBmode = 0, ASDR_USBmode = 1, ASDR_CW_LSBmode = 2, ASDR_CW_USBmode = 3, ASDR_AMmode = 4,
@@ -42,7 +43,9 @@ enum { ASDR_AGCoff = 0, ASDR_AGCfast = 1, ASDR_AGCmedium = 2, ASDR_AGCslow = 3 }
 typedef struct asdr_batch asdr_batch_t;
 
 /* ---- lifetime: replaces N x `AudioSDR sdr;` (constructor AudioSDR.h:77-79 -> init() AudioSDR.cpp:174-185).
- * `device` is a HIP device ordinal.  Returns NULL on failure. */
+ * `device` is a HIP device ordinal, or ASDR_NO_DEVICE for a control-plane-only batch whose setters and
+ * pure-parameter getters work but whose update()/status getters fail (there is no CPU signal path).
+ * Returns NULL on failure. */
 asdr_batch_t *asdr_create(int n_channels, int device);
 void asdr_destroy(asdr_batch_t *b);
 const char *asdr_last_error(void);
@@ -150,6 +153,11 @@ int asdr_read_taps(asdr_batch_t *b, float *dst /* [ASDR_N_TAPS][n_channels][128]
 /* Kernel-only timing of the most recent asdr_update_device() in milliseconds (HIP events recorded on the
  * launch stream around the kernel launches of that call); synchronises on the stop event. */
 float asdr_last_kernel_ms(asdr_batch_t *b);
+/* Per-launch kernel timing across a region: _begin() arms up to `max_launches` HIP-event pairs; every following
+ * asdr_update_device() records one pair on ITS launch stream around the kernel; _end() synchronises, writes the
+ * elapsed milliseconds of each launch into ms[0..return-1] and disarms. */
+int asdr_kernel_timing_begin(asdr_batch_t *b, int max_launches);
+int asdr_kernel_timing_end(asdr_batch_t *b, float *ms, int cap);
 /* Library / build identification string (contains "gfx950"). */
 const char *asdr_version(void);
 

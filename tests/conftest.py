@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ao():
+    """The CPU oracle binding (built on demand with gcc)."""
+    from oracle import asdr_oracle
+    asdr_oracle.build()
+    asdr_oracle.lib()
+    return asdr_oracle
+
+
+@pytest.fixture(scope="session")
+def A():
+    """The product binding; the HIP library is built on demand (hipcc cross-compiles without a GPU)."""
+    from audiosdr_amd import build as b
+    b.build()
+    import audiosdr_amd
+    audiosdr_amd.load_library()
+    return audiosdr_amd
+
+
+@pytest.fixture(scope="session")
+def gpu(A):
+    """Skips (loudly named) when there is no HIP device; GPU tests call through the C ABI only."""
+    try:
+        b = A.AudioSDRBatch(1, device=0)
+    except A.AsdrError as e:
+        pytest.skip("no HIP device: %s" % e)
+    b.close()
+    return A

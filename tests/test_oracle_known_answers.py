@@ -1,0 +1,325 @@
+"""What pins the oracle (the reference has no tests and is unbuildable here):
+
+ 1. table DATA is literal-for-literal the reference's (checked against /root/reference when present,
+    and by a committed hash otherwise);
+ 2. documented behaviour of the reference -- numbers written in its sources/comments -- reproduced as
+    known answers (cited per test);
+ 3. independent float64 mathematics (scipy/numpy) agrees with each restated stage to float32 accuracy.
+"""
+import hashlib
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+REF_H = "/root/reference/SRC/AudioSDRlib/AudioSDR.h"
+FS = 44100.0
+
+
+# ---- 1. tables ---------------------------------------------------------------------------------------
+def test_tables_header_hash():
+    """asdr_tables.h is generated from the reference header; its hash is pinned so that a silent edit of
+    any coefficient fails CI even where /root/reference is absent."""
+    with open(os.path.join(ROOT, "audiosdr_amd", "csrc", "asdr_tables.h"), "rb") as f:
+        h = hashlib.sha256(f.read()).hexdigest()
+    with open(os.path.join(ROOT, "tests", "golden", "asdr_tables.sha256")) as f:
+        assert h == f.read().split()[0]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_H), reason="reference not present (GPU box)")
+def test_tables_match_reference_literals():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "extract_tables.py"), "--check"])
+    assert r.returncode == 0
+
+
+def test_sine_table_is_8_decimal_sine(ao):
+    """AudioSDR.h:780-814: 257 entries = sin(2*pi*i/256) printed with 8 decimals."""
+    t = ao.sine_table()
+    for i in range(257):
+        assert abs(float(t[i]) - math.sin(2 * math.pi * i / 256)) < 6e-9 + 6e-8
+    assert t[64] == 1.0 and t[192] == -1.0 and t[0] == 0.0 and t[256] == 0.0
+    assert np.signbit(t[256])  # the reference's last literal is -0.00000000
+
+
+def test_hilbert_taps_shape(ao):
+    """AudioSDR.h:752-774: 64 folded taps of an odd-symmetric length-257 Hilbert transformer; the
+    ideal tap at odd offset n from the centre is 2/(pi*n), windowed."""
+    h = ao.hilbert_taps().astype(np.float64)
+    assert len(h) == 64 and np.all(h < 0)
+    # h[k] multiplies (x[p-(2k+1)] - x[p-255+2k]): offsets from the centre p-128 are +-(127-2k)
+    n = 127 - 2 * np.arange(64)
+    ideal = 2.0 / (np.pi * n)
+    ratio = -h / ideal
+    assert np.all(ratio[56:] > 0.95) and np.all(ratio[1:] < 1.0001)      # near the centre ~ ideal, windowed elsewhere
+    assert np.all(np.diff(ratio[1:]) > 0)                                 # window rises monotonically toward the centre
+
+
+# ---- 2. scalar helpers vs the accuracy the reference's own comments state ------------------------------
+def test_sin_cos_accuracy_all_table_phases(ao):
+    L = ao.lib()
+    worst = 0.0
+    for ip in range(0, 65536, 7):
+        ph = ip * 2 * math.pi / 65535.0
+        worst = max(worst, abs(L.ao_sin_from_index(ip) - math.sin(ph)))
+    assert worst < 4e-4  # linear interpolation on a 256-point table: (2*pi/256)^2/8 = 7.5e-5, plus index quantisation
+    for ph in np.linspace(0, 2 * math.pi, 1000, endpoint=False):
+        assert abs(L.ao_sin_f32(float(ph)) - math.sin(ph)) < 4e-4
+        assert abs(L.ao_cos_f32(float(ph)) - math.cos(ph)) < 4e-4
+
+
+def test_sin_index_is_exact_floor(ao):
+    """AudioSDR.h:364: intPhase = (long)(Phase*65535.0/twoPI): compare with exact rational arithmetic."""
+    from fractions import Fraction
+    L = ao.lib()
+    two_pi = np.float32(2.0 * 3.1415926535897932384626433832795)
+    rng = np.random.default_rng(1)
+    phases = np.concatenate([rng.uniform(0, float(two_pi), 2000).astype(np.float32),
+                             (np.arange(1, 400, dtype=np.float64) * float(two_pi) / 65535.0 * 163).astype(np.float32)])
+    for ph in phases:
+        if ph >= two_pi or ph < 0:
+            continue
+        exact = Fraction(float(ph)) * 65535 / Fraction(float(two_pi))
+        got = L.ao_sin_index(float(ph))
+        assert got in (int(exact), int(exact) + 1, int(exact) - 1)
+        # double rounding can only move the quotient by one ulp; equality with trunc of the rounded double:
+        assert got == int(float(np.float64(ph) * 65535.0 / np.float64(two_pi)))
+
+
+def test_atan2_max_error_matches_reference_comment(ao):
+    """AudioSDR.h:382-383: 'Max error < 0.005 (or 0.29 degrees)'."""
+    L = ao.lib()
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    for _ in range(20000):
+        y, x = rng.normal(), rng.normal()
+        worst = max(worst, abs(L.ao_approx_atan2_f32(float(y), float(x)) - math.atan2(np.float32(y), np.float32(x))))
+    assert worst < 0.005
+    assert L.ao_approx_atan2_f32(0.0, 0.0) == 0.0                      # AudioSDR.h:407
+    assert L.ao_approx_atan2_f32(1.0, 0.0) == np.float32(0.5 * math.pi)
+    assert L.ao_approx_atan2_f32(-1.0, 0.0) == -np.float32(0.5 * math.pi)
+
+
+def test_fast_sqrt(ao):
+    L = ao.lib()
+    for x in [1e-6, 0.001, 0.02, 0.5, 1.0, 2.0, 3.7, 100.0]:
+        assert abs(L.ao_fast_sqrt_f32(x, 1) / math.sqrt(x) - 1) < 2e-3      # one Newton step on the bit trick
+        assert abs(L.ao_fast_sqrt_f32(x, 2) / math.sqrt(x) - 1) < 1e-5
+    # x = 0: uint32 wrap gives bits 0x9FC00000 before the Newton step: tiny negative, halved
+    v = np.float32(L.ao_fast_sqrt_f32(0.0, 1))
+    assert v < 0 and v.view(np.uint32) == np.uint32(0x9F400000)
+
+
+def test_log2_approx(ao):
+    L = ao.lib()
+    for x in [0.0078125, 0.1, 0.5, 0.75, 1.0, 1.0078125, 3.0]:
+        assert abs(L.ao_log2_approx_f32(x) - math.log2(x)) < 0.01
+
+
+def test_scale_sample(ao):
+    L = ao.lib()
+    assert L.ao_scale_sample(32767, 1.0) == 1.0
+    assert L.ao_scale_sample(-32768, 1.0) == -32768 / 32767.0
+    assert L.ao_scale_sample(1000, 2.5) == (1000 / 32767.0) * 2.5
+
+
+# ---- 3. stages vs independent float64 mathematics -------------------------------------------------------
+@pytest.mark.parametrize("tbl", range(15))
+def test_biquad_cascade_vs_scipy_float64(ao, tbl):
+    """The restated CMSIS DF1 cascade must equal a float64 SOS filter to float32 accuracy.  Coefficient rows
+    are {b0,b1,b2,a1,a2} with the a's sign-flipped (AudioSDR.h:575-577)."""
+    from scipy.signal import sosfilt
+    c = ao.biquad_table(tbl).astype(np.float64)
+    sos = np.concatenate([c[:, :3], np.ones((4, 1)), -c[:, 3:]], axis=1)
+    rng = np.random.default_rng(tbl)
+    x = rng.uniform(-0.5, 0.5, 1024).astype(np.float32)
+    y, _ = ao.biquad_cascade(c, np.zeros(16, np.float32), x)
+    ref = sosfilt(sos, x.astype(np.float64))
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(y - ref).max() / scale < 5e-4
+    # block-wise with carried state == one long run (the state layout {x1,x2,y1,y2} is carried correctly)
+    st = np.zeros(16, np.float32)
+    parts = []
+    for b in range(8):
+        yb, st = ao.biquad_cascade(c, st, x[128 * b:128 * b + 128])
+        parts.append(yb)
+    assert np.array_equal(np.concatenate(parts), y)
+
+
+def _gain_db(ao, tbl, f):
+    from scipy.signal import sosfreqz
+    c = ao.biquad_table(tbl).astype(np.float64)
+    sos = np.concatenate([c[:, :3], np.ones((4, 1)), -c[:, 3:]], axis=1)
+    _, h = sosfreqz(sos, worN=np.atleast_1d(f), fs=FS)
+    return 20 * np.log10(np.abs(h) + 1e-300)
+
+
+def test_filter_tables_match_their_design_comments(ao):
+    """Design comments in AudioSDR.h: audio BPFs f_cl = 150 Hz, f_cu = 2100..3300 Hz (:578-653); IF filters
+    centred on 6.89 kHz with 3 kHz (SSB :719-721), 1 kHz (CW :697-699) bandwidths; AM image LPF (:730-732)."""
+    base = 5
+    for fid, fcu in [(3, 2100), (4, 2300), (5, 2500), (6, 2700), (7, 2900), (8, 3100), (9, 3300)]:
+        mid = _gain_db(ao, base + fid, [600.0, 1000.0])
+        assert np.all(np.abs(mid) < 1.5), (fid, mid)                       # pass-band ~ 0 dB
+        edges = _gain_db(ao, base + fid, [150.0, float(fcu)])
+        assert np.all(np.abs(edges + 3.0) < 1.0), (fid, edges)             # the documented -3 dB corner frequencies
+        assert _gain_db(ao, base + fid, [fcu * 2.0])[0] < -30              # stop-band above
+        assert _gain_db(ao, base + fid, [40.0])[0] < -40                   # and below
+    ssb = 0
+    assert np.all(np.abs(_gain_db(ao, ssb, [5390.0, 5800.0, 6890.0, 7900.0, 8390.0])) < 2.5)   # 6890 +- 1500 Hz
+    assert np.all(_gain_db(ao, ssb, [3000.0, 11000.0]) < -30)
+    cw = 2
+    assert abs(_gain_db(ao, cw, [6890.0])[0]) < 2.0 and np.all(_gain_db(ao, cw, [5500.0, 8300.0]) < -30)
+    img = 4
+    assert abs(_gain_db(ao, img, [1000.0])[0]) < 2.0 and _gain_db(ao, img, [13780.0])[0] < -30   # 2 x 6890 image
+
+
+def test_known_table_typos_are_kept(ao):
+    """wspr_coefs row 2 has a1 = -1.9139 (AudioSDR.h:691); bw470 row 4 is scrambled (:683)."""
+    w = ao.biquad_table(5 + 2)
+    assert w[1, 3] == np.float32(-1.913861406136361690)
+    c = ao.biquad_table(5 + 1)
+    assert c[3, 2] == np.float32(-1.963497179540541810) and c[3, 4] == np.float32(-0.170604083645742671)
+
+
+def test_freq_shifter_vs_float64(ao):
+    L = ao.lib()
+    rng = np.random.default_rng(3)
+    I = rng.uniform(-0.5, 0.5, 128).astype(np.float32)
+    Q = rng.uniform(-0.5, 0.5, 128).astype(np.float32)
+    I2, Q2 = I.copy(), Q.copy()
+    import ctypes as C
+    fp = C.POINTER(C.c_float)
+    ph = L.ao_freq_shifter(I2.ctypes.data_as(fp), Q2.ctypes.data_as(fp), -5390.0, 0.25)
+    n = np.arange(128)
+    w = 0.25 + n * (-5390.0) * 2 * np.pi / FS
+    ref = (I + 1j * Q) * np.exp(1j * w)
+    assert np.abs((I2 + 1j * Q2) - ref).max() < 1e-3
+    wrapped = (0.25 + 128 * (-5390.0) * 2 * np.pi / FS) % (2 * np.pi)
+    assert abs(ph - wrapped) < 1e-3
+
+
+def test_ssb_path_equals_257_tap_convolution(ao):
+    """AudioSDR.cpp:99-112: the folded loop is the convolution of Q with the full odd-symmetric 257-tap
+    kernel; I is delayed by exactly 128 samples."""
+    h = ao.hilbert_taps().astype(np.float64)
+    full = np.zeros(257)
+    for k in range(64):
+        full[2 * k + 1] = h[k]        # lag 2k+1
+        full[255 - 2 * k] = -h[k]     # lag 255-2k
+    sdr = ao.OracleSDR(taps=True)
+    sdr.setDemodMode(ao.USBmode)
+    sdr.disableNoiseBlanker(); sdr.disableAGC()
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(1, 6, fc=6290.0, A=0.25)
+    mixq, miq, mixi, dem = [], [], [], []
+    for b in range(6):
+        sdr.update(I[0, b], Q[0, b])
+        mixq.append(sdr.tap("MIX_Q")); mixi.append(sdr.tap("MIX_I")); dem.append(sdr.tap("DEMOD"))
+    qh = np.concatenate(mixq).astype(np.float64)      # Hilbert output
+    idel = np.concatenate(mixi).astype(np.float64)    # delayed I
+    # reconstruct the shifted (pre-Hilbert) I/Q in float64 from the IF taps is not available per block; instead
+    # check self-consistency: audio = I_delayed - Q_hilbert for USB (:116)
+    assert np.allclose(np.concatenate(dem), (idel - qh).astype(np.float32), atol=1e-7)
+    # analytic signal property: for a +900 Hz baseband tone, Hilbert(Q) ~ -I delayed -> audio ~ 2*I_delayed
+    seg = slice(3 * 128, 6 * 128)
+    assert np.corrcoef(idel[seg], -qh[seg])[0, 1] > 0.999
+
+
+# ---- 4. documented behaviour of the whole chain ---------------------------------------------------------
+def _tone_db(x, f):
+    x = np.asarray(x, dtype=np.float64)
+    n = np.arange(len(x))
+    w = np.hanning(len(x))
+    return 20 * np.log10(abs(np.sum(x * w * np.exp(-2j * np.pi * f * n / FS))) / np.sum(w) * 2 + 1e-12)
+
+
+def test_usb_lsb_sideband_selection(ao):
+    """README.md:4-13 'SSB demodulation (phasing method)': a carrier 900 Hz above the USB tuning offset gives a
+    900 Hz tone in USB; the mirror-image signal is suppressed."""
+    from audiosdr_amd.synth import make_iq
+    out = {}
+    for name, mode, fc in [("usb_wanted", ao.USBmode, 5390.0 + 900), ("usb_image", ao.USBmode, 5390.0 - 900),
+                           ("lsb_wanted", ao.LSBmode, 8390.0 - 900), ("lsb_image", ao.LSBmode, 8390.0 + 900)]:
+        s = ao.OracleSDR()
+        s.setDemodMode(mode); s.disableAGC(); s.disableNoiseBlanker()
+        I, Q = make_iq(1, 40, fc=fc, A=0.25, noise=0.0)
+        out[name] = _tone_db(s.update(I[0], Q[0])[-2048:], 900.0)
+    assert out["usb_wanted"] - out["usb_image"] > 40
+    assert out["lsb_wanted"] - out["lsb_image"] > 40
+    assert abs(out["usb_wanted"] - out["lsb_wanted"]) < 1.0
+
+
+def test_am_and_sam_recover_modulation(ao):
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(1, 48, fc=6890.0, A=0.3, m=0.5, fm=400.0)
+    am = ao.OracleSDR(); am.setDemodMode(ao.AMmode); am.setNoiseBlankerThresholdDb(10.0)
+    a = am.update(I[0], Q[0])
+    assert _tone_db(a[-4096:], 400.0) > _tone_db(a[-4096:], 1234.0) + 30
+    assert 0.25 < am.getAMcarrierLevel() < 0.35                     # carrier amplitude A = 0.3
+    sam = ao.OracleSDR(); sam.setDemodMode(ao.SAMmode); sam.setNoiseBlankerThresholdDb(10.0)
+    s = sam.update(I[0], Q[0])
+    assert sam.getSAMphaseLockStatus() == 1
+    assert abs(sam.getSAMfrequency() - 6890.0) < 25.0               # lock window +-1000 Hz around 6890 (AudioSDR.h:254-255)
+    assert _tone_db(s[-4096:], 400.0) > _tone_db(s[-4096:], 1234.0) + 30
+
+
+def test_sam_default_blanker_threshold_prevents_lock(ao):
+    """with the default threshold 1.2 the blanker chops a 50 %-depth AM signal and the PLL
+    does not reach lock -> envelope fall-back (AudioSDR.cpp:130-143)."""
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(1, 16, fc=6890.0, A=0.3, m=0.5, fm=400.0)
+    s = ao.OracleSDR(); s.setDemodMode(ao.SAMmode)
+    s.update(I[0], Q[0])
+    assert s.NoiseBlankerDetection() == 1
+
+
+def test_noise_blanker_latency_and_blanking(ao):
+    """AudioSDR.cpp:646-649: output is the oldest of three blocks -> first two output blocks are zero."""
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(1, 12, fc=6290.0, A=0.25)
+    s = ao.OracleSDR(taps=True); s.setDemodMode(ao.USBmode); s.setNoiseBlankerThresholdDb(10.0)
+    out = s.update(I[0], Q[0]).reshape(12, 128)
+    assert not out[0].any() and not out[1].any() and out[3].any()
+    # a large impulse is detected and the mask zeroes 10 samples either side (AudioSDR.cpp:630)
+    I2, Q2 = I.copy(), Q.copy()
+    I2[0, 6, 40] = 30000; Q2[0, 6, 40] = -30000
+    s2 = ao.OracleSDR(taps=True); s2.setDemodMode(ao.USBmode); s2.setNoiseBlankerThresholdDb(10.0)
+    hit = False
+    for b in range(12):
+        s2.update(I2[0, b], Q2[0, b])
+        if b == 7:
+            hit = bool(s2.NoiseBlankerDetection())
+        if b == 8:   # block 6 leaves the blanker two calls later
+            nb_i = s2.tap("NB_I")
+            # mask = 0 on [i-10, i+10] = [30, 50]; then the trailing-edge pass (AudioSDR.cpp:638-639, the only
+            # reachable branch) overwrites mask[44..50] with {.933,.75,.5,.25,.067,0,0}
+            assert np.all(nb_i[30:44] == 0.0) and np.all(nb_i[49:51] == 0.0)
+            assert np.all(nb_i[44:49] != 0.0) and nb_i[29] != 0.0 and nb_i[51] != 0.0
+    assert hit
+
+
+def test_agc_levels_output(ao):
+    """AudioSDR.cpp:439-446: threshold -60 dB, slope 0.1, static gain 10: two inputs 20 dB apart come out
+    ~2 dB apart once the AGC has settled."""
+    from audiosdr_amd.synth import make_iq
+    lv = []
+    for A_ in (0.02, 0.2):
+        s = ao.OracleSDR(); s.setDemodMode(ao.USBmode); s.disableNoiseBlanker()
+        I, Q = make_iq(1, 200, fc=6290.0, A=A_, noise=0.0)
+        lv.append(_tone_db(s.update(I[0], Q[0])[-4096:], 900.0))
+        assert s.AGCisActive() == 1
+    assert 1.0 < lv[1] - lv[0] < 3.5
+
+
+def test_als_notch_removes_a_steady_tone(ao):
+    """AudioSDR.cpp:314-352: the adaptive notch (error output) suppresses a persistent tone."""
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(1, 300, fc=6290.0, A=0.1, noise=0.002)
+    a = ao.OracleSDR(); a.setDemodMode(ao.USBmode); a.disableNoiseBlanker(); a.disableAGC()
+    b = ao.OracleSDR(); b.setDemodMode(ao.USBmode); b.disableNoiseBlanker(); b.disableAGC(); b.enableALSfilter()
+    ya, yb = a.update(I[0], Q[0]), b.update(I[0], Q[0])
+    assert _tone_db(ya[-4096:], 900.0) - _tone_db(yb[-4096:], 900.0) > 15
