@@ -7,10 +7,10 @@
  *
  *   params   ChanParams  [C+1]            96 B  read-only per launch (row C = dummy channel)
  *   small    ChanSmall   [C+1]           448 B  biquad states, phases, AGC/PLL/NB scalars, ring slots
- *   nb_hist  float       [C+1][2][2][128]  2 KiB  noise-blanker ring: slot x {I,Q} x sample
+ *   nb_hist  float       [C+1][3][2][128]  3 KiB  noise-blanker ring: slot x {I,Q} x sample (oldest, middle, newest)
  *   nb_mask  float       [C+1][144]        576 B  mask of (middle block + 10 look-ahead), 138 used
  *   hil_q    float       [C+1][2][128]     1 KiB  Hilbert Q history ring (2 previous shifted blocks)
- *   hil_i    float       [C+1][128]        512 B  previous shifted I block (the 128-sample delay)
+ *   hil_i    float       [C+1][2][128]     1 KiB  ring of mixed I blocks (this block, previous = the 128-sample delay)
  *   als_x    float       [C+1][128]        512 B  previous ALS input block
  *   als_w    float       [C+1][128]        512 B  ALS coefficients
  *   agc_tab  float       [T][132]                 pool of distinct AGC gain tables (130 used)
@@ -85,6 +85,7 @@ typedef struct {
 /* constants identical for every channel, evaluated once on the host exactly as the reference's
  * in-class initialisers evaluate them (AudioSDR.h:164-168, 238-239, 249-284) */
 typedef struct {
+  double inv_two_pi_d;          /* RN(1.0 / (double)two_pi_f): reciprocal for the exact sine-index division */
   float if_center;              /* 6890.0f */
   float two_pi_f;               /* (float)(2.0*PI) */
   float half_pi_f;              /* (float)(0.5*PI) */

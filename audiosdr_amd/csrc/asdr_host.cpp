@@ -312,10 +312,10 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
     alloc((void **)&b->d_params, rows * sizeof(ChanParams));
     alloc((void **)&b->d_small, rows * sizeof(ChanSmall));
-    alloc((void **)&b->d_nb_hist, rows * 512 * sizeof(float));
+    alloc((void **)&b->d_nb_hist, rows * 768 * sizeof(float));
     alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(float));
     alloc((void **)&b->d_hil_q, rows * 256 * sizeof(float));
-    alloc((void **)&b->d_hil_i, rows * 128 * sizeof(float));
+    alloc((void **)&b->d_hil_i, rows * 256 * sizeof(float));
     alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
     alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
     alloc((void **)&b->d_sched, (rows + 8) * sizeof(int32_t));
@@ -332,6 +332,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   k.if_center = kIFcenter;
   k.two_pi_f = (float)(2.0 * kPI);
   k.half_pi_f = (float)(0.5 * kPI);
+  k.inv_two_pi_d = 1.0 / (double)k.two_pi_f;
   k.phase_inc_unit = k.two_pi_f / kFs;
   k.nb_alpha = 0.995f;
   k.nb_beta = (float)(1.0 - (double)k.nb_alpha);

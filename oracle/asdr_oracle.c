@@ -649,6 +649,50 @@ float ao_getSAMfrequency(const asdr_oracle_t *o) { return o->pll_freq; }
 int ao_getSAMphaseLockStatus(const asdr_oracle_t *o) { return o->pll_locked; }
 
 /* ------------------------------------------------------------------------------------------ */
+/* exhaustive checks of the exact-arithmetic shortcuts the HIP kernels use (test helpers)       */
+/* ------------------------------------------------------------------------------------------ */
+static double div_by_const_fma(double x, double c, double r) { /* Markstein: RN(x/c) from r = RN(1/c) */
+  double q0 = x * r;
+  double rem = fma(-q0, c, x);
+  return fma(rem, r, q0);
+}
+
+/* For every float32 bit pattern in [bits_lo, bits_hi): does the reciprocal/fma quotient of
+ * (double)phase*65535.0 by (double)(float)(2*pi) equal the true IEEE quotient (AudioSDR.h:364)?  Returns the
+ * number of mismatching QUOTIENTS (stronger than equal truncations). */
+uint64_t ao_check_sin_index_division(uint32_t bits_lo, uint32_t bits_hi) {
+  const double c = (double)(float)(2.0 * AO_PI), r = 1.0 / c;
+  uint64_t bad = 0;
+  for (uint32_t b = bits_lo; b < bits_hi; b++) {
+    union { uint32_t u; float f; } v; v.u = b;
+    double x = (double)v.f * 65535.0;
+    if (div_by_const_fma(x, c, r) != x / c) bad++;
+  }
+  return bad;
+}
+
+/* all int16: s/32767.0 (AudioSDR.cpp:68) */
+int ao_check_scale_division(void) {
+  int bad = 0;
+  for (int s = -32768; s < 32768; s++)
+    if (div_by_const_fma((double)s, 32767.0, 1.0 / 32767.0) != (double)s / 32767.0) bad++;
+  return bad;
+}
+
+/* all 65,536 table phases: float32 interpolation == the reference's mixed float/double form (AudioSDR.h:369) */
+int ao_check_sin_interp_f32(void) {
+  int bad = 0;
+  for (int ip = 0; ip < 65536; ip++) {
+    uint16_t index = (uint16_t)(ip >> 8), delta = (uint16_t)(ip & 0xFF);
+    float v1 = asdr_sine_table[index], v2 = asdr_sine_table[index + 1];
+    float f32 = v1 + ((v2 - v1) * (float)delta) * (1.0f / 256.0f);
+    float ref = ao_sin_from_index((uint16_t)ip);
+    if (memcmp(&f32, &ref, 4) != 0) bad++;
+  }
+  return bad;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* CPU-baseline runner for bench.py                                                            */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {

@@ -146,6 +146,11 @@ const float *ao_hilbert_taps(void);   /* 64 floats */
 const float *ao_sine_table(void);     /* 257 floats */
 const float *ao_biquad_table(int pool_index); /* 20 floats, index as in asdr_tables.h */
 
+/* ---- exhaustive checks of exact-arithmetic shortcuts used by the HIP kernels (see asdr_kernels.hip) */
+uint64_t ao_check_sin_index_division(uint32_t bits_lo, uint32_t bits_hi);
+int ao_check_scale_division(void);
+int ao_check_sin_interp_f32(void);
+
 /* ---- CPU-baseline helper for bench.py: run `n_channels` independent default-constructed
  * instances configured by `config` (0 = C2 USB chain, see oracle source) over `n_blocks`
  * blocks of caller-provided I/Q (layout [channel][block][128]); returns seconds of wall time

@@ -323,3 +323,24 @@ def test_als_notch_removes_a_steady_tone(ao):
     b = ao.OracleSDR(); b.setDemodMode(ao.USBmode); b.disableNoiseBlanker(); b.disableAGC(); b.enableALSfilter()
     ya, yb = a.update(I[0], Q[0]), b.update(I[0], Q[0])
     assert _tone_db(ya[-4096:], 900.0) - _tone_db(yb[-4096:], 900.0) > 15
+
+
+# ---- 5. exact-arithmetic shortcuts used by the HIP kernels, proven exhaustively on the CPU ----------------
+def test_reciprocal_division_is_exact_for_every_phase(ao):
+    """asdr_kernels.hip div_by_const(): mul + 2 fma == IEEE division for x = phase*65535.0, c = (double)(float)2pi,
+    for EVERY float32 phase in [0, 2*pi] (all 1.09e9 bit patterns, split over threads)."""
+    import struct
+    from concurrent.futures import ThreadPoolExecutor
+    L = ao.lib()
+    hi = struct.unpack("<I", struct.pack("<f", np.float32(2.0 * 3.1415926535897932384626433832795)))[0] + 1
+    n = 16
+    edges = [hi * k // n for k in range(n + 1)]
+    with ThreadPoolExecutor(max_workers=8) as ex:      # ctypes releases the GIL
+        bad = sum(ex.map(lambda k: L.ao_check_sin_index_division(edges[k], edges[k + 1]), range(n)))
+    assert bad == 0
+
+
+def test_scale_division_and_f32_interpolation_are_exact(ao):
+    L = ao.lib()
+    assert L.ao_check_scale_division() == 0        # s/32767.0 for all int16
+    assert L.ao_check_sin_interp_f32() == 0        # sin_lut in float32 == reference's mixed form, all 65,536 phases

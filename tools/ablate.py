@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Phase ablation of asdr_update_kernel: builds variants with -DASDR_ABLATE=<mask> and times them
+interleaved in ONE process on the C2 workload (cdna_hip_programming.md 5.4 rule 24).  Outputs of ablated builds
+are wrong by construction; only their kernel time matters.
+
+  python tools/ablate.py build          # here (hipcc cross-compiles): audiosdr_amd/variants/*.so
+  python tools/ablate.py run [rounds]   # on the GPU box
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "audiosdr_amd", "variants")
+PHASES = {"NB": 1, "IF": 2, "SAM": 4, "MIX": 8, "HIL": 16, "ENV": 32, "AF": 64, "AGC": 128, "ALS": 256}
+VARIANTS = {"full": 0, "no_NB": 1, "no_IF": 2, "no_MIX": 8, "no_HIL": 16, "no_AF": 64, "no_AGC": 128,
+            "io_only": 511}
+EXTRA = {"full_w3": ["-DASDR_WAVES_PER_EU=3"]}   # same code, 168-VGPR budget
+
+
+def build():
+    from audiosdr_amd import build as b
+    os.makedirs(VDIR, exist_ok=True)
+    for name, mask in VARIANTS.items():
+        out = os.path.join(VDIR, "libasdr_%s.so" % name)
+        b.build(force=True, extra_flags=["-DASDR_ABLATE=%d" % mask], out=out)
+        print("built", out)
+    for name, flags in EXTRA.items():
+        out = os.path.join(VDIR, "libasdr_%s.so" % name)
+        b.build(force=True, extra_flags=flags, out=out)
+        print("built", out)
+
+
+def run(rounds=5, n_ch=65536):
+    import audiosdr_amd as A
+    from audiosdr_amd.synth import make_iq
+    import torch
+    uniq = 4096
+    I, Q = make_iq(uniq, 2, fc=6290.0, A=0.25)
+    I = np.tile(I, (n_ch // uniq, 1, 1)); Q = np.tile(Q, (n_ch // uniq, 1, 1))
+    dI = [torch.from_numpy(np.ascontiguousarray(I[:, b])).cuda() for b in range(2)]
+    dQ = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).cuda() for b in range(2)]
+    dOut = torch.empty((n_ch, 128), dtype=torch.int16, device="cuda")
+    libs = {}
+    for name in list(VARIANTS) + list(EXTRA):
+        p = os.path.join(VDIR, "libasdr_%s.so" % name)
+        if not os.path.exists(p):
+            continue
+        L = A.binding.load_library(p)
+        h = L.asdr_create(n_ch, 0)
+        L.asdr_setDemodMode(h, -1, 1)
+        L.asdr_enableAudioFilter(h, -1)
+        libs[name] = (L, h)
+    times = {k: [] for k in libs}
+    for r in range(rounds + 1):
+        for name, (L, h) in libs.items():
+            for i in range(6):
+                L.asdr_update_device(h, C.c_void_p(dI[i & 1].data_ptr()), C.c_void_p(dQ[i & 1].data_ptr()),
+                                     C.c_void_p(dOut.data_ptr()), 1, None)
+                ms = L.asdr_last_kernel_ms(h)
+                if r > 0 and i >= 2:
+                    times[name].append(ms)
+    res = {k: {"median_ms": float(np.median(v)), "min_ms": float(np.min(v))} for k, v in times.items()}
+    full = res.get("full", {}).get("median_ms")
+    for k, v in res.items():
+        v["delta_vs_full_ms"] = None if full is None else round(full - v["median_ms"], 4)
+        print("%-10s median %.4f ms  min %.4f ms  (full - this = %s ms)" % (k, v["median_ms"], v["min_ms"], v["delta_vs_full_ms"]))
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
