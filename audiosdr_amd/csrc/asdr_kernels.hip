@@ -478,6 +478,9 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
       if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
     }
     WAVE_SYNC();
+    float *hi_ring = a.hil_i + (size_t)ch * 256 + k0;   // 2-slot ring of mixed I blocks: slot hs = this block, hs^1 = previous
+    float *hq = a.hil_q + (size_t)ch * 256;
+    float i_del[16];
     float mi_[16], mq_[16];   // mixed (shifted) I, Q of this lane's 16 samples
     if (ABL_ON(ABL_MIX) && do_mix) {
       float ph[16], vi[16], vq[16];
@@ -493,13 +496,11 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
     WAVE_SYNC();   // all reads of the phase row done before the history overlay is written
 
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
-    float *hi_ring = a.hil_i + (size_t)ch * 256 + k0;   // 2-slot ring of mixed I blocks: slot hs = this block, hs^1 = previous
     if (is_ssb) {
-      store16(hi_ring + hs * 128, mi_);
-      float *hq = a.hil_q + (size_t)ch * 256;
       float q_old[16], q_mid[16];
       load16(hq + hs * 128 + k0, q_old);          // two blocks back
       load16(hq + (hs ^ 1u) * 128 + k0, q_mid);   // previous block
+      store16(hi_ring + hs * 128, mi_);
       store16(hq + hs * 128 + k0, mq_);           // newest replaces oldest
       // history sample m = B + k0 + j (B = 0, 128, 256): odd m -> X0[(m-1)/2], even m -> X1[(m-2)/2]
 #pragma unroll
@@ -542,7 +543,7 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
     }
     WAVE_SYNC();
     if (is_ssb) {
-      float qh[16], au[16], i_del[16];
+      float qh[16], au[16];
       load16(hi_ring + (hs ^ 1u) * 128, i_del);   // previous block's mixed I == bufferI[3n+i-128] (:111)
       load16(L + W0 + k0, qh);
 #pragma unroll
@@ -595,6 +596,12 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
     WAVE_SYNC();
     TAP_ROW(ASDR_TAP_DEMOD, W0);
 
+    // AGC inputs are requested here, one phase early (latency hides behind the audio-filter pipeline)
+    float agc_gain_in = 0.f, agc_old0 = 0.f, agc_carrier0 = 0.f;
+    uint32_t agc_hc0 = 0u;
+    if (ABL_ON(ABL_AGC) && agc_en) {
+      agc_gain_in = S->agc_gain; agc_old0 = S->agc_old_abs; agc_hc0 = S->agc_hang_counter; agc_carrier0 = S->am_carrier;
+    }
     // ---- audio IIR filter, AudioSDR.cpp:149, 280-286: lanes s8 = 0..3 are the four stages ---------------------
     if (ABL_ON(ABL_AF) && __any(af_en)) {
       const int st = s8 & 3;
@@ -612,21 +619,21 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
     // Split into (a) the sequential envelope/hang recurrence, which records for every sample which update
     // governs the gain, and (b) a parallel pass that evaluates the static compressor and applies the gain.
     if (ABL_ON(ABL_AGC) && __any(agc_en)) {
-      const float *gtab = a.agc_tab + (size_t)P.agc_table * ASDR_AGC_TAB_ROW;
       const float *tab = L + AGC_TAB;
-      const float gain_in = S->agc_gain;
+      const float gain_in = agc_gain_in;
       if (agc_en) {   // stage the channel's gain table (row of 132 floats) in LDS, all loads in flight at once
-        float4 t4[5];
+        const float *gtab = a.agc_tab + (size_t)P.agc_table * ASDR_AGC_TAB_ROW;
+        float4 agc_t4[5];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; t4[r] = (q < 33) ? reinterpret_cast<const float4 *>(gtab)[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; agc_t4[r] = (q < 33) ? reinterpret_cast<const float4 *>(gtab)[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = t4[r]; }
+        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = agc_t4[r]; }
       }
       WAVE_SYNC();
       if (agc_en && lead) {
-        float old_abs = S->agc_old_abs;
-        uint32_t hc = S->agc_hang_counter;
-        const float am_level = (float)(2.0 * (double)(carrier_fresh ? carrier_now : S->am_carrier));
+        float old_abs = agc_old0;
+        uint32_t hc = agc_hc0;
+        const float am_level = (float)(2.0 * (double)(carrier_fresh ? carrier_now : agc_carrier0));
         const float al_a = P.agc_alpha_att, be_a = P.agc_beta_att, al_r = P.agc_alpha_rel, be_r = P.agc_beta_rel;
         const uint32_t hang = P.agc_hang_count;
         float gv = -1.0f;   // envelope value governing the current gain; -1 = no update yet in this block
