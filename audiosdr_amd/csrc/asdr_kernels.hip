@@ -5,18 +5,18 @@
 //   * one workgroup == one wavefront (64 lanes) == 8 channels ("slots" c8 = lane>>3, s8 = lane&7);
 //     no inter-wave communication, no MFMA, no atomics, no collectives.
 //   * pointwise / FIR stages: lane (c8, s8) owns 16 samples of its channel's 128-sample block
-//     (contiguous 16 for load/scale/mix/output; 16 same-parity outputs for the Hilbert FIR).
-//   * IIR biquad cascades: a 4-lane systolic pipeline per cascade (lane = stage, one sample of skew),
+//     (contiguous 16, processed LDS-resident in two 8-sample pieces; 16 same-parity outputs for the Hilbert FIR).
+//   * IIR biquad cascades: a 4-lane systolic pipeline per cascade (lane = stage, one 4-sample chunk of skew),
 //     stage-to-stage hand-off by DPP row_shr:1, so 8 channels x {I,Q} x 4 stages fill the wave.
 //   * strictly sequential scalar recurrences (noise-blanker average, mixer phase, AGC envelope, PLL,
-//     AM carrier tracker): lane s8==0 of each channel, fed from / draining to LDS.
-//   * every channel's block, filter scratch and FIR history are staged in LDS (2576 B per channel);
-//     carried state lives in HBM in per-channel rows (asdr_device.h) and is loaded/stored with
+//     AM carrier tracker): lane s8==0 of each channel, fed from / draining to LDS in 4/8-sample chunks.
+//   * every channel's block, filter scratch and FIR history are staged in LDS (1552 B per channel; 2064 B in the
+//     ALS instantiation); carried state lives in HBM in per-channel rows (asdr_device.h) and is loaded/stored with
 //     coalesced 16-B-per-lane accesses.
 //
 // Numerics: built with -ffp-contract=off.  Every float operation is a separately rounded binary32
 // operation in the reference's order; the reference's "double islands"  are computed
-// in binary64 here too, so the int16 output is intended to be bit-identical to the CPU restatement.
+// in binary64 here too, so the int16 output is bit-identical to the CPU restatement.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,26 +25,27 @@
 #include "../../include/asdr.h"
 
 // ---- per-channel LDS layout (floats) --------------------------------------------------------------
-#define CH_STRIDE 516   // 2064 B: 16-B slot stride 129 == 1 (mod 16) keeps the 8 channels' rows on different LDS slots
-#define W0 0     // working row A: I, later the mono audio
-#define W1 128   // working row B: Q; dead once the mixer has read it, then part of the Hilbert history below
-#define HB 128   // Hilbert history, de-interleaved: X0 = odd samples [HB, HB+192), X1 = even samples (shifted by one) [HB+192, HB+384)
-#define HX1 (HB + 192)
-#define PH 384   // mixer phase sequence [PH, PH+128): inside X1, written/read before the history is assembled
-#define SCR 512  // 4 per-channel scalar words (flags broadcast between a channel's lanes)
-// noise-blanker overlay (before the rows above are live)
-#define NB_MSK 0     // mask[0..265]
-#define NB_C 272     // padded running detection count C[0..222] (int): C[3..23] = 0, C[24+t] = count after detection
-                     // index t (t = i-78, 0..177), C[202..222] = final count.  Before the sequential pass the slots
-                     // C[24+t] hold the envelope mag[t] (float), which the pass consumes chunk by chunk.
-#define NB_MAG (NB_C + 24)
+// Two instantiations: STRIDE 388 (no channel of the batch uses the ALS filter; 12 waves/CU fit) and 516 (ALS).
+// 388 = 97 sixteen-byte slots == 1 (mod 16): the 8 channels' rows start on different LDS slots.
+#define W0 0       // working row A: I, later the mono audio
+#define W1 128     // working row B: Q
+#define PH 256     // mixer phase sequence [256,384)
+#define XQ0 0      // Hilbert history, de-interleaved, overlays W0/W1/PH once the mixer has consumed them:
+#define XQ1 192    //   X0 = odd samples [0,192), X1 = even samples shifted by one [192,384)
+#define SCR0 387   // SAM lock flag (last, unused word of the AGC table row; never live together)
+// noise-blanker overlay (dead before the rows above are written)
+#define NB_MAG 0   // envelope of detection indices 78..255: mag[0..177]; later overlaid by the mask
+#define NB_MSK 0   // mask[0..265(..271)]
+#define NB_CB 272  // 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count after
+                   // detection index t (0..177), CB[202..222] = final count
 // AGC overlay
-#define AGC_GV W1    // per sample: the envelope value whose compressor gain applies (-1 = gain carried in)
+#define AGC_GV 128   // per sample: the envelope value whose compressor gain applies (-1 = gain carried in)
 #define AGC_TAB 256  // this channel's gain table (row of 132 floats)
-// ALS overlay
-#define ALS_X 128         // [0..255] previous + current block
-#define ALS_W 384         // [0..127] taps
-#define ALS_OUT W0        // in place: the input was copied to ALS_X first
+// ALS overlay (516 variant only)
+#define ALS_X 128    // [0..255] previous + current block
+#define ALS_W 384    // [0..127] taps
+#define ALS_OUT W0   // in place: the input was copied to ALS_X first
+#define SCR1 513     // ALS error broadcast word
 
 #define PI_D 3.1415926535897932384626433832795 /* Arduino.h PI (double) */
 
@@ -63,9 +64,9 @@
 #define ABL_ALS 256
 #define ABL_ON(x) (!(ASDR_ABLATE & (x)))
 
-// register budget: 2 -> <=256 VGPRs (8 waves/CU), 3 -> <=168 (LDS then allows 9 waves/CU)
+// register budget of the main instantiation: 3 -> <=168 VGPRs (12 waves/CU with 13.4 KB LDS per wave)
 #ifndef ASDR_WAVES_PER_EU
-#define ASDR_WAVES_PER_EU 2
+#define ASDR_WAVES_PER_EU 3
 #endif
 
 __constant__ float c_bq_pool[ASDR_N_BQ_TABLES][ASDR_BQ_COEFS];
@@ -83,7 +84,7 @@ extern "C" int asdr_kernels_upload_tables(void) {
 // Correctly rounded binary64 quotient x / c for a constant c with r = RN(1/c) (Markstein): q0 = RN(x*r),
 // rem = x - c*q0 exactly (fma), q = RN(q0 + rem*r) == RN(x/c).  Replaces the ~30-instruction IEEE f64 division
 // sequence by mul + 2 fma.  Verified exhaustively against true division by the CPU test-suite (all float32
-// phases in [0, 2*pi) for c = (double)(float)(2*pi); all int16 for c = 32767.0) and on the GPU by the taps.
+// phases in [0, 2*pi] for c = (double)(float)(2*pi); all int16 for c = 32767.0) and on the GPU by the taps.
 __device__ __forceinline__ double div_by_const(double x, double c, double r) {
   const double q0 = x * r;
   const double rem = __builtin_fma(-q0, c, x);
@@ -203,10 +204,14 @@ __device__ __forceinline__ void load16(const float *p, float *v) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) { float4 t = q[r]; v[4 * r] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w; }
 }
-__device__ __forceinline__ void store16(float *p, const float *v) {
+__device__ __forceinline__ void load8(const float *p, float *v) {
+  const float4 *q = reinterpret_cast<const float4 *>(p);
+  const float4 a = q[0], b = q[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float *p, const float *v) {
   float4 *q = reinterpret_cast<float4 *>(p);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) q[r] = make_float4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
+  q[0] = make_float4(v[0], v[1], v[2], v[3]); q[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
@@ -214,15 +219,17 @@ __device__ __forceinline__ void store16(float *p, const float *v) {
 #define WAVE_SYNC() __syncthreads() /* workgroup == one wave: lowers to a wave barrier + LDS/VMEM waits */
 
 // =====================================================================================================
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * CH_STRIDE + 264];
+// Pointwise stages work LDS-resident in two 8-sample pieces per lane (`#pragma unroll 1` loops), so no 16-wide
+// register array is carried from one stage to the next.
+template <int STRIDE, bool HAS_ALS>
+__device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds) {
   const int lane = threadIdx.x, c8 = lane >> 3, s8_ = lane & 7;
-  float *sine = lds + 8 * CH_STRIDE;
+  float *sine = lds + 8 * STRIDE;
   for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   const int ch_ = a.sched[blockIdx.x * 8 + c8];
   const bool valid = ch_ < a.n_channels;
-  const int loff_ = c8 * CH_STRIDE;
+  const int loff_ = c8 * STRIDE;
   const ChanParams *Pp_ = a.params + ch_;
 #define P (*Pp)
   const ChainConsts K = a.k;
@@ -234,7 +241,8 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
   const bool is_am = (mode == ASDR_AMmode), is_sam = (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
   const bool nb_en = pflags & ASDR_F_NB_EN, af_en = pflags & ASDR_F_AF_EN, agc_en = pflags & ASDR_F_AGC_EN;
-  const bool als_en = pflags & ASDR_F_ALS_EN, muted = pflags & ASDR_F_MUTED;
+  const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
+  const bool muted = pflags & ASDR_F_MUTED;
   const float two_pi = K.two_pi_f;
   WAVE_SYNC();
 
@@ -254,116 +262,132 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
     const bool tap_on = (a.taps != nullptr) && valid && (blk == a.n_blocks - 1);
     float *tap_base = tap_on ? a.taps + (size_t)ch * ASDR_N + k0 : nullptr;
     const size_t tap_stride = (size_t)a.n_channels * ASDR_N;
-#define TAP_REGS(id, v) do { if (tap_on) store16(tap_base + (size_t)(id) * tap_stride, v); } while (0)
-#define TAP_ROW(id, rowoff) do { if (tap_on) { float tv_[16]; load16(L + (rowoff) + k0, tv_); store16(tap_base + (size_t)(id) * tap_stride, tv_); } } while (0)
+#define TAP8(id, h, v) do { if (tap_on) store8(tap_base + (size_t)(id) * tap_stride + 8 * (h), v); } while (0)
+#define TAP_ROW(id, rowoff) do { if (tap_on) { for (int h_ = 0; h_ < 2; ++h_) { float tv_[8]; load8(L + (rowoff) + k0 + 8 * h_, tv_); \
+                                  store8(tap_base + (size_t)(id) * tap_stride + 8 * h_, tv_); } } } while (0)
 
-    // ---- issue every load whose address is known now (per-channel scalars, raw input, blanker ring) before any use
     uint32_t status = S->status;
     const uint32_t ns = S->nb_slot % 3u, hs = S->hil_slot & 1u;   // oldest NB ring slot (of 3), Hilbert ring parity
+    const uint32_t ns_mid = (ns + 1u) % 3u, ns_new = (ns + 2u) % 3u;
     float carrier_now = 0.0f;   // set by the envelope path when it runs in this block
     bool carrier_fresh = false;
     const size_t io = ((size_t)ch * a.n_blocks + blk) * ASDR_N + k0;
-    union { int4 v[2]; int16_t s[16]; } ri, rq;
-    ri.v[0] = ri.v[1] = rq.v[0] = rq.v[1] = make_int4(0, 0, 0, 0);
-    if (valid) {
-      const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
-      const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
-      ri.v[0] = pi[0]; ri.v[1] = pi[1]; rq.v[0] = pq[0]; rq.v[1] = pq[1];
-    }
-    const bool nb_run = ABL_ON(ABL_NB) && nb_en;
-    const bool nb_wave = ABL_ON(ABL_NB) && __any(nb_en);   // wave-uniform: at least one of the 8 channels has the blanker on
+    const bool nb_wave = ABL_ON(ABL_NB) && __any(nb_en);   // wave-uniform: some channel of this wave has the blanker on
     float *hist = a.nb_hist + (size_t)ch * 768;
-    const uint32_t ns_mid = (ns + 1u) % 3u, ns_new = (ns + 2u) % 3u;
     float *mrow = a.nb_mask + (size_t)ch * ASDR_NB_MASK_ROW;
-    // ---- input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
-    float xi[16], xq[16];
+
+    // ---- load + input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
+    // With a blanker in the wave the scaled block is parked in the third ring slot in HBM (also by channels whose
+    // blanker is OFF: their ring is dead state, enabling the blanker always resets it, AudioSDR.cpp:653-656);
+    // otherwise it goes straight to the IF filter's LDS rows.
     {
-      const double gi = (double)P.in_gain_i, gq = (double)P.in_gain_q;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        xi[j] = (float)(div_by_const((double)ri.s[j], 32767.0, 1.0 / 32767.0) * gi);
-        xq[j] = (float)(div_by_const((double)rq.s[j], 32767.0, 1.0 / 32767.0) * gq);
-        if ((j & 1) == 1) SCHED_FENCE();
+      union { int4 v; int16_t s[8]; } ri[2], rq[2];
+      ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
+      if (valid) {
+        const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
+        const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
+        ri[0].v = pi[0]; ri[1].v = pi[1]; rq[0].v = pq[0]; rq[1].v = pq[1];
       }
-    }
-    TAP_REGS(ASDR_TAP_SCALED_I, xi); TAP_REGS(ASDR_TAP_SCALED_Q, xq);
-    float oi[16], oq[16], mi[16], mq[16];
-    if (nb_run) {
-      const float *old_i = hist + ns * 256 + k0, *mid_i = hist + ns_mid * 256 + k0;
-      load16(mid_i, mi); load16(mid_i + 128, mq);
-      if (s8 >= 4) { load16(old_i, oi); load16(old_i + 128, oq); }   // only samples 78..127 of the oldest block are re-scanned
-    }
-    if (nb_wave) {
-      // Third ring slot: the newest block is parked in HBM, so no registers are held across the blanker's phases.
-      // Channels whose blanker is OFF use their (otherwise dead: enabling the blanker always resets it,
-      // AudioSDR.cpp:653-656) ring slot as the same parking space and read it back with mask 1.0.
+      const double gi = (double)P.in_gain_i, gq = (double)P.in_gain_q;
       float *new_i = hist + ns_new * 256 + k0;
-      store16(new_i, xi); store16(new_i + 128, xq);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float xi[8], xq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xi[j] = (float)(div_by_const((double)ri[h].s[j], 32767.0, 1.0 / 32767.0) * gi);
+          xq[j] = (float)(div_by_const((double)rq[h].s[j], 32767.0, 1.0 / 32767.0) * gq);
+          if ((j & 1) == 1) SCHED_FENCE();
+        }
+        TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq);
+        if (nb_wave) { store8(new_i + 8 * h, xi); store8(new_i + 128 + 8 * h, xq); }
+        else { store8(L + W0 + k0 + 8 * h, xi); store8(L + W1 + k0 + 8 * h, xq); }
+        SCHED_FENCE();
+      }
     }
 
     // ---- impulse noise blanker, AudioSDR.cpp:606-650 ------------------------------------------------------
-    // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The ring
-    // in HBM holds oldest+middle; the newest block is only stored.  Output = mask x oldest (2 blocks late).
+    // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
+    // in HBM holds them; output = mask x oldest (2 blocks late).
     if (nb_wave) {
+      float4 mk4[5];
       if (nb_en) {
-        // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          L[NB_MAG + 50 + k0 + j] = fast_sqrt1(mi[j] * mi[j] + mq[j] * mq[j]);
-          const int k = k0 + j;
-          if (k >= 78) L[NB_MAG + k - 78] = fast_sqrt1(oi[j] * oi[j] + oq[j] * oq[j]);
-          if ((j & 3) == 3) SCHED_FENCE();
-        }
-        // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
-        // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
-        float4 mk4[5];
+        const float *old_i = hist + ns * 256 + k0, *mid_i = hist + ns_mid * 256 + k0;
+        // mask row (carried mask[128..265]) requested now, consumed after the sequential pass
 #pragma unroll
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; mk4[r] = (q < 36) ? reinterpret_cast<const float4 *>(mrow)[q] : make_float4(1.f, 1.f, 1.f, 1.f); }
+        // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628)
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          float vi[8], vq[8];
+          load8(mid_i + 8 * h, vi); load8(mid_i + 128 + 8 * h, vq);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { L[NB_MAG + 50 + k0 + 8 * h + j] = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]); if ((j & 3) == 3) SCHED_FENCE(); }
+          if (k0 + 8 * h + 7 >= 78) {   // only samples 78..127 of the oldest block are re-scanned
+            load8(old_i + 8 * h, vi); load8(old_i + 128 + 8 * h, vq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int k = k0 + 8 * h + j;
+              if (k >= 78) L[NB_MAG + k - 78] = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]);
+              if ((j & 3) == 3) SCHED_FENCE();
+            }
+          }
+        }
+      }
+      WAVE_SYNC();
+      if (nb_en && lead) {   // sequential: threshold test against the running average (:627-635), 8 samples per trip
+        float avg = S->nb_avg;
+        const float thr = P.nb_threshold;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int z = 0; z < 6; ++z) Li[NB_CB + z] = 0;
+#pragma unroll 1
+        for (int t = 0; t < 176; t += 8) {
+          float m[8];
+          load8(L + NB_MAG + t, m);
+          uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            cnt += (m[u] > avg * thr) ? 1u : 0u;
+            if (u < 4) w0 |= cnt << (8 * u); else w1 |= cnt << (8 * (u - 4));
+            avg = K.nb_alpha * avg + K.nb_beta * m[u];
+          }
+          *reinterpret_cast<uint2 *>(Li + NB_CB + 6 + (t >> 2)) = make_uint2(w0, w1);   // bytes 24+t .. 24+t+7
+        }
+        uint32_t w = 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float m = L[NB_MAG + 176 + u];
+          cnt += (m > avg * thr) ? 1u : 0u;
+          w |= cnt << (8 * u);
+          avg = K.nb_alpha * avg + K.nb_beta * m;
+        }
+        Li[NB_CB + 50] = w | (cnt << 16) | (cnt << 24);                                  // bytes 200..203
+#pragma unroll
+        for (int z = 51; z < 56; ++z) Li[NB_CB + z] = cnt * 0x01010101u;                 // bytes 204..223
+        S->nb_avg = avg;
+        S->nb_slot = ns_mid;
+        status = (status & ~ASDR_S_NB_DETECTED) | (cnt > 0 ? ASDR_S_NB_DETECTED : 0u);
+      }
+      WAVE_SYNC();
+      if (nb_en) {
+        // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
+        // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
 #pragma unroll
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 36) *reinterpret_cast<float4 *>(L + NB_MSK + 4 * q) = mk4[r]; }
 #pragma unroll
         for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;
       }
       WAVE_SYNC();
-      if (nb_en && lead) {   // sequential: threshold test against the running average (:627-635), 8 samples per trip
-        float avg = S->nb_avg;
-        const float thr = P.nb_threshold;
-        int cnt = 0;
-        for (int z = 3; z < 24; ++z) Li[NB_C + z] = 0;
-#pragma unroll 1
-        for (int t = 0; t < 176; t += 8) {
-          float m[8]; int cv[8];
-          const float4 ma = *reinterpret_cast<const float4 *>(L + NB_MAG + t), mb = *reinterpret_cast<const float4 *>(L + NB_MAG + t + 4);
-          m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w; m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            cnt += (m[u] > avg * thr) ? 1 : 0;
-            cv[u] = cnt;
-            avg = K.nb_alpha * avg + K.nb_beta * m[u];
-          }
-          *reinterpret_cast<int4 *>(Li + NB_MAG + t) = make_int4(cv[0], cv[1], cv[2], cv[3]);
-          *reinterpret_cast<int4 *>(Li + NB_MAG + t + 4) = make_int4(cv[4], cv[5], cv[6], cv[7]);
-        }
-        for (int t = 176; t < 178; ++t) {
-          const float m = L[NB_MAG + t];
-          cnt += (m > avg * thr) ? 1 : 0;
-          Li[NB_MAG + t] = cnt;
-          avg = K.nb_alpha * avg + K.nb_beta * m;
-        }
-        for (int z = 202; z < 223; ++z) Li[NB_C + z] = cnt;
-        S->nb_avg = avg;
-        S->nb_slot = ns_mid;
-        status = (status & ~ASDR_S_NB_DETECTED) | (cnt > 0 ? ASDR_S_NB_DETECTED : 0u);
-      }
-      WAVE_SYNC();
       if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are 0.0, so order-free:
-                     // mask[m] is hit iff a detection index lies in [m-10, m+10] iff C[m-44] - C[m-65] > 0
+                     // mask[m] is hit iff a detection index lies in [m-10, m+10] iff CB[m-44] - CB[m-65] > 0
+        const uint8_t *cb = reinterpret_cast<const uint8_t *>(Li + NB_CB);
         const int m0 = 68 + s8 * 25;
 #pragma unroll
         for (int g5 = 0; g5 < 25; g5 += 5) {
           int hi[5], lo[5];
 #pragma unroll
-          for (int r = 0; r < 5; ++r) { hi[r] = Li[NB_C + m0 - 44 + g5 + r]; lo[r] = Li[NB_C + m0 - 65 + g5 + r]; }
+          for (int r = 0; r < 5; ++r) { hi[r] = cb[m0 - 44 + g5 + r]; lo[r] = cb[m0 - 65 + g5 + r]; }
 #pragma unroll
           for (int r = 0; r < 5; ++r) if (m0 + g5 + r <= 265 && hi[r] - lo[r] > 0) L[NB_MSK + m0 + g5 + r] = 0.0f;
           SCHED_FENCE();
@@ -389,24 +413,31 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
         }
       }
       WAVE_SYNC();
-      { const float *old_i = hist + (nb_en ? ns : ns_new) * 256 + k0; load16(old_i, oi); load16(old_i + 128, oq); }
-      {              // output = mask x oldest block (:646-649); carry mask[128..265(..271)] to the next call
-        float mk[16];
-        load16(L + NB_MSK + k0, mk);
+      float mk[16];
+      {   // read this lane's mask values and carry mask[128..265(..271)] to the next call, before the rows are reused
+        load8(L + NB_MSK + k0, mk); load8(L + NB_MSK + k0 + 8, mk + 8);
+        if (nb_en) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { const float mv = nb_en ? mk[j] : 1.0f; xi[j] = mv * oi[j]; xq[j] = mv * oq[j]; }
-      }
-      if (nb_en) {
-#pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 36) reinterpret_cast<float4 *>(mrow)[q] = *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + 4 * q); }
+          for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 36) reinterpret_cast<float4 *>(mrow)[q] = *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + 4 * q); }
+        }
       }
       WAVE_SYNC();
+      {   // output = mask x oldest block (:646-649) -> IF filter rows; blanker-off channels read their parked block x 1.0
+        const float *src = hist + (nb_en ? ns : ns_new) * 256 + k0;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          float vi[8], vq[8];
+          load8(src + 8 * h, vi); load8(src + 128 + 8 * h, vq);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float mv = nb_en ? mk[8 * h + j] : 1.0f; vi[j] = mv * vi[j]; vq[j] = mv * vq[j]; }
+          store8(L + W0 + k0 + 8 * h, vi); store8(L + W1 + k0 + 8 * h, vq);
+        }
+      }
     }
-    TAP_REGS(ASDR_TAP_NB_I, xi); TAP_REGS(ASDR_TAP_NB_Q, xq);
+    WAVE_SYNC();
+    TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1);
 
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
-    store16(L + W0 + k0, xi); store16(L + W1 + k0, xq);
-    WAVE_SYNC();
     if (ABL_ON(ABL_IF)) {
       const int iq = s8 >> 2, st = s8 & 3;
       float sv[4];
@@ -450,10 +481,10 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
         S->pll_y_re = y_re; S->pll_y_im = y_im; S->pll_prev_filt = prev_filt;
         S->pll_d0 = d0; S->pll_d1 = d1; S->pll_phase_est = phase_est; S->pll_freq = pfreq;
         status = (status & ~ASDR_S_PLL_LOCKED) | (locked ? ASDR_S_PLL_LOCKED : 0u);
-        Li[SCR + 0] = locked ? 1 : 0;
+        Li[SCR0] = locked ? 1 : 0;
       }
       WAVE_SYNC();
-      if (is_sam) pll_locked = Li[SCR + 0] != 0;
+      if (is_sam) pll_locked = Li[SCR0] != 0;
     }
     // envelope detector runs for AM, and for SAM when the PLL is unlocked at the end of the block (:132)
     const bool do_env = is_am || (is_sam && !pll_locked);
@@ -478,83 +509,109 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
       if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
     }
     WAVE_SYNC();
-    float *hi_ring = a.hil_i + (size_t)ch * 256 + k0;   // 2-slot ring of mixed I blocks: slot hs = this block, hs^1 = previous
+    // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
+    // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
+    float *hi_ring = a.hil_i + (size_t)ch * 256 + k0;
     float *hq = a.hil_q + (size_t)ch * 256;
-    float i_del[16];
-    float mi_[16], mq_[16];   // mixed (shifted) I, Q of this lane's 16 samples
     if (ABL_ON(ABL_MIX) && do_mix) {
-      float ph[16], vi[16], vq[16];
-      load16(L + PH + k0, ph); load16(L + W0 + k0, vi); load16(L + W1 + k0, vq);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        float ph[8], vi[8], vq[8], mi[8], mq[8];
+        load8(L + PH + k0 + 8 * h, ph); load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float c = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d), s = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
-        mi_[j] = vi[j] * c - vq[j] * s;
-        mq_[j] = vq[j] * c + vi[j] * s;
-        if ((j & 1) == 1) SCHED_FENCE();
+        for (int j = 0; j < 8; ++j) {
+          const float c = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d), sn = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
+          mi[j] = vi[j] * c - vq[j] * sn;
+          mq[j] = vq[j] * c + vi[j] * sn;
+          if ((j & 1) == 1) SCHED_FENCE();
+        }
+        store8(L + W0 + k0 + 8 * h, mi); store8(L + W1 + k0 + 8 * h, mq);
+        if (is_ssb) store8(hi_ring + hs * 128 + 8 * h, mi);
       }
     }
-    WAVE_SYNC();   // all reads of the phase row done before the history overlay is written
 
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
-    if (is_ssb) {
-      float q_old[16], q_mid[16];
-      load16(hq + hs * 128 + k0, q_old);          // two blocks back
-      load16(hq + (hs ^ 1u) * 128 + k0, q_mid);   // previous block
-      store16(hi_ring + hs * 128, mi_);
-      store16(hq + hs * 128 + k0, mq_);           // newest replaces oldest
-      // history sample m = B + k0 + j (B = 0, 128, 256): odd m -> X0[(m-1)/2], even m -> X1[(m-2)/2]
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int m = k0 + j;
-        if (j & 1) {
-          L[HB + (m - 1) / 2] = q_old[j]; L[HB + (128 + m - 1) / 2] = q_mid[j]; L[HB + (256 + m - 1) / 2] = mq_[j];
-        } else {
-          if (m >= 2) L[HX1 + (m - 2) / 2] = q_old[j];
-          L[HX1 + (128 + m - 2) / 2] = q_mid[j]; L[HX1 + (256 + m - 2) / 2] = mq_[j];
-        }
-      }
-      if (lead) S->hil_slot = hs ^ 1u;
-    }
-    WAVE_SYNC();
-    if (ABL_ON(ABL_HIL) && is_ssb) {
-      // lane (par, g): outputs i = 2*(16g + j) + par, j = 0..15:
-      //   Q[i] = sum_k h[k] * (X[127 + 16g + j - k] - X[16g + j + k]),  k ascending, accumulate from 0.0
-      const int par = s8 & 1, g = s8 >> 1;
-      const float *X = L + (par ? HX1 : HB);
-      float acc[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    if (__any(is_ssb)) {
+      float qn[16];
+      if (is_ssb) { load8(L + W1 + k0, qn); load8(L + W1 + k0 + 8, qn + 8); }   // own mixed Q samples, written above
+      WAVE_SYNC();   // every lane has consumed W0/W1/PH: the history may now overlay them
+      if (is_ssb) {
+        // history sample m' = B + k0 + j (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1, 256: this
+        // block): odd m' -> X0[(m'-1)/2], even m' -> X1[(m'-2)/2] (m' = 0 is never used)
 #pragma unroll 1
-      for (int kc = 0; kc < 4; ++kc) {
-        float dw[32], uw[32];
-        const float *dp = X + 112 + 16 * (g - kc), *up = X + 16 * (g + kc);
-        load16(dp, dw); load16(dp + 16, dw + 16);
-        load16(up, uw); load16(up + 16, uw + 16);
+        for (int h = 0; h < 2; ++h) {
+          float qo[8], qm[8];
+          load8(hq + hs * 128 + k0 + 8 * h, qo);
+          load8(hq + (hs ^ 1u) * 128 + k0 + 8 * h, qm);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const float h = c_hilbert[16 * kc + kk];
+          for (int j = 0; j < 8; ++j) {
+            const int m = k0 + 8 * h + j;
+            if (j & 1) { L[XQ0 + (m - 1) / 2] = qo[j]; L[XQ0 + (128 + m - 1) / 2] = qm[j]; }
+            else { if (m >= 2) L[XQ1 + (m - 2) / 2] = qo[j]; L[XQ1 + (128 + m - 2) / 2] = qm[j]; }
+          }
+        }
 #pragma unroll
-          for (int j = 0; j < 16; ++j) acc[j] += h * (dw[15 + j - kk] - uw[j + kk]);
-          SCHED_FENCE();
+        for (int j = 0; j < 16; ++j) {
+          const int m = k0 + j;
+          if (j & 1) L[XQ0 + (256 + m - 1) / 2] = qn[j]; else L[XQ1 + (256 + m - 2) / 2] = qn[j];
+        }
+        store8(hq + hs * 128 + k0, qn); store8(hq + hs * 128 + k0 + 8, qn + 8);   // newest replaces oldest (after its load)
+        if (lead) S->hil_slot = hs ^ 1u;
+      }
+      WAVE_SYNC();
+      float acc[16];
+      if (ABL_ON(ABL_HIL) && is_ssb) {
+        // lane (par, g): outputs i = 2*(16g + j) + par, j = 0..15:
+        //   Q[i] = sum_k h[k] * (X[127 + 16g + j - k] - X[16g + j + k]),  k ascending, accumulate from 0.0
+        const int par = s8 & 1, g = s8 >> 1;
+        const float *X = L + (par ? XQ1 : XQ0);
+        // two passes of 8 outputs keep the register windows at 24 + 24 floats
+#pragma unroll
+        for (int p8 = 0; p8 < 2; ++p8) {
+          float a8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a8[j] = 0.0f;
+#pragma unroll 1
+          for (int kc = 0; kc < 4; ++kc) {
+            float dw[24], uw[24];   // dw[m] = X[112 + 16(g-kc) + 8*p8 + m], uw[m] = X[16(g+kc) + 8*p8 + m]
+            const float *dp = X + 112 + 16 * (g - kc) + 8 * p8, *up = X + 16 * (g + kc) + 8 * p8;
+            load8(dp, dw); load8(dp + 8, dw + 8); load8(dp + 16, dw + 16);
+            load8(up, uw); load8(up + 8, uw + 8); load8(up + 16, uw + 16);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+              const float hk = c_hilbert[16 * kc + kk];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) a8[j] += hk * (dw[15 + j - kk] - uw[j + kk]);
+              SCHED_FENCE();
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[8 * p8 + j] = a8[j];
         }
       }
+      WAVE_SYNC();   // all history reads done: the outputs may overwrite the start of X0 (= row W0)
+      if (is_ssb) {
+        const int par = s8 & 1, g = s8 >> 1;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) L[W0 + 2 * (16 * g + j) + par] = acc[j];
-    }
-    WAVE_SYNC();
-    if (is_ssb) {
-      float qh[16], au[16];
-      load16(hi_ring + (hs ^ 1u) * 128, i_del);   // previous block's mixed I == bufferI[3n+i-128] (:111)
-      load16(L + W0 + k0, qh);
+        for (int j = 0; j < 16; ++j) L[W0 + 2 * (16 * g + j) + par] = acc[j];
+      }
+      WAVE_SYNC();
+      if (is_ssb) {   // sideband combine (:115-118) with the delayed I = previous block's mixed I (ring slot hs^1)
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          float qh[8], idl[8], au[8];
+          load8(hi_ring + (hs ^ 1u) * 128 + 8 * h, idl);
+          load8(L + W0 + k0 + 8 * h, qh);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) au[j] = sub_q ? (i_del[j] - qh[j]) : (i_del[j] + qh[j]);
-      store16(L + W0 + k0, au);
-      TAP_REGS(ASDR_TAP_MIX_I, i_del); TAP_REGS(ASDR_TAP_MIX_Q, qh);
+          for (int j = 0; j < 8; ++j) au[j] = sub_q ? (idl[j] - qh[j]) : (idl[j] + qh[j]);
+          store8(L + W0 + k0 + 8 * h, au);
+          TAP8(ASDR_TAP_MIX_I, h, idl); TAP8(ASDR_TAP_MIX_Q, h, qh);
+        }
+      }
     }
 
-    // ---- AM envelope path, AudioSDR.cpp:132-143 -------------------------------------------------------------
+    // ---- AM envelope path, AudioSDR.cpp:132-143 (rows W0/W1 hold the mixed I/Q already) ----------------------
     if (ABL_ON(ABL_ENV) && __any(do_env)) {
-      if (do_env) { store16(L + W0 + k0, mi_); store16(L + W1 + k0, mq_); }
       WAVE_SYNC();
       {
         const int iq = s8 >> 2, st = s8 & 3;
@@ -566,37 +623,47 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
       }
       WAVE_SYNC();
       if (do_env) {
-        float vi[16], vq[16], au[16];
-        load16(L + W0 + k0, vi); load16(L + W1 + k0, vq);
-        TAP_REGS(ASDR_TAP_MIX_I, vi); TAP_REGS(ASDR_TAP_MIX_Q, vq);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          float vi[8], vq[8], au[8];
+          load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+          TAP8(ASDR_TAP_MIX_I, h, vi); TAP8(ASDR_TAP_MIX_Q, h, vq);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { au[j] = sqrtf(vi[j] * vi[j] + vq[j] * vq[j]); if ((j & 3) == 3) SCHED_FENCE(); }
-        store16(L + W0 + k0, au);
+          for (int j = 0; j < 8; ++j) { au[j] = sqrtf(vi[j] * vi[j] + vq[j] * vq[j]); if ((j & 3) == 3) SCHED_FENCE(); }
+          store8(L + W0 + k0 + 8 * h, au);
+        }
       }
       WAVE_SYNC();
       if (do_env && lead) {   // carrier level tracker in binary64, stored float each sample (:141)
         float lvl = S->am_carrier;
-#pragma unroll 4
-        for (int i = 0; i < ASDR_N; ++i) lvl = (float)(.995 * (double)lvl + 0.005 * (double)fabsf(L[W0 + i]));
+#pragma unroll 1
+        for (int i = 0; i < ASDR_N; i += 4) {
+          const float4 x4 = *reinterpret_cast<const float4 *>(L + W0 + i);
+          lvl = (float)(.995 * (double)lvl + 0.005 * (double)fabsf(x4.x));
+          lvl = (float)(.995 * (double)lvl + 0.005 * (double)fabsf(x4.y));
+          lvl = (float)(.995 * (double)lvl + 0.005 * (double)fabsf(x4.z));
+          lvl = (float)(.995 * (double)lvl + 0.005 * (double)fabsf(x4.w));
+        }
         S->am_carrier = lvl; carrier_now = lvl; carrier_fresh = true;
       }
     }
     if (is_sam && pll_locked) {   // audio = rotated Q (:126-128)
-      float vi[16], vq[16];
-      load16(L + W0 + k0, vi); load16(L + W1 + k0, vq);
-      TAP_REGS(ASDR_TAP_MIX_I, vi); TAP_REGS(ASDR_TAP_MIX_Q, vq);
-      store16(L + W0 + k0, vq);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        float vi[8], vq[8];
+        load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+        TAP8(ASDR_TAP_MIX_I, h, vi); TAP8(ASDR_TAP_MIX_Q, h, vq);
+        store8(L + W0 + k0 + 8 * h, vq);
+      }
     }
     if (!is_ssb && !is_am && !is_sam) {   // unknown mode: the reference re-processes stale audio; we emit silence
-      float z[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) z[j] = 0.0f;
-      store16(L + W0 + k0, z);
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      store8(L + W0 + k0, z); store8(L + W0 + k0 + 8, z);
     }
     WAVE_SYNC();
     TAP_ROW(ASDR_TAP_DEMOD, W0);
 
-    // AGC inputs are requested here, one phase early (latency hides behind the audio-filter pipeline)
+    // AGC scalars are requested here, one phase early (latency hides behind the audio-filter pipeline)
     float agc_gain_in = 0.f, agc_old0 = 0.f, agc_carrier0 = 0.f;
     uint32_t agc_hc0 = 0u;
     if (ABL_ON(ABL_AGC) && agc_en) {
@@ -616,18 +683,18 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
     TAP_ROW(ASDR_TAP_AUDIO_FILT, W0);
 
     // ---- AGC, AudioSDR.cpp:404-436 --------------------------------------------------------------------------
-    // Split into (a) the sequential envelope/hang recurrence, which records for every sample which update
-    // governs the gain, and (b) a parallel pass that evaluates the static compressor and applies the gain.
+    // Split into (a) the sequential envelope/hang recurrence, which records for every sample the envelope value
+    // that governs its gain, and (b) a parallel pass that evaluates the static compressor and applies the gain.
     if (ABL_ON(ABL_AGC) && __any(agc_en)) {
       const float *tab = L + AGC_TAB;
       const float gain_in = agc_gain_in;
       if (agc_en) {   // stage the channel's gain table (row of 132 floats) in LDS, all loads in flight at once
         const float *gtab = a.agc_tab + (size_t)P.agc_table * ASDR_AGC_TAB_ROW;
-        float4 agc_t4[5];
+        float4 t4[5];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; agc_t4[r] = (q < 33) ? reinterpret_cast<const float4 *>(gtab)[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; t4[r] = (q < 33) ? reinterpret_cast<const float4 *>(gtab)[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = agc_t4[r]; }
+        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = t4[r]; }
       }
       WAVE_SYNC();
       if (agc_en && lead) {
@@ -640,8 +707,7 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
 #pragma unroll 1
         for (int i = 0; i < ASDR_N; i += 8) {
           float x[8], gvv[8];
-          const float4 xa = *reinterpret_cast<const float4 *>(L + W0 + i), xb = *reinterpret_cast<const float4 *>(L + W0 + i + 4);
-          x[0] = xa.x; x[1] = xa.y; x[2] = xa.z; x[3] = xa.w; x[4] = xb.x; x[5] = xb.y; x[6] = xb.z; x[7] = xb.w;
+          load8(L + W0 + i, x);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             float av = is_am ? am_level : fabsf(x[u]);
@@ -657,8 +723,7 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
             hc = att ? hang : (idle ? 0u : hc - 1u);
             gvv[u] = gv;
           }
-          *reinterpret_cast<float4 *>(L + AGC_GV + i) = make_float4(gvv[0], gvv[1], gvv[2], gvv[3]);
-          *reinterpret_cast<float4 *>(L + AGC_GV + i + 4) = make_float4(gvv[4], gvv[5], gvv[6], gvv[7]);
+          store8(L + AGC_GV + i, gvv);
         }
         S->agc_old_abs = old_abs;
         S->agc_hang_counter = hc;
@@ -668,104 +733,127 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_
       }
       WAVE_SYNC();
       if (agc_en) {
-        float au[16], gvr[16];
-        load16(L + W0 + k0, au); load16(L + AGC_GV + k0, gvr);
+        const float sg = P.agc_static_gain;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          float au[8], gvr[8];
+          load8(L + W0 + k0 + 8 * h, au); load8(L + AGC_GV + k0 + 8 * h, gvr);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float gain = (gvr[j] < 0.0f) ? gain_in : agc_compress(tab, gvr[j]);
-          float o = gain * P.agc_static_gain * au[j];
-          o = (o > 1.0f) ? 1.0f : o;
-          o = (o < -1.0f) ? -1.0f : o;
-          au[j] = o;
-          if ((j & 3) == 3) SCHED_FENCE();
+          for (int j = 0; j < 8; ++j) {
+            const float gain = (gvr[j] < 0.0f) ? gain_in : agc_compress(tab, gvr[j]);
+            float o = gain * sg * au[j];
+            o = (o > 1.0f) ? 1.0f : o;
+            o = (o < -1.0f) ? -1.0f : o;
+            au[j] = o;
+            if ((j & 3) == 3) SCHED_FENCE();
+          }
+          store8(L + W0 + k0 + 8 * h, au);
         }
-        store16(L + W0 + k0, au);
       }
       WAVE_SYNC();
     }
     TAP_ROW(ASDR_TAP_AGC, W0);
 
-    // ---- ALS adaptive notch / peak filter, AudioSDR.cpp:324-352 ------------------------------------------------
-    int arow = W0;
-    if (ABL_ON(ABL_ALS) && __any(als_en)) {
-      const int M = P.als_m, D = P.als_delay;
-      const bool adaptive = P.flags & ASDR_F_ALS_ADAPTIVE, notch = P.flags & ASDR_F_ALS_NOTCH;
-      float *gx = a.als_x + (size_t)ch * ASDR_N + k0, *gw = a.als_w + (size_t)ch * ASDR_N + k0;
-      if (als_en) {
-        float t[16];
-        load16(gx, t); store16(L + ALS_X + k0, t);            // previous block
-        load16(L + W0 + k0, t); store16(L + ALS_X + 128 + k0, t); store16(gx, t);
-        load16(gw, t); store16(L + ALS_W + k0, t);
-      }
-      WAVE_SYNC();
-#define ALS_HIST(idx) (((idx) >= 0 && (idx) < 256) ? L[ALS_X + (idx)] : 0.0f)
-      if (__any(als_en && !adaptive)) {
-        if (als_en && !adaptive) {
-          for (int j = 0; j < 16; ++j) {
-            const int i = 128 + k0 + j;
-            float y = 0.0f;
-            for (int q = 0; q < M; ++q) y += L[ALS_W + q] * ALS_HIST(i - D - q);
-            const float e = L[ALS_X + i] - y;
-            L[ALS_OUT + k0 + j] = notch ? e : y;
+    // ---- ALS adaptive notch / peak filter, AudioSDR.cpp:324-352 (516-float instantiation only) -----------------
+    if constexpr (HAS_ALS) {
+      if (ABL_ON(ABL_ALS) && __any(als_en)) {
+        const int M = P.als_m, D = P.als_delay;
+        const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
+        float *gx = a.als_x + (size_t)ch * ASDR_N + k0, *gw = a.als_w + (size_t)ch * ASDR_N + k0;
+        if (als_en) {
+#pragma unroll 1
+          for (int h = 0; h < 2; ++h) {
+            float t[8];
+            load8(gx + 8 * h, t); store8(L + ALS_X + k0 + 8 * h, t);            // previous block
+            load8(L + W0 + k0 + 8 * h, t); store8(L + ALS_X + 128 + k0 + 8 * h, t); store8(gx + 8 * h, t);
+            load8(gw + 8 * h, t); store8(L + ALS_W + k0 + 8 * h, t);
           }
         }
-      }
-      if (__any(als_en && adaptive)) {
-        // taps change only after samples n = 0, 4, 8, ...; samples sharing one tap set run on lanes s8 = 0..3
-#pragma unroll 1
-        for (int ep = -1; ep < 32; ++ep) {
-          const int base = (ep < 0) ? 0 : 4 * ep + 1;
-          const int cntn = (ep < 0) ? 1 : ((ep == 31) ? 3 : 4);
-          const int n = base + s8;
-          const bool mine = als_en && adaptive && (s8 < cntn);
-          if (mine) {
-            const int i = 128 + n;
-            float y = 0.0f;
-            for (int q = 0; q < M; ++q) y += L[ALS_W + q] * ALS_HIST(i - D - q);
-            const float e = L[ALS_X + i] - y;
-            L[ALS_OUT + n] = notch ? e : y;
-            if ((n & 3) == 0) L[SCR + 1] = e;
-          }
-          WAVE_SYNC();
-          const int nu = (ep < 0) ? 0 : 4 * ep + 4;   // the updating sample of this epoch
-          if (als_en && adaptive && nu < ASDR_N) {
-            const float e = L[SCR + 1];
-            const int iu = 128 + nu;
-            for (int q = s8; q < M; q += 8) {
-              const float gq = e * ALS_HIST(iu - D - q);
-              L[ALS_W + q] += P.als_lambda * gq;
+        WAVE_SYNC();
+#define ALS_HIST(idx) (((idx) >= 0 && (idx) < 256) ? L[ALS_X + (idx)] : 0.0f)
+        if (__any(als_en && !adaptive)) {
+          if (als_en && !adaptive) {
+            for (int j = 0; j < 16; ++j) {
+              const int i = 128 + k0 + j;
+              float y = 0.0f;
+              for (int q = 0; q < M; ++q) y += L[ALS_W + q] * ALS_HIST(i - D - q);
+              const float e = L[ALS_X + i] - y;
+              L[ALS_OUT + k0 + j] = notch ? e : y;
             }
           }
-          WAVE_SYNC();
         }
-      }
-      WAVE_SYNC();
-      if (als_en) {
-        float t[16];
-        load16(L + ALS_W + k0, t); store16(gw, t);
-        arow = ALS_OUT;   // == W0
+        if (__any(als_en && adaptive)) {
+          // taps change only after samples n = 0, 4, 8, ...; samples sharing one tap set run on lanes s8 = 0..3
+#pragma unroll 1
+          for (int ep = -1; ep < 32; ++ep) {
+            const int base = (ep < 0) ? 0 : 4 * ep + 1;
+            const int cntn = (ep < 0) ? 1 : ((ep == 31) ? 3 : 4);
+            const int n = base + s8;
+            const bool mine = als_en && adaptive && (s8 < cntn);
+            if (mine) {
+              const int i = 128 + n;
+              float y = 0.0f;
+              for (int q = 0; q < M; ++q) y += L[ALS_W + q] * ALS_HIST(i - D - q);
+              const float e = L[ALS_X + i] - y;
+              L[ALS_OUT + n] = notch ? e : y;
+              if ((n & 3) == 0) L[SCR1] = e;
+            }
+            WAVE_SYNC();
+            const int nu = (ep < 0) ? 0 : 4 * ep + 4;   // the updating sample of this epoch
+            if (als_en && adaptive && nu < ASDR_N) {
+              const float e = L[SCR1];
+              const int iu = 128 + nu;
+              for (int q = s8; q < M; q += 8) {
+                const float gq = e * ALS_HIST(iu - D - q);
+                L[ALS_W + q] += P.als_lambda * gq;
+              }
+            }
+            WAVE_SYNC();
+          }
+        }
+        WAVE_SYNC();
+        if (als_en) {
+#pragma unroll 1
+          for (int h = 0; h < 2; ++h) { float t[8]; load8(L + ALS_W + k0 + 8 * h, t); store8(gw + 8 * h, t); }
+        }
       }
     }
     {
-      float au[16];
-      load16(L + arow + k0, au);
-      TAP_REGS(ASDR_TAP_ALS, au);
       // ---- output, AudioSDR.cpp:158-161: float product, x 32767.0 in binary64, truncate, wrap to int16 ------
-      union { int4 v[2]; int16_t s[16]; } ro;
+      const float og = P.output_gain;
+      union { int4 v; int16_t s[8]; } ro[2];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int v = (int)((double)(P.output_gain * au[j]) * 32767.0);
-        ro.s[j] = muted ? (int16_t)0 : (int16_t)v;
-        if ((j & 3) == 3) SCHED_FENCE();
+      for (int h = 0; h < 2; ++h) {
+        float au[8];
+        load8(L + W0 + k0 + 8 * h, au);
+        TAP8(ASDR_TAP_ALS, h, au);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int v = (int)((double)(og * au[j]) * 32767.0);
+          ro[h].s[j] = muted ? (int16_t)0 : (int16_t)v;
+        }
+        SCHED_FENCE();
       }
       if (valid) {
         int4 *po = reinterpret_cast<int4 *>(a.out + io);
-        po[0] = ro.v[0]; po[1] = ro.v[1];
+        po[0] = ro[0].v; po[1] = ro[1].v;
       }
     }
     if (lead) S->status = status;
     WAVE_SYNC();
   }
+#undef P
+}
+
+// no channel of the batch has the ALS filter enabled: 388 floats of LDS per channel
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * 388 + 260];
+  asdr_update_body<388, false>(a, lds);
+}
+// some channel uses the ALS filter: 516 floats per channel (256-sample ALS history + 128 taps in LDS)
+extern "C" __global__ __launch_bounds__(64, 2) void asdr_update_kernel_als(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * 516 + 260];
+  asdr_update_body<516, true>(a, lds);
 }
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
@@ -798,10 +886,12 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
   }
 }
 
-extern "C" int asdr_launch_update(const UpdateArgs *a, hipStream_t stream) {
+// `with_als`: some channel of the batch has the ALS filter enabled -> the larger-LDS instantiation
+extern "C" int asdr_launch_update(const UpdateArgs *a, int with_als, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  if (with_als) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a);
+  else hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -13,3 +13,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$ROOT/$OUT/fet
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$ROOT/$OUT/write" -- $CMD > "$ROOT/$OUT/write.log" 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$ROOT/$OUT/grbm" -- $CMD > "$ROOT/$OUT/grbm.log" 2>&1
 find "$ROOT/$OUT" -name "*counter_collection.csv" | head
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d "$ROOT/$OUT/tcc" -- $CMD > "$ROOT/$OUT/tcc.log" 2>&1
