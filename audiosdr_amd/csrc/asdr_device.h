@@ -7,8 +7,9 @@
  *
  *   params   ChanParams  [C+1]            96 B  read-only per launch (row C = dummy channel)
  *   small    ChanSmall   [C+1]           448 B  biquad states, phases, AGC/PLL/NB scalars, ring slots
- *   nb_hist  float       [C+1][3][2][128]  3 KiB  noise-blanker ring: slot x {I,Q} x sample (oldest, middle, newest)
- *   nb_mask  float       [C+1][144]        576 B  mask of (middle block + 10 look-ahead), 138 used
+ *   nb_hist  int16       [C+1][3][2][128] 1.5 KiB noise-blanker ring of RAW samples: slot x {I,Q} x sample (oldest, middle,
+ *                                                 newest); the gains in force at arrival are in ChanSmall.nb_gain
+ *   nb_mask  uint8       [C+1][160]        160 B  mask codes of (middle block + 10 look-ahead), 138 used
  *   hil_q    float       [C+1][2][128]     1 KiB  Hilbert Q history ring (2 previous shifted blocks)
  *   hil_i    float       [C+1][2][128]     1 KiB  ring of mixed I blocks (this block, previous = the 128-sample delay)
  *   als_x    float       [C+1][128]        512 B  previous ALS input block
@@ -71,14 +72,15 @@ typedef struct {
   float pll_d0, pll_d1, pll_phase_est, pll_freq; /* delay0, delay1, phase_est, _PLLfreq */
   uint32_t nb_slot, hil_slot;         /* ring positions (oldest slot) */
   uint32_t status;                    /* ASDR_S_* bits */
-  uint32_t pad_[15];
+  float nb_gain[3][2];                /* input gains {I,Q} in force when each noise-blanker ring slot was written */
+  uint32_t pad_[9];
 } ChanSmall; /* 80 + 17 + 15 = 112 words = 448 B */
 
 #define ASDR_S_AGC_ACTIVE  (1u << 0) /* _agc_is_active (in-class initialiser: true) */
 #define ASDR_S_NB_DETECTED (1u << 1) /* _nb_impulseDetected */
 #define ASDR_S_PLL_LOCKED  (1u << 2) /* _SAM_PLL_isLocked */
 
-#define ASDR_NB_MASK_ROW 144
+#define ASDR_NB_MASK_ROW 160
 #define ASDR_NB_MASK_USED 138
 #define ASDR_AGC_TAB_ROW 132
 
@@ -98,7 +100,9 @@ typedef struct {
 typedef struct {
   const ChanParams *params;
   ChanSmall *small;
-  float *nb_hist, *nb_mask, *hil_q, *hil_i, *als_x, *als_w;
+  int16_t *nb_hist;
+  uint8_t *nb_mask;
+  float *hil_q, *hil_i, *als_x, *als_w;
   const float *agc_tab;
   const int32_t *sched;   /* channel index per wave slot, padded to a multiple of 8 with n_channels (dummy) */
   int32_t n_sched;        /* multiple of 8 */

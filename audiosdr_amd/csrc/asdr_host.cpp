@@ -115,7 +115,9 @@ struct asdr_batch {
   // device
   ChanParams *d_params = nullptr;
   ChanSmall *d_small = nullptr;
-  float *d_nb_hist = nullptr, *d_nb_mask = nullptr, *d_hil_q = nullptr, *d_hil_i = nullptr, *d_als_x = nullptr,
+  int16_t *d_nb_hist = nullptr;
+  uint8_t *d_nb_mask = nullptr;
+  float *d_hil_q = nullptr, *d_hil_i = nullptr, *d_als_x = nullptr,
         *d_als_w = nullptr, *d_agc_tab = nullptr, *d_taps = nullptr;
   size_t agc_tab_cap = 0;
   int32_t *d_sched = nullptr;
@@ -315,8 +317,8 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
     alloc((void **)&b->d_params, rows * sizeof(ChanParams));
     alloc((void **)&b->d_small, rows * sizeof(ChanSmall));
-    alloc((void **)&b->d_nb_hist, rows * 768 * sizeof(float));
-    alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(float));
+    alloc((void **)&b->d_nb_hist, rows * 768 * sizeof(int16_t));
+    alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(uint8_t));
     alloc((void **)&b->d_hil_q, rows * 256 * sizeof(float));
     alloc((void **)&b->d_hil_i, rows * 256 * sizeof(float));
     alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));

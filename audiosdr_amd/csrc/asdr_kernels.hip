@@ -214,6 +214,28 @@ __device__ __forceinline__ void store8(float *p, const float *v) {
   q[0] = make_float4(v[0], v[1], v[2], v[3]); q[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// AudioSDR.cpp:68-69 for 8 raw samples: ((float)s / 32767.0) * gain in binary64, rounded to float by the store
+__device__ __forceinline__ void scale8(const int16_t *s, double g, float *out) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    out[j] = (float)(div_by_const((double)s[j], 32767.0, 1.0 / 32767.0) * g);
+    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// The blanker mask only ever holds {0, 1, .933, .750, .500, .250, .067} (AudioSDR.cpp:608, 623, 630): one byte each in HBM.
+__device__ __forceinline__ float mask_decode(uint32_t c) {
+  float v = (c == 0u) ? 0.0f : 1.0f;
+  v = (c == 2u) ? (float)0.933 : v; v = (c == 3u) ? (float)0.750 : v; v = (c == 4u) ? (float)0.500 : v;
+  v = (c == 5u) ? (float)0.250 : v; v = (c == 6u) ? (float)0.067 : v;
+  return v;
+}
+__device__ __forceinline__ uint32_t mask_encode(float v) {
+  uint32_t c = (v == 0.0f) ? 0u : 1u;
+  c = (v == (float)0.933) ? 2u : c; c = (v == (float)0.750) ? 3u : c; c = (v == (float)0.500) ? 4u : c;
+  c = (v == (float)0.250) ? 5u : c; c = (v == (float)0.067) ? 6u : c;
+  return c;
+}
+
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define WAVE_SYNC() __syncthreads() /* workgroup == one wave: lowers to a wave barrier + LDS/VMEM waits */
@@ -273,35 +295,40 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     bool carrier_fresh = false;
     const size_t io = ((size_t)ch * a.n_blocks + blk) * ASDR_N + k0;
     const bool nb_wave = ABL_ON(ABL_NB) && __any(nb_en);   // wave-uniform: some channel of this wave has the blanker on
-    float *hist = a.nb_hist + (size_t)ch * 768;
-    float *mrow = a.nb_mask + (size_t)ch * ASDR_NB_MASK_ROW;
+    int16_t *hist = a.nb_hist + (size_t)ch * 768;              // 3 slots x {I,Q} x 128 raw int16 samples
+    uint32_t *mrow = reinterpret_cast<uint32_t *>(a.nb_mask + (size_t)ch * ASDR_NB_MASK_ROW) + 5 * s8;   // this lane's 20 mask codes
 
     // ---- load + input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
-    // With a blanker in the wave the scaled block is parked in the third ring slot in HBM (also by channels whose
-    // blanker is OFF: their ring is dead state, enabling the blanker always resets it, AudioSDR.cpp:653-656);
-    // otherwise it goes straight to the IF filter's LDS rows.
-    {
-      union { int4 v; int16_t s[8]; } ri[2], rq[2];
-      ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
-      if (valid) {
-        const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
-        const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
-        ri[0].v = pi[0]; ri[1].v = pi[1]; rq[0].v = pq[0]; rq[1].v = pq[1];
+    // With a blanker in the wave, the blanker's delay line is kept as RAW int16 samples plus the gains that were in
+    // force when each block arrived: the scaled float is an exact function of (sample, gain), so re-scaling on
+    // read reproduces the reference's stored floats bit for bit at a quarter of the HBM traffic.
+    union Raw8 { int4 v; int16_t s[8]; };
+    Raw8 ri[2], rq[2];
+    ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
+    if (valid) {
+      const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
+      const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
+      ri[0].v = pi[0]; ri[1].v = pi[1]; rq[0].v = pq[0]; rq[1].v = pq[1];
+    }
+    const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
+    if (nb_wave) {
+      if (nb_en) {   // newest block -> third ring slot, with its gains
+        int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + k0);
+        ni[0] = ri[0].v; ni[1] = ri[1].v; ni[16] = rq[0].v; ni[17] = rq[1].v;   // Q row starts 128 samples = 16 int4 later
+        if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
       }
-      const double gi = (double)P.in_gain_i, gq = (double)P.in_gain_q;
-      float *new_i = hist + ns_new * 256 + k0;
+      if (tap_on) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { float xi[8], xq[8]; scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
+                                      TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq); }
+      }
+    } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float xi[8], xq[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          xi[j] = (float)(div_by_const((double)ri[h].s[j], 32767.0, 1.0 / 32767.0) * gi);
-          xq[j] = (float)(div_by_const((double)rq[h].s[j], 32767.0, 1.0 / 32767.0) * gq);
-          if ((j & 1) == 1) SCHED_FENCE();
-        }
+        scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
         TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq);
-        if (nb_wave) { store8(new_i + 8 * h, xi); store8(new_i + 128 + 8 * h, xq); }
-        else { store8(L + W0 + k0 + 8 * h, xi); store8(L + W1 + k0 + 8 * h, xq); }
+        store8(L + W0 + k0 + 8 * h, xi); store8(L + W1 + k0 + 8 * h, xq);
         SCHED_FENCE();
       }
     }
@@ -310,21 +337,26 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
     // in HBM holds them; output = mask x oldest (2 blocks late).
     if (nb_wave) {
-      float4 mk4[5];
+      uint32_t mkc[5];
       if (nb_en) {
-        const float *old_i = hist + ns * 256 + k0, *mid_i = hist + ns_mid * 256 + k0;
-        // mask row (carried mask[128..265]) requested now, consumed after the sequential pass
+        const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + k0), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + k0);
+        const double gmi = (double)S->nb_gain[ns_mid][0], gmq = (double)S->nb_gain[ns_mid][1];
+        const double goi = (double)S->nb_gain[ns][0], goq = (double)S->nb_gain[ns][1];
+        // mask codes of the carried mask[128..265] requested now, consumed after the sequential pass
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; mk4[r] = (q < 36) ? reinterpret_cast<const float4 *>(mrow)[q] : make_float4(1.f, 1.f, 1.f, 1.f); }
+        for (int r = 0; r < 5; ++r) mkc[r] = mrow[r];
         // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628)
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
+          Raw8 wi, wq;
           float vi[8], vq[8];
-          load8(mid_i + 8 * h, vi); load8(mid_i + 128 + 8 * h, vq);
+          wi.v = mid4[h]; wq.v = mid4[16 + h];
+          scale8(wi.s, gmi, vi); scale8(wq.s, gmq, vq);
 #pragma unroll
           for (int j = 0; j < 8; ++j) { L[NB_MAG + 50 + k0 + 8 * h + j] = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]); if ((j & 3) == 3) SCHED_FENCE(); }
           if (k0 + 8 * h + 7 >= 78) {   // only samples 78..127 of the oldest block are re-scanned
-            load8(old_i + 8 * h, vi); load8(old_i + 128 + 8 * h, vq);
+            wi.v = old4[h]; wq.v = old4[16 + h];
+            scale8(wi.s, goi, vi); scale8(wq.s, goq, vq);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int k = k0 + 8 * h + j;
@@ -373,8 +405,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (nb_en) {
         // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
         // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
+        // lane s8 decodes mask entries 20*s8 .. 20*s8+19 (entries >= 138 are padding)
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 36) *reinterpret_cast<float4 *>(L + NB_MSK + 4 * q) = mk4[r]; }
+        for (int r = 0; r < 5; ++r) {
+          const int e = 20 * s8 + 4 * r;
+          if (e < ASDR_NB_MASK_USED + 2)
+            *reinterpret_cast<float4 *>(L + NB_MSK + e) = make_float4(mask_decode(mkc[r] & 0xFFu), mask_decode((mkc[r] >> 8) & 0xFFu),
+                                                                       mask_decode((mkc[r] >> 16) & 0xFFu), mask_decode(mkc[r] >> 24));
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;
       }
@@ -418,16 +456,25 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         load8(L + NB_MSK + k0, mk); load8(L + NB_MSK + k0 + 8, mk + 8);
         if (nb_en) {
 #pragma unroll
-          for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 36) reinterpret_cast<float4 *>(mrow)[q] = *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + 4 * q); }
+          for (int r = 0; r < 5; ++r) {
+            const int e = 20 * s8 + 4 * r;   // entries >= 138 are padding: store code 1
+            const float4 mv = (e < ASDR_NB_MASK_USED + 2) ? *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+            mrow[r] = mask_encode(mv.x) | (mask_encode(mv.y) << 8) | (mask_encode(mv.z) << 16) | (mask_encode(mv.w) << 24);
+          }
         }
       }
       WAVE_SYNC();
-      {   // output = mask x oldest block (:646-649) -> IF filter rows; blanker-off channels read their parked block x 1.0
-        const float *src = hist + (nb_en ? ns : ns_new) * 256 + k0;
-#pragma unroll 1
+      {   // output = mask x oldest block (:646-649) -> IF filter rows; blanker-off channels pass their own input (x 1.0)
+        const int4 *src4 = nb_en ? reinterpret_cast<const int4 *>(hist + ns * 256 + k0) : reinterpret_cast<const int4 *>(a.in_i + io);
+        const int4 *srq4 = nb_en ? src4 + 16 : reinterpret_cast<const int4 *>(a.in_q + io);
+        const double goi = nb_en ? (double)S->nb_gain[ns][0] : (double)gain_i, goq = nb_en ? (double)S->nb_gain[ns][1] : (double)gain_q;
+#pragma unroll   /* mk[] is a register array: h must be a compile-time index */
         for (int h = 0; h < 2; ++h) {
+          Raw8 wi, wq;
           float vi[8], vq[8];
-          load8(src + 8 * h, vi); load8(src + 128 + 8 * h, vq);
+          wi.v = make_int4(0, 0, 0, 0); wq.v = wi.v;
+          if (nb_en || valid) { wi.v = src4[h]; wq.v = srq4[h]; }
+          scale8(wi.s, goi, vi); scale8(wq.s, goq, vq);
 #pragma unroll
           for (int j = 0; j < 8; ++j) { const float mv = nb_en ? mk[8 * h + j] : 1.0f; vi[j] = mv * vi[j]; vq[j] = mv * vq[j]; }
           store8(L + W0 + k0 + 8 * h, vi); store8(L + W1 + k0 + 8 * h, vq);
@@ -565,7 +612,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         //   Q[i] = sum_k h[k] * (X[127 + 16g + j - k] - X[16g + j + k]),  k ascending, accumulate from 0.0
         const int par = s8 & 1, g = s8 >> 1;
         const float *X = L + (par ? XQ1 : XQ0);
-        // two passes of 8 outputs keep the register windows at 24 + 24 floats
+        // two passes of 8 outputs keep the register windows at 24 + 24 floats.  (A packed v_pk_*_f32 formulation of
+        // this loop -- half the instructions, bit-identical -- measured 10 % SLOWER end to end: profiles/README.md.)
 #pragma unroll
         for (int p8 = 0; p8 < 2; ++p8) {
           float a8[8];
@@ -877,8 +925,9 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
   if (all || (r & ASDR_R_IMG)) { if (t < 32) (&S->img_state[0][0])[t] = 0.0f; }
   if (all || (r & ASDR_R_AF)) { if (t < 16) S->af_state[t] = 0.0f; }
   if (all || (r & ASDR_R_NB)) {
-    for (int i = t; i < 768; i += 128) a.nb_hist[(size_t)ch * 768 + i] = 0.0f;
-    for (int i = t; i < ASDR_NB_MASK_ROW; i += 128) a.nb_mask[(size_t)ch * ASDR_NB_MASK_ROW + i] = 1.0f;
+    for (int i = t; i < 768; i += 128) a.nb_hist[(size_t)ch * 768 + i] = 0;
+    for (int i = t; i < ASDR_NB_MASK_ROW; i += 128) a.nb_mask[(size_t)ch * ASDR_NB_MASK_ROW + i] = 1;   // code 1 == 1.0
+    if (t < 6) (&S->nb_gain[0][0])[t] = 0.0f;
   }
   if (all || (r & ASDR_R_ALS)) {
     a.als_x[(size_t)ch * 128 + t] = 0.0f;
