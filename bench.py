@@ -130,6 +130,14 @@ def main():
         samples = float(world) * n_ch * BLOCK * args.steps
         k_ms = float(np.mean(kernel_ms))
         ach = ALGO_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/prof_pmc.sh)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pj = json.load(f)
+            if n_ch == CHANNELS_PER_GPU:
+                traffic = pj.get("traffic_bytes_per_launch")
+        except Exception:
+            pass
         out = {
             "metric": "Msamples/s through full SSB demod chain, batched 128-sample blocks",
             "value": round(samples / wall / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -138,7 +146,7 @@ def main():
             "config": {"workload": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
                        "channels_per_gpu": n_ch, "block": BLOCK, "sharding": "channels, no collective"},
             "roofline": {"bound": "hbm", "kernel": "asdr_update_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BLOCK * n_ch,
                          "hbm_read_share_frac": round(ALGO_READ_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
