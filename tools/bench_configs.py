@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""BASELINE.md configs 1-5 on ONE MI355X (the per-GPU share of the multi-GPU configs), kernel time from HIP events,
+each spot-checked bit-for-bit against the CPU oracle.  Prints one JSON line per config.  (GPU box.)
+
+  C1  AM, 1 channel, 8+ blocks              (CPU oracle timing; GPU run for latency only)
+  C2  USB, 65,536 channels x 1 block/launch (the bench.py workload) and x 64 blocks/launch (streaming variant)
+  C3  SAM + PLL + AGC, 262,144 channels x 1 block/launch, measured after the PLLs have locked; lock fraction
+  C4  mixed modes (c mod 7) + ALS notch, 131,072 channels (= 1 M over 8 GPUs) x 1 block/launch
+  C5  WSPR receiver settings, 512 channels (= 4096 over 8 GPUs), 2 minutes = 41,344 blocks, T blocks per launch
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import audiosdr_amd as A  # noqa: E402
+from audiosdr_amd.synth import make_iq  # noqa: E402
+from oracle import asdr_oracle as ao  # noqa: E402
+import torch  # noqa: E402
+
+BLOCK = 128
+
+
+def tiled(n_ch, n_blk, uniq, **sig):
+    I, Q = make_iq(uniq, n_blk, **sig)
+    reps = (n_ch + uniq - 1) // uniq
+    return np.tile(I, (reps, 1, 1))[:n_ch], np.tile(Q, (reps, 1, 1))[:n_ch]
+
+
+def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
+    """I, Q: [ch][n_blk][128] host arrays, consumed blocks_per_launch at a time.  Returns (ms per launch list, all outputs)."""
+    n_ch, n_blk = I.shape[0], I.shape[1]
+    outs, ms = [], []
+    T = blocks_per_launch
+    dO = torch.empty((n_ch, T, BLOCK), dtype=torch.int16, device="cuda")
+    for li, b0 in enumerate(range(0, n_blk - T + 1, T)):
+        dI = torch.from_numpy(np.ascontiguousarray(I[:, b0:b0 + T])).cuda()
+        dQ = torch.from_numpy(np.ascontiguousarray(Q[:, b0:b0 + T])).cuda()
+        torch.cuda.synchronize()
+        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
+        t = batch.last_kernel_ms()
+        if li >= warm_launches:
+            ms.append(t)
+        outs.append(dO.cpu().numpy().copy())
+        if len(ms) >= timed_launches:
+            break
+    return ms, np.concatenate(outs, axis=1)
+
+
+def check(configure, I, Q, got, channels):
+    for c in channels:
+        o = ao.OracleSDR()
+        configure(o, c)
+        want = o.update(I[c, :got.shape[1]], Q[c, :got.shape[1]]).reshape(got.shape[1], BLOCK)
+        if not np.array_equal(got[c], want):
+            return False
+    return True
+
+
+def report(name, n_ch, T, ms, extra):
+    k = float(np.median(ms))
+    out = {"config": name, "channels": n_ch, "blocks_per_launch": T, "kernel_ms_median": round(k, 5),
+           "Msamples_per_s": round(n_ch * T * BLOCK / k / 1e3, 1), "launches_timed": len(ms)}
+    out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    which = set(sys.argv[1:]) or {"c1", "c2", "c2s", "c3", "c4", "c5"}
+    if "c1" in which:
+        I, Q = make_iq(1, 2048, fc=6890.0, A=0.3, m=0.5, fm=400.0)
+        t, _ = ao.bench_run(1, I, Q, 1)
+        o = ao.OracleSDR(); o.setDemodMode(ao.AMmode)
+        b = A.AudioSDRBatch(1); b.setDemodMode(A.AMmode)
+        got = b.update(I[:, :16], Q[:, :16])
+        ok = np.array_equal(got[0].reshape(-1), o.update(I[0, :16], Q[0, :16]))
+        ms = []
+        for i in range(16, 48):
+            b.update(I[:, i:i + 1], Q[:, i:i + 1]); ms.append(b.last_kernel_ms())
+        print(json.dumps({"config": "C1 AM single channel", "cpu_oracle_us_per_block": round(t / 2048 * 1e6, 2),
+                          "cpu_oracle_Msamples_per_s": round(2048 * BLOCK / t / 1e6, 2), "gpu_kernel_us_per_block_1ch": round(float(np.median(ms)) * 1e3, 1),
+                          "parity": bool(ok)}), flush=True)
+        b.close()
+    if "c2" in which or "c2s" in which:
+        def cfg(s, c=0):
+            s.setDemodMode(1); s.enableAudioFilter()
+        n_ch = 65536
+        if "c2" in which:
+            I, Q = tiled(n_ch, 12, 2048, fc=6290.0, A=0.25)
+            b = A.AudioSDRBatch(n_ch); cfg(b)
+            ms, got = run_launches(b, I, Q, 1, 4, 8)
+            report("C2 USB 64k x 1 block/launch", n_ch, 1, ms, {"parity": check(cfg, I, Q, got, [0, 777, 2047, 65535])})
+            b.close()
+        if "c2s" in which:
+            I, Q = tiled(n_ch, 64 * 3, 512, fc=6290.0, A=0.25)
+            b = A.AudioSDRBatch(n_ch); cfg(b)
+            ms, got = run_launches(b, I, Q, 64, 1, 2)
+            report("C2 streaming USB 64k x 64 blocks/launch", n_ch, 64, ms, {"parity": check(cfg, I, Q, got, [0, 511, 40000])})
+            b.close()
+    if "c3" in which:
+        def cfg(s, c=0):
+            s.setDemodMode(5); s.setNoiseBlankerThresholdDb(10.0); s.enableAudioFilter(); s.setAudioFilter(0)
+        n_ch, uniq = 262144, 3584
+        fc = 6890.0 + (np.arange(uniq) % 7 - 3) * 50.0
+        I, Q = tiled(n_ch, 16, uniq, fc=fc, A=0.3, m=0.5, fm=400.0)
+        b = A.AudioSDRBatch(n_ch); cfg(b)
+        ms, got = run_launches(b, I, Q, 1, 10, 6)
+        st = b.read_status()
+        report("C3 SAM 256k x 1 block/launch", n_ch, 1, ms, {"lock_fraction": float(st["sam_locked"].mean()),
+                                                              "parity": check(cfg, I, Q, got, [0, 3, 3583, 262143 % uniq + uniq * 70])})
+        b.close()
+    if "c4" in which:
+        def cfg(s, c):
+            s.setDemodMode(c % 7); s.enableALSfilter(); s.setNoiseBlankerThresholdDb(10.0)
+        n_ch, uniq = 131072, 3584
+        I, Q = tiled(n_ch, 12, uniq, fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15)
+        b = A.AudioSDRBatch(n_ch)
+        for m in range(7):
+            pass
+        # per-channel modes: c mod 7 (uniq is a multiple of 7, so tiling keeps the pattern)
+        L = A.load_library()
+        for c in range(n_ch):
+            L.asdr_setDemodMode(b._h, c, c % 7)
+        b.enableALSfilter(); b.setNoiseBlankerThresholdDb(10.0)
+        ms, got = run_launches(b, I, Q, 1, 4, 8)
+        report("C4 mixed modes + ALS, 128k (1/8 of 1M) x 1 block/launch", n_ch, 1, ms,
+               {"parity": check(cfg, I, Q, got, [0, 1, 2, 3, 4, 5, 6, 3583, 100000])})
+        b.close()
+    if "c5" in which:
+        def cfg(s, c=0):   # BareBonesWSPR.ino:87-102,129
+            s.enableAGC(); s.setAGCmode(2); s.disableALSfilter(); s.disableNoiseBlanker(); s.setNoiseBlankerThresholdDb(10.0)
+            s.setInputGain(1.0); s.setOutputGain(0.5); s.setIQgainBalance(1.020); s.setAudioFilter(2); s.setDemodMode(6); s.setMute(0)
+        n_ch, T, total = 512, 646, 41344     # 41344 = 64 x 646
+        I, Q = make_iq(n_ch, T * 3, fc=6890.0, A=0.02, noise=0.05)
+        b = A.AudioSDRBatch(n_ch); cfg(b)
+        ms, got = run_launches(b, I, Q, T, 1, 2)
+        k = float(np.median(ms))
+        report("C5 WSPR 512 ch (1/8 of 4096), %d blocks/launch" % T, n_ch, T, ms,
+               {"two_minutes_41344_blocks_s": round(k * 1e-3 * total / T, 3), "times_real_time": round(120.0 / (k * 1e-3 * total / T), 1),
+                "parity": check(cfg, I, Q, got, [0, 511])})
+        b.close()
+
+
+if __name__ == "__main__":
+    main()
