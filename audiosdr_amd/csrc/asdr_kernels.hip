@@ -25,13 +25,21 @@
 #include "../../include/asdr.h"
 
 // ---- per-channel LDS layout (floats) --------------------------------------------------------------
-// Two instantiations: STRIDE 388 (no channel of the batch uses the ALS filter; 12 waves/CU fit) and 516 (ALS).
-// 388 = 97 sixteen-byte slots == 1 (mod 16): the 8 channels' rows start on different LDS slots.
+// Two instantiations: STRIDE 388 (no channel of the batch uses the ALS filter; 11 waves/CU fit) and 516 (ALS).
+// 388 = 97 sixteen-byte slots == 1 (mod 16): the 8 channels' rows start on different LDS slots.  (A layout that also
+// removes the 2-way conflict between the two sample parities of the Hilbert reads, -DASDR_STRIDE=420 -DASDR_XQ1=224,
+// measured 7 % slower in the same process: profiles/README.md.)
 #define W0 0       // working row A: I, later the mono audio
 #define W1 128     // working row B: Q
 #define PH 256     // mixer phase sequence [256,384)
 #define XQ0 0      // Hilbert history, de-interleaved, overlays W0/W1/PH once the mixer has consumed them:
-#define XQ1 192    //   X0 = odd samples [0,192), X1 = even samples shifted by one [192,384)
+#ifndef ASDR_XQ1
+#define ASDR_XQ1 192
+#endif
+#ifndef ASDR_STRIDE
+#define ASDR_STRIDE 388
+#endif
+#define XQ1 ASDR_XQ1   //   X0 = odd samples [0,192), X1 = even samples shifted by one [192,384)
 #define SCR0 387   // SAM lock flag (last, unused word of the AGC table row; never live together)
 // noise-blanker overlay (dead before the rows above are written)
 #define NB_MAG 0   // envelope of detection indices 78..255: mag[0..177]; later overlaid by the mask
@@ -895,8 +903,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
 // no channel of the batch has the ALS filter enabled: 388 floats of LDS per channel
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * 388 + 260];
-  asdr_update_body<388, false>(a, lds);
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE + 260];
+  asdr_update_body<ASDR_STRIDE, false>(a, lds);
 }
 // some channel uses the ALS filter: 516 floats per channel (256-sample ALS history + 128 taps in LDS)
 extern "C" __global__ __launch_bounds__(64, 2) void asdr_update_kernel_als(UpdateArgs a) {
