@@ -98,13 +98,19 @@ typedef struct {
 } ChainConsts;
 
 typedef struct {
+  int32_t ch;
+  uint32_t mode, flags, pad_;
+} SlotInfo;
+
+typedef struct {
   const ChanParams *params;
   ChanSmall *small;
   int16_t *nb_hist;
   uint8_t *nb_mask;
   float *hil_q, *hil_i, *als_x, *als_w;
   const float *agc_tab;
-  const int32_t *sched;   /* channel index per wave slot, padded to a multiple of 8 with n_channels (dummy) */
+  const SlotInfo *sched;  /* per wave slot: channel index (padded to a multiple of 8 with the dummy channel n_channels),
+                             mode and flags -- one 16-B load instead of the dependent chain sched -> params */
   int32_t n_sched;        /* multiple of 8 */
   int32_t n_channels;
   const int16_t *in_i, *in_q;

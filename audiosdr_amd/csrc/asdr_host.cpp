@@ -109,7 +109,7 @@ struct asdr_batch {
   std::vector<AgcTable> agc_pool;
   std::vector<ChanParams> hp;
   std::vector<uint32_t> reset;
-  std::vector<int32_t> sched;
+  std::vector<SlotInfo> sched;
   bool params_dirty = true, reset_pending = true, agc_pool_dirty = true;
   bool any_als = false;          // some channel has the ALS filter enabled -> larger-LDS kernel instantiation
   // device
@@ -120,7 +120,7 @@ struct asdr_batch {
   float *d_hil_q = nullptr, *d_hil_i = nullptr, *d_als_x = nullptr,
         *d_als_w = nullptr, *d_agc_tab = nullptr, *d_taps = nullptr;
   size_t agc_tab_cap = 0;
-  int32_t *d_sched = nullptr;
+  SlotInfo *d_sched = nullptr;
   uint32_t *d_reset = nullptr;
   int16_t *d_io[3] = {nullptr, nullptr, nullptr};
   size_t io_cap = 0;
@@ -242,10 +242,10 @@ int flush(asdr_batch *b, hipStream_t stream) {
     std::stable_sort(order.begin(), order.end(),
                      [&](int32_t x, int32_t y) { return sched_key(b->hp[x]) < sched_key(b->hp[y]); });
     const int n_sched = ((b->n + 7) / 8) * 8;
-    b->sched.assign(n_sched, b->n);
-    std::copy(order.begin(), order.end(), b->sched.begin());
+    b->sched.assign(n_sched, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});
+    for (int i = 0; i < b->n; i++) b->sched[i] = SlotInfo{order[i], b->hp[order[i]].mode, b->hp[order[i]].flags, 0u};
     HIPCHK(hipMemcpyAsync(b->d_params, b->hp.data(), rows * sizeof(ChanParams), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(b->d_sched, b->sched.data(), n_sched * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(b->d_sched, b->sched.data(), n_sched * sizeof(SlotInfo), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));  // host vectors may be rewritten by the next setter
     b->params_dirty = false;
   }
@@ -323,7 +323,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_hil_i, rows * 256 * sizeof(float));
     alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
     alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
-    alloc((void **)&b->d_sched, (rows + 8) * sizeof(int32_t));
+    alloc((void **)&b->d_sched, (rows + 8) * sizeof(SlotInfo));
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
     if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;

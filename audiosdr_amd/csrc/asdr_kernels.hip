@@ -257,15 +257,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   float *sine = lds + 8 * STRIDE;
   for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
-  const int ch_ = a.sched[blockIdx.x * 8 + c8];
+  const int4 slot = *reinterpret_cast<const int4 *>(a.sched + blockIdx.x * 8 + c8);   // {channel, mode, flags, -}
+  const int ch_ = slot.x;
   const bool valid = ch_ < a.n_channels;
   const int loff_ = c8 * STRIDE;
-  const ChanParams *Pp_ = a.params + ch_;
 #define P (*Pp)
   const ChainConsts K = a.k;
 
-  const uint32_t mode = Pp_->mode;
-  const uint32_t pflags = Pp_->flags;
+  const uint32_t mode = (uint32_t)slot.y;
+  const uint32_t pflags = (uint32_t)slot.z;
   const bool is_ssb = (mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                       (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode);
   const bool is_am = (mode == ASDR_AMmode), is_sam = (mode == ASDR_SAMmode);

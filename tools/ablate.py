@@ -47,7 +47,13 @@ def run(rounds=5, n_ch=65536):
     dQ = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).cuda() for b in range(2)]
     dOut = torch.empty((n_ch, 128), dtype=torch.int16, device="cuda")
     libs = {}
-    for name in list(VARIANTS) + list(EXTRA):
+    import glob
+    names = list(VARIANTS) + list(EXTRA)
+    names += [os.path.basename(f)[8:-3] for f in sorted(glob.glob(os.path.join(VDIR, "libasdr_*.so"))) if os.path.basename(f)[8:-3] not in names]
+    only = os.environ.get("ABLATE_ONLY")
+    if only:
+        names = [n for n in names if n in only.split(",")]
+    for name in names:
         p = os.path.join(VDIR, "libasdr_%s.so" % name)
         if not os.path.exists(p):
             continue
@@ -57,6 +63,7 @@ def run(rounds=5, n_ch=65536):
         L.asdr_enableAudioFilter(h, -1)
         libs[name] = (L, h)
     times = {k: [] for k in libs}
+    VARS = libs
     for r in range(rounds + 1):
         for name, (L, h) in libs.items():
             for i in range(6):
