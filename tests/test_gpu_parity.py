@@ -166,24 +166,41 @@ def test_all_int16_inputs_through_the_scale_stage(gpu, ao):
 
 
 def test_device_pointer_entry_point_and_stream(gpu, ao):
-    """asdr_update_device with torch-owned HBM buffers on a side stream == host-pointer entry point."""
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
+    """asdr_update_device with caller-owned HBM buffers on a caller-created side stream == host-pointer entry point.
+    HBM and the stream come straight from the HIP runtime (ctypes on libamdhip64), as a C host application would do."""
+    import ctypes as C
     from audiosdr_amd.synth import make_iq
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipFree.argtypes = [C.c_void_p]
     n_ch, n_blk = 33, 4
     I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.25)
     batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")])
-    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
-    dOut = torch.zeros_like(dI)
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dOut.data_ptr(), n_blk, side.cuda_stream)
-    side.synchronize()
+    nbytes = I.nbytes
+    dI, dQ, dO, stream = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(dI), nbytes) == 0 and hip.hipMalloc(C.byref(dQ), nbytes) == 0 and hip.hipMalloc(C.byref(dO), nbytes) == 0
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    H2D, D2H = 1, 2
+    assert hip.hipMemcpy(dI, I.ctypes.data_as(C.c_void_p), nbytes, H2D) == 0
+    assert hip.hipMemcpy(dQ, Q.ctypes.data_as(C.c_void_p), nbytes, H2D) == 0
+    batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
+    assert hip.hipStreamSynchronize(stream) == 0
+    got = np.empty_like(I)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dO, nbytes, D2H) == 0
     want = np.stack([orcs[c].update(I[c], Q[c]).reshape(n_blk, 128) for c in range(n_ch)])
-    assert np.array_equal(dOut.cpu().numpy(), want)
+    assert np.array_equal(got, want)
     assert batch.last_kernel_ms() > 0
+    # per-launch timing API used by bench.py
+    batch.kernel_timing_begin(3)
+    for _ in range(3):
+        batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
+    ms = batch.kernel_timing_end(3)
+    assert len(ms) == 3 and (ms > 0).all()
+    for p_ in (dI, dQ, dO):
+        hip.hipFree(p_)
     batch.close()
 
 
