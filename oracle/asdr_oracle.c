@@ -216,6 +216,17 @@ float ao_freq_shifter(float *I, float *Q, float freq_shift, float phase0) {
   return phase;
 }
 
+/* `(int)` of a double outside the int range is undefined in C.  The reference's target (ARM Cortex-M7,
+ * vcvt.s32.f64) SATURATES and converts NaN to 0 -- and so does the GPU's v_cvt_i32_f64 -- whereas x86's cvttsd2si
+ * returns INT_MIN.  The oracle pins the ARM definition (only reachable when a diverging ALS filter or extreme
+ * gains push the audio beyond +-65536 full scales). */
+int32_t ao_f64_to_i32(double v) {
+  if (v != v) return 0;
+  if (v >= 2147483647.0) return INT32_MAX;
+  if (v <= -2147483648.0) return INT32_MIN;
+  return (int32_t)v;
+}
+
 /* .cpp:68: ((float)s / 32767.0) * gain, in double, before the store rounds it to float */
 double ao_scale_sample(int16_t s, float gain) { return ((double)(float)s / 32767.0) * (double)gain; }
 
@@ -461,7 +472,7 @@ void ao_update(asdr_oracle_t *o, const int16_t *bi, const int16_t *bq, int16_t *
 
   /* .cpp:158-161: float product, double x 32767.0, truncate to int, wrap into int16 */
   if (o->muted) for (int i = 0; i < N; i++) out[i] = 0;
-  else for (int i = 0; i < N; i++) out[i] = (int16_t)(int)((double)(o->output_gain * o->audio[i]) * 32767.0);
+  else for (int i = 0; i < N; i++) out[i] = (int16_t)ao_f64_to_i32((double)(o->output_gain * o->audio[i]) * 32767.0);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -141,6 +141,7 @@ void ao_biquad_cascade_df1(const float *coefs, float *state, int n_stages,
                            const float *src, float *dst, int n);
 float ao_freq_shifter(float *I, float *Q, float freq_shift, float phase0); /* .h:508-526 */
 double ao_scale_sample(int16_t s, float gain);                             /* .cpp:68 before the store */
+int32_t ao_f64_to_i32(double v);   /* (int)double with the ARM target's saturating semantics (.cpp:160) */
 float ao_agc_static_compressor(const float *table130, uint16_t input);     /* .cpp:483-494 */
 const float *ao_hilbert_taps(void);   /* 64 floats */
 const float *ao_sine_table(void);     /* 257 floats */

@@ -1,0 +1,105 @@
+"""Randomised and long-running parity: seeded fuzz over the whole control surface, decay into float32 denormals,
+pathological inputs.  Everything bit-exact against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from helpers import S, apply_setters, compare_status
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_setter(rng):
+    k = rng.integers(0, 24)
+    f = float
+    table = [
+        lambda: S("setDemodMode", int(rng.integers(0, 7))),
+        lambda: S("setDemodMode", int(rng.integers(0, 7))),
+        lambda: S("enableAudioFilter"), lambda: S("disableAudioFilter"),
+        lambda: S("setAudioFilter", int(rng.integers(0, 11))),
+        lambda: S("enableNoiseBlanker"), lambda: S("disableNoiseBlanker"),
+        lambda: S("setNoiseBlankerThresholdDb", f(rng.choice([3.0, 6.0, 10.0, 20.0]))),
+        lambda: S("setNoiseBlankerThreshold", f(rng.choice([1.2, 2.0, 5.0]))),
+        lambda: S("enableAGC"), lambda: S("disableAGC"), lambda: S("setAGCmode", int(rng.integers(0, 4))),
+        lambda: S("setAGCthreshold", f(rng.choice([-60.0, -40.0, -20.0]))), lambda: S("setAGCslope", f(rng.choice([0.1, 0.3, 0.7]))),
+        lambda: S("setAGCkneeWidth", f(rng.choice([2.0, 6.0]))), lambda: S("setAGCstaticGain", f(rng.choice([1.0, 10.0, 30.0]))),
+        lambda: S("setAGChangTime", f(rng.choice([1.0, 20.0, 100.0]))),
+        lambda: S("enableALSfilter"), lambda: S("disableALSfilter"),
+        lambda: S(str(rng.choice(["setALSfilterNotch", "setALSfilterPeak", "setALSfilterAdaptive", "setALSfilterStatic"]))),
+        lambda: S("setALSfilterParams", int(rng.choice([8, 32, 55, 100, 128])), f(rng.choice([0.05, 0.5])), f(rng.choice([1.0, 3.0, 9.0]))),
+        lambda: S("setInputGain", f(rng.choice([0.5, 1.0, 2.5]))), lambda: S("setIQgainBalance", f(rng.choice([0.95, 1.02]))),
+        lambda: S("setOutputGain", f(rng.choice([0.25, 0.5, 1.0]))),
+    ]
+    return table[k]()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_fuzz_control_surface(gpu, ao, seed):
+    """40 channels x 36 blocks: every channel starts from a random configuration and receives random setter calls
+    between blocks (each call applied to a random subset of channels, identically on both sides)."""
+    from audiosdr_amd.synth import make_iq
+    rng = np.random.default_rng(seed)
+    n_ch, n_blk = 40, 36
+    fc = 6890.0 + rng.uniform(-1800, 1800, n_ch)
+    I, Q = make_iq(n_ch, n_blk, fc=fc, A=rng.uniform(0.01, 0.6, n_ch), m=0.4, fm=300.0, impulse_every=int(rng.integers(300, 900)),
+                   f2=fc + 700.0, a2=0.05)
+    batch = gpu.AudioSDRBatch(n_ch)
+    orcs = [ao.OracleSDR() for _ in range(n_ch)]
+    for _ in range(60):                                   # random initial configuration
+        meth, args, _sel = _random_setter(rng)
+        mask = rng.random(n_ch) < 0.3
+        apply_setters(batch, orcs, [S(meth, *args, sel=lambda c, m=mask: bool(m[c]))])
+    for b in range(n_blk):
+        for _ in range(int(rng.integers(0, 4))):
+            meth, args, _sel = _random_setter(rng)
+            mask = rng.random(n_ch) < 0.2
+            apply_setters(batch, orcs, [S(meth, *args, sel=lambda c, m=mask: bool(m[c]))])
+        got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b], Q[c, b])
+            assert np.array_equal(got[c], want), "seed %d block %d ch %d (mode %d)" % (seed, b, c, orcs[c].getDemodMode())
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
+@pytest.mark.parametrize("mode", [1, 4, 5])
+def test_decay_into_denormals(gpu, ao, mode):
+    """Signal for 12 blocks, then digital silence for 400 blocks: biquad, AGC, blanker-average and PLL states decay
+    through the float32 denormal range (the CPU reference keeps denormals; so must the GPU), then signal again."""
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(3, 12, fc=6890.0 if mode != 1 else 6290.0, A=0.3, m=0.5)
+    Z = np.zeros((3, 400, 128), np.int16)
+    I = np.concatenate([I, Z, I], axis=1); Q = np.concatenate([Q, Z, Q], axis=1)
+    batch = gpu.AudioSDRBatch(3)
+    orcs = [ao.OracleSDR() for _ in range(3)]
+    apply_setters(batch, orcs, [S("setDemodMode", mode), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0),
+                                S("disableAGC", sel=lambda c: c == 1), S("enableALSfilter", sel=lambda c: c == 2)])
+    got = batch.update(I, Q)
+    want = np.stack([orcs[c].update(I[c], Q[c]).reshape(-1, 128) for c in range(3)])
+    assert np.array_equal(got, want)
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
+def test_pathological_inputs(gpu, ao):
+    """Full-scale square waves, Nyquist alternation, DC, single-sample spikes, -32768."""
+    n_blk = 10
+    t = np.arange(n_blk * 128)
+    pats = [
+        (np.where((t // 3) % 2 == 0, 32767, -32768), np.where((t // 5) % 2 == 0, -32768, 32767)),
+        (np.where(t % 2 == 0, 32767, -32767), np.where(t % 2 == 0, -32767, 32767)),
+        (np.full_like(t, 12345), np.full_like(t, -23456)),
+        (np.where(t % 257 == 0, 32767, 0), np.where(t % 263 == 0, -32768, 0)),
+        (np.full_like(t, -32768), np.full_like(t, -32768)),
+    ]
+    I = np.stack([p[0] for p in pats]).astype(np.int16).reshape(len(pats), n_blk, 128)
+    Q = np.stack([p[1] for p in pats]).astype(np.int16).reshape(len(pats), n_blk, 128)
+    for mode in (0, 3, 4, 5, 6):
+        batch = gpu.AudioSDRBatch(len(pats))
+        orcs = [ao.OracleSDR() for _ in pats]
+        apply_setters(batch, orcs, [S("setDemodMode", mode), S("enableAudioFilter"), S("enableALSfilter"), S("setInputGain", 4.0),
+                                    S("setOutputGain", 1.0)])
+        got = batch.update(I, Q)
+        want = np.stack([orcs[c].update(I[c], Q[c]).reshape(-1, 128) for c in range(len(pats))])
+        assert np.array_equal(got, want), mode
+        compare_status(gpu, batch, orcs)
+        batch.close()
