@@ -130,3 +130,21 @@ def test_product_does_not_link_the_oracle(A):
                 assert "asdr_oracle" not in src and "from oracle" not in src and "import oracle" not in src, fn
     syms = subprocess.run(["nm", "-D", A.library_path()], capture_output=True, text=True).stdout
     assert "ao_update" not in syms and "ao_create" not in syms
+
+
+def test_worked_examples_of_the_reference_manual(A, ao):
+    """DOC/AudioSDR.pdf, section 2 "System Description" (tuning): the IF is centred at +6890 Hz; to tune an AM station at
+    7,150,000 Hz the rf oscillator is set to 7,150,000 - 6890 = 7,143,110 Hz; an LSB signal is aligned with the upper edge of
+    the 3 kHz SSB filter, 6890 + (3000/2) = 8390 Hz, oscillator 7,150,000 - 8390 = 7,141,610 Hz.  setDemodMode() returns that
+    mode-dependent offset (BareBonesWSPR.ino:102,116 subtracts it from the LO)."""
+    b = A.AudioSDRBatch(1, device=-1)
+    o = ao.OracleSDR()
+    for sdr_set in (lambda m: b.setDemodMode(m), lambda m: o.setDemodMode(m)):
+        assert 7150000 - sdr_set(A.AMmode) == 7143110
+        assert 7150000 - sdr_set(A.LSBmode) == 7141610
+        assert sdr_set(A.USBmode) == 6890 - 3000 / 2
+    # "8th order, elliptic IIR band-pass filter with a bandwidth of 1, 3, or 8 kHz, for CW, SSB, or AM" (manual, IF pre-filters)
+    for mode, bw in ((A.CW_USBmode, 1000.0), (A.USBmode, 3000.0), (A.AMmode, 8500.0)):
+        b.setDemodMode(mode)
+        assert b.getBPFupper(0) - b.getBPFlower(0) == bw
+    b.close()
