@@ -170,39 +170,57 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // Restates CMSIS-DSP arm_biquad_cascade_df1_f32 (arm_math.h:1360-1378; call sites AudioSDR.cpp:77-78,
 // 136-137, 285): per stage, per sample  acc = b0*x; acc += b1*x1; acc += b2*x2; acc += a1*y1; acc += a2*y2
 // (separately rounded, this association).  The reference runs stage-major over the block; each stage is causal,
-// so running the four stages on four adjacent lanes with one 4-sample CHUNK of skew produces identical values.
-// At chunk-step c lane `st` handles samples 4(c-st)..4(c-st)+3: stage 0 reads them from the LDS row (one
-// ds_read_b128, prefetched a step ahead), stage k>0 takes the previous lane's four outputs of the previous step
+// so running the four stages on four adjacent lanes with one CHUNK (4 or 8 samples) of skew produces identical values.
+// At chunk-step c lane `st` handles samples C(c-st)..C(c-st)+C-1: stage 0 reads them from the LDS row
+// (ds_read_b128, prefetched a step ahead), stage k>0 takes the previous lane's four outputs of the previous step
 // through DPP row_shr:1, stage 3 writes back in place (ds_write_b128).  The y-independent part
 // p = (b0*x + b1*x1) + b2*x2 of all four samples is off the critical path; the recurrence is 3 dependent ops/sample.
+#ifndef ASDR_PIPE_CHUNK
+#define ASDR_PIPE_CHUNK 8   /* samples per lane per pipeline step: 4 (35 steps) or 8 (19 steps, less per-step overhead) */
+#endif
 __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const float *cf, float *sv) {
+  constexpr int C = ASDR_PIPE_CHUNK, NSTEP = ASDR_N / C + 3;
   const float b0 = cf[0], b1 = cf[1], b2 = cf[2], a1 = cf[3], a2 = cf[4];
   float x1 = sv[0], x2 = sv[1], y1 = sv[2], y2 = sv[3];
-  float yo0 = 0.0f, yo1 = 0.0f, yo2 = 0.0f, yo3 = 0.0f;
-  const float4 *row4 = reinterpret_cast<const float4 *>(row);
-  float4 xn = row4[0];
+  float yo[C], xn[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) yo[j] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
+  const bool s0 = (st == 0);
 #pragma unroll 1
-  for (int c = 0; c < ASDR_N / 4 + 3; ++c) {
+  for (int c = 0; c < NSTEP; ++c) {
     const int cn = c - st;
-    const float4 xl = xn;
-    xn = row4[(c + 1 < ASDR_N / 4) ? c + 1 : ASDR_N / 4 - 1];   // prefetch the next chunk for stage 0
-    const float d0 = dpp_row_shr1(yo0), d1 = dpp_row_shr1(yo1), d2 = dpp_row_shr1(yo2), d3 = dpp_row_shr1(yo3);
-    const bool s0 = (st == 0);
-    const float xa = s0 ? xl.x : d0, xb = s0 ? xl.y : d1, xc = s0 ? xl.z : d2, xd = s0 ? xl.w : d3;
-    // y-independent partial sums, in the reference's association
-    float pa = b0 * xa; pa += b1 * x1; pa += b2 * x2;
-    float pb = b0 * xb; pb += b1 * xa; pb += b2 * x1;
-    float pc = b0 * xc; pc += b1 * xb; pc += b2 * xa;
-    float pd = b0 * xd; pd += b1 * xc; pd += b2 * xb;
-    // recurrence
-    float ya = pa + a1 * y1; ya += a2 * y2;
-    float yb = pb + a1 * ya; yb += a2 * y1;
-    float yc = pc + a1 * yb; yc += a2 * ya;
-    float yd = pd + a1 * yc; yd += a2 * yb;
-    const bool act = (cn >= 0) && (cn < ASDR_N / 4);
-    if (act) { x1 = xd; x2 = xc; y1 = yd; y2 = yc; }
-    yo0 = ya; yo1 = yb; yo2 = yc; yo3 = yd;
-    if (on && act && st == 3) reinterpret_cast<float4 *>(row)[cn] = make_float4(ya, yb, yc, yd);
+    float x[C], p[C], y[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { const float d = dpp_row_shr1(yo[j]); x[j] = s0 ? xn[j] : d; }
+    {   // prefetch the next chunk for stage 0
+      const int nc = (c + 1 < ASDR_N / C) ? c + 1 : ASDR_N / C - 1;
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[nc * (C / 4) + q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
+    }
+    // y-independent partial sums p = (b0*x + b1*x[-1]) + b2*x[-2], in the reference's association
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const float xm1 = (j >= 1) ? x[j - 1] : x1, xm2 = (j >= 2) ? x[j - 2] : ((j == 1) ? x1 : x2);
+      float t = b0 * x[j]; t += b1 * xm1; t += b2 * xm2;
+      p[j] = t;
+    }
+    // recurrence: y = (p + a1*y[-1]) + a2*y[-2]
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const float ym1 = (j >= 1) ? y[j - 1] : y1, ym2 = (j >= 2) ? y[j - 2] : ((j == 1) ? y1 : y2);
+      float t = p[j] + a1 * ym1; t += a2 * ym2;
+      y[j] = t;
+    }
+    const bool act = (cn >= 0) && (cn < ASDR_N / C);
+    if (act) { x1 = x[C - 1]; x2 = x[C - 2]; y1 = y[C - 1]; y2 = y[C - 2]; }
+#pragma unroll
+    for (int j = 0; j < C; ++j) yo[j] = y[j];
+    if (on && act && st == 3) {
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) reinterpret_cast<float4 *>(row)[cn * (C / 4) + q] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+    }
   }
   sv[0] = x1; sv[1] = x2; sv[2] = y1; sv[3] = y2;
 }

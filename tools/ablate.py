@@ -20,7 +20,7 @@ PHASES = {"NB": 1, "IF": 2, "SAM": 4, "MIX": 8, "HIL": 16, "ENV": 32, "AF": 64, 
 VARIANTS = {"full": 0, "no_NB": 1, "no_IF": 2, "no_MIX": 8, "no_HIL": 16, "no_AF": 64, "no_AGC": 128,
             "io_only": 511}
 EXTRA = {"full_w2": ["-DASDR_WAVES_PER_EU=2"],   # same code, 256-VGPR budget (8 waves/CU)
-         "lds420": ["-DASDR_XQ1=224", "-DASDR_STRIDE=420"]}   # conflict-free FIR reads, bigger footprint: measured slower
+         "chunk4": ["-DASDR_PIPE_CHUNK=4"]}   # biquad pipeline with 4-sample chunks (35 steps)
 
 
 def build():
