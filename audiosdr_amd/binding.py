@@ -47,7 +47,9 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
             "asdr_read_status", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
-            "asdr_kernel_timing_begin", "asdr_kernel_timing_end"] +
+            "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_update_device_strided", "asdr_capture_open",
+            "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
+            "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read"] +
            ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
 
 _lib = None
@@ -72,6 +74,15 @@ def load_library(path=None):
     L.asdr_update.argtypes = [vp, i16p, i16p, i16p, _i]; L.asdr_update.restype = _i
     L.asdr_update_device.argtypes = [vp, vp, vp, vp, _i, vp]; L.asdr_update_device.restype = _i
     L.asdr_synchronize.argtypes = [vp]; L.asdr_synchronize.restype = _i
+    L.asdr_update_device_strided.argtypes = [vp, vp, vp, vp, _i, C.c_long, C.c_long, vp]; L.asdr_update_device_strided.restype = _i
+    L.asdr_capture_open.argtypes = [vp, C.c_long]; L.asdr_capture_open.restype = _i
+    for n in ("asdr_capture_close", "asdr_capture_rewind"):
+        getattr(L, n).argtypes = [vp]; getattr(L, n).restype = _i
+    for n in ("asdr_capture_capacity", "asdr_capture_position"):
+        getattr(L, n).argtypes = [vp]; getattr(L, n).restype = C.c_long
+    L.asdr_capture_device_ptr.argtypes = [vp]; L.asdr_capture_device_ptr.restype = vp
+    L.asdr_capture_update_device.argtypes = [vp, vp, vp, _i, C.c_long, vp]; L.asdr_capture_update_device.restype = _i
+    L.asdr_capture_read.argtypes = [vp, _i, C.c_long, C.c_long, i16p]; L.asdr_capture_read.restype = _i
     L.asdr_last_kernel_ms.argtypes = [vp]; L.asdr_last_kernel_ms.restype = _f
     for n in _SETTERS_VOID:
         fn = getattr(L, "asdr_" + n); fn.argtypes = [vp, _i]; fn.restype = None
@@ -141,8 +152,46 @@ class AudioSDRBatch:
         self._chk(self._L.asdr_update_device(self._h, C.c_void_p(dI), C.c_void_p(dQ), C.c_void_p(dOut), int(n_blocks),
                                              C.c_void_p(stream)))
 
+    def update_device_strided(self, dI, dQ, dOut, n_blocks, in_stride_blocks, out_stride_blocks, stream=0):
+        """As update_device, with explicit row strides (in blocks) of the I/Q rows and of the out rows."""
+        self._chk(self._L.asdr_update_device_strided(self._h, C.c_void_p(dI), C.c_void_p(dQ), C.c_void_p(dOut), int(n_blocks),
+                                                     int(in_stride_blocks), int(out_stride_blocks), C.c_void_p(stream)))
+
     def synchronize(self):
         self._chk(self._L.asdr_synchronize(self._h))
+
+    # ---- capture sink: one contiguous audio row per channel in HBM (include/asdr.h) ----
+    def capture_open(self, capacity_blocks):
+        self._chk(self._L.asdr_capture_open(self._h, int(capacity_blocks)))
+
+    def capture_close(self):
+        self._chk(self._L.asdr_capture_close(self._h))
+
+    def capture_rewind(self):
+        self._chk(self._L.asdr_capture_rewind(self._h))
+
+    @property
+    def capture_position(self):
+        return int(self._L.asdr_capture_position(self._h))
+
+    @property
+    def capture_capacity(self):
+        return int(self._L.asdr_capture_capacity(self._h))
+
+    def capture_device_ptr(self):
+        return int(self._L.asdr_capture_device_ptr(self._h) or 0)
+
+    def capture_update_device(self, dI, dQ, n_blocks, in_stride_blocks=None, stream=0):
+        self._chk(self._L.asdr_capture_update_device(self._h, C.c_void_p(dI), C.c_void_p(dQ), int(n_blocks),
+                                                     int(n_blocks if in_stride_blocks is None else in_stride_blocks), C.c_void_p(stream)))
+
+    def capture_read(self, ch, first_block=0, n_blocks=None):
+        """int16 [n_blocks*128] of channel `ch`, starting at block `first_block` of its capture row."""
+        if n_blocks is None:
+            n_blocks = self.capture_position - first_block
+        out = np.empty(int(n_blocks) * BLOCK, dtype=np.int16)
+        self._chk(self._L.asdr_capture_read(self._h, int(ch), int(first_block), int(n_blocks), out.ctypes.data_as(C.POINTER(C.c_int16))))
+        return out
 
     def last_kernel_ms(self):
         return float(self._L.asdr_last_kernel_ms(self._h))

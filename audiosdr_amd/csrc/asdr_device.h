@@ -115,7 +115,9 @@ typedef struct {
   int32_t n_channels;
   const int16_t *in_i, *in_q;
   int16_t *out;
-  int32_t n_blocks;       /* blocks per channel in this call (row stride of I/Q/out = n_blocks*128) */
+  int32_t n_blocks;       /* blocks per channel processed by this call */
+  int32_t in_stride;      /* row stride of I and Q in blocks (>= n_blocks; == n_blocks for the packed layout) */
+  int32_t out_stride;     /* row stride of out in blocks (a capture row holds many calls' worth) */
   float *taps;            /* NULL or [ASDR_N_TAPS][n_channels][128] */
   ChainConsts k;
 } UpdateArgs;

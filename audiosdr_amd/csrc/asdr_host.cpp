@@ -123,6 +123,8 @@ struct asdr_batch {
   SlotInfo *d_sched = nullptr;
   uint32_t *d_reset = nullptr;
   int16_t *d_io[3] = {nullptr, nullptr, nullptr};
+  int16_t *d_capture = nullptr;  // capture sink [n][capture_cap][128]
+  long capture_cap = 0, capture_pos = 0;
   size_t io_cap = 0;
   bool taps_on = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -369,7 +371,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipSetDevice(b->device);
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
-                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_io[0], b->d_io[1], b->d_io[2]};
+                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture};
   for (void *p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -380,12 +382,16 @@ void asdr_destroy(asdr_batch_t *b) {
 
 int asdr_n_channels(const asdr_batch_t *b) { return b ? b->n : 0; }
 
-int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks, void *stream_) {
+int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
+                               long in_stride_blocks, long out_stride_blocks, void *stream_) {
   if (!b) return fail("null batch");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the signal path needs a HIP device");
   if (!dI || !dQ) return 0;  // missing-input guard, AudioSDR.cpp:48-56
   if (!dOut) return fail("null output");
   if (n_blocks <= 0) return 0;
+  if (in_stride_blocks < n_blocks || out_stride_blocks < n_blocks) return fail("row stride shorter than n_blocks");
+  if (in_stride_blocks > 0x7fffffffL || out_stride_blocks > 0x7fffffffL) return fail("row stride too large");
+  if ((((uintptr_t)dI | (uintptr_t)dQ | (uintptr_t)dOut) & 15u) != 0) return fail("I/Q/out device pointers must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
   HIPCHK(hipSetDevice(b->device));
   if (flush(b, stream) != 0) return -1;
@@ -393,6 +399,7 @@ int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, in
   UpdateArgs a;
   fill_args(b, a);
   a.in_i = dI; a.in_q = dQ; a.out = dOut; a.n_blocks = n_blocks;
+  a.in_stride = (int32_t)in_stride_blocks; a.out_stride = (int32_t)out_stride_blocks;
   hipEvent_t e0 = b->ev0, e1 = b->ev1;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   HIPCHK(hipEventRecord(e0, stream));
@@ -400,6 +407,61 @@ int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, in
   HIPCHK(hipEventRecord(e1, stream));
   b->ev_valid = (e0 == b->ev0);
   b->last_stream = stream;
+  return 0;
+}
+
+int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks, void *stream_) {
+  return asdr_update_device_strided(b, dI, dQ, dOut, n_blocks, n_blocks, n_blocks, stream_);
+}
+
+// ---- capture sink: each channel's audio appended to one contiguous HBM row ---------------
+int asdr_capture_open(asdr_batch_t *b, long capacity_blocks) {
+  if (!b) return fail("null batch");
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the capture sink lives in HBM");
+  if (capacity_blocks <= 0 || capacity_blocks > 0x7fffffffL) return fail("bad capture capacity");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->d_capture) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b->d_capture)); b->d_capture = nullptr; }
+  const size_t bytes = (size_t)b->n * (size_t)capacity_blocks * ASDR_N * sizeof(int16_t);
+  if (hipMalloc(&b->d_capture, bytes) != hipSuccess) { b->d_capture = nullptr; return fail("capture sink: out of device memory"); }
+  b->capture_cap = capacity_blocks; b->capture_pos = 0;
+  return 0;
+}
+
+int asdr_capture_close(asdr_batch_t *b) {
+  if (!b) return fail("null batch");
+  if (b->d_capture) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b->d_capture)); }
+  b->d_capture = nullptr; b->capture_cap = 0; b->capture_pos = 0;
+  return 0;
+}
+
+long asdr_capture_capacity(const asdr_batch_t *b) { return b ? b->capture_cap : 0; }
+long asdr_capture_position(const asdr_batch_t *b) { return b ? b->capture_pos : 0; }
+int16_t *asdr_capture_device_ptr(asdr_batch_t *b) { return b ? b->d_capture : nullptr; }
+int asdr_capture_rewind(asdr_batch_t *b) { if (!b) return fail("null batch"); b->capture_pos = 0; return 0; }
+
+int asdr_capture_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int n_blocks, long in_stride_blocks, void *stream) {
+  if (!b) return fail("null batch");
+  if (!b->d_capture) return fail("capture sink is not open");
+  if (!dI || !dQ) return 0;   // missing input: nothing is transmitted, nothing is appended (AudioSDR.cpp:48-56)
+  if (n_blocks <= 0) return 0;
+  if (b->capture_pos + n_blocks > b->capture_cap) return fail("capture sink overflow");
+  int16_t *dst = b->d_capture + (size_t)b->capture_pos * ASDR_N;
+  if (asdr_update_device_strided(b, dI, dQ, dst, n_blocks, in_stride_blocks, b->capture_cap, stream) != 0) return -1;
+  b->capture_pos += n_blocks;
+  return 0;
+}
+
+int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, int16_t *host_out) {
+  if (!b) return fail("null batch");
+  if (!b->d_capture) return fail("capture sink is not open");
+  if (ch < 0 || ch >= b->n) return fail("bad channel");
+  if (first_block < 0 || n_blocks < 0 || first_block + n_blocks > b->capture_pos) return fail("capture read beyond the write position");
+  if (n_blocks == 0) return 0;
+  if (!host_out) return fail("null output");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipMemcpy(host_out, b->d_capture + ((size_t)ch * b->capture_cap + first_block) * ASDR_N,
+                   (size_t)n_blocks * ASDR_N * sizeof(int16_t), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -319,7 +319,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const uint32_t ns_mid = (ns + 1u) % 3u, ns_new = (ns + 2u) % 3u;
     float carrier_now = 0.0f;   // set by the envelope path when it runs in this block
     bool carrier_fresh = false;
-    const size_t io = ((size_t)ch * a.n_blocks + blk) * ASDR_N + k0;
+    const size_t io = ((size_t)ch * a.in_stride + blk) * ASDR_N + k0;       // this lane's 16 input samples
+    const size_t io_out = ((size_t)ch * a.out_stride + blk) * ASDR_N + k0;  // ... and its 16 output samples (capture rows may be longer)
     const bool nb_wave = ABL_ON(ABL_NB) && __any(nb_en);   // wave-uniform: some channel of this wave has the blanker on
     int16_t *hist = a.nb_hist + (size_t)ch * 768;              // 3 slots x {I,Q} x 128 raw int16 samples
     uint32_t *mrow = reinterpret_cast<uint32_t *>(a.nb_mask + (size_t)ch * ASDR_NB_MASK_ROW) + 5 * s8;   // this lane's 20 mask codes
@@ -909,7 +910,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         SCHED_FENCE();
       }
       if (valid) {
-        int4 *po = reinterpret_cast<int4 *>(a.out + io);
+        int4 *po = reinterpret_cast<int4 *>(a.out + io_out);
         po[0] = ro[0].v; po[1] = ro[1].v;
       }
     }

@@ -65,7 +65,28 @@ int asdr_n_channels(const asdr_batch_t *b);
 int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks);
 int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
                        void *stream);
+/* Same, with explicit row strides in blocks: I and Q rows are in_stride_blocks*128 samples apart, out rows
+ * out_stride_blocks*128 (both >= n_blocks).  Lets a caller stream out of a longer input buffer and into a longer
+ * per-channel audio row without repacking.  All three pointers must be 16-byte aligned. */
+int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
+                               long in_stride_blocks, long out_stride_blocks, void *stream);
 int asdr_synchronize(asdr_batch_t *b);
+
+/* ---- capture sink (the continuous receive loop of EXTRAS/BareBonesWSPR/BareBonesWSPR.ino:
+ * 87-135 with the audio kept instead of played): one contiguous mono int16 row per channel in HBM,
+ * [channel][capacity_blocks*128] at 44.1 kHz, appended to by every asdr_capture_update_device() call, so that a
+ * 2-minute WSPR slot (41,344 blocks) ends up as one row per receiver that a decoder can read in place
+ * (asdr_capture_device_ptr) or copy out (asdr_capture_read).  The 12 kHz resampling WSPR decoders expect is not
+ * part of the reference and is not done here. */
+int asdr_capture_open(asdr_batch_t *b, long capacity_blocks);       /* (re)allocates, position = 0 */
+int asdr_capture_close(asdr_batch_t *b);
+long asdr_capture_capacity(const asdr_batch_t *b);                  /* blocks per channel row */
+long asdr_capture_position(const asdr_batch_t *b);                  /* blocks appended so far */
+int asdr_capture_rewind(asdr_batch_t *b);                           /* position = 0 (channel state is kept) */
+int16_t *asdr_capture_device_ptr(asdr_batch_t *b);                  /* [n_channels][capacity_blocks][128] */
+int asdr_capture_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int n_blocks,
+                               long in_stride_blocks, void *stream); /* update() x n_blocks, audio appended */
+int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, int16_t *host_out);
 
 /* ---- general (AudioSDR.h:88-97; AudioSDR.cpp:174-273) */
 void asdr_init(asdr_batch_t *b, int ch);                              /* init()            .cpp:174 */

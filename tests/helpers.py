@@ -28,3 +28,56 @@ def compare_status(A, batch, oracles):
         assert int(st["sam_locked"][c]) == o.getSAMphaseLockStatus(), "SAM lock ch %d" % c
         assert f32_bits(st["sam_frequency"][c]) == f32_bits(np.float32(o.getSAMfrequency())), "SAM frequency ch %d" % c
         assert f32_bits(st["am_carrier"][c]) == f32_bits(np.float32(o.getAMcarrierLevel())), "carrier ch %d" % c
+
+
+class Hip:
+    """Bare HIP runtime through ctypes (libamdhip64), as a C host application would use it: HBM buffers and streams
+    owned by the caller, handed to the C ABI as raw pointers.  GPU tests only."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        h = self.h = C.CDLL("libamdhip64.so")
+        h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        h.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        h.hipStreamSynchronize.argtypes = [C.c_void_p]
+        h.hipStreamDestroy.argtypes = [C.c_void_p]
+        h.hipFree.argtypes = [C.c_void_p]
+        self._bufs = []
+
+    def malloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.h.hipMalloc(self.C.byref(p), int(nbytes)) == 0
+        self._bufs.append(p.value)
+        return p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        assert self.h.hipMemcpy(p, arr.ctypes.data_as(self.C.c_void_p), arr.nbytes, 1) == 0
+        return p
+
+    def fill(self, ptr, byte, nbytes):
+        assert self.h.hipMemset(ptr, byte, nbytes) == 0
+
+    def download(self, ptr, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        assert self.h.hipDeviceSynchronize() == 0
+        assert self.h.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), ptr + offset_bytes, out.nbytes, 2) == 0
+        return out
+
+    def stream(self):
+        s = self.C.c_void_p()
+        assert self.h.hipStreamCreate(self.C.byref(s)) == 0
+        return s.value
+
+    def sync(self, stream=None):
+        assert (self.h.hipStreamSynchronize(stream) if stream else self.h.hipDeviceSynchronize()) == 0
+
+    def free_all(self):
+        self.h.hipDeviceSynchronize()
+        for p in self._bufs:
+            self.h.hipFree(p)
+        self._bufs = []

@@ -148,3 +148,14 @@ def test_worked_examples_of_the_reference_manual(A, ao):
         b.setDemodMode(mode)
         assert b.getBPFupper(0) - b.getBPFlower(0) == bw
     b.close()
+
+
+def test_capture_sink_needs_a_device(A):
+    """The capture sink and the strided entry point are signal-path calls: a control-plane-only batch refuses them."""
+    b = A.AudioSDRBatch(4, device=A.NO_DEVICE) if hasattr(A, "NO_DEVICE") else A.AudioSDRBatch(4, device=-1)
+    with pytest.raises(A.AsdrError, match="HBM|device"):
+        b.capture_open(8)
+    with pytest.raises(A.AsdrError, match="device"):
+        b.update_device_strided(16, 16, 16, 1, 1, 1)
+    assert b.capture_position == 0 and b.capture_capacity == 0
+    b.close()

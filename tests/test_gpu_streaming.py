@@ -1,0 +1,102 @@
+"""SURVEY.md 8(f) row 1 on the GPU: strided streaming out of / into longer HBM rows and the capture sink
+(one contiguous audio row per channel), bit-for-bit against the CPU oracle run block by block."""
+import numpy as np
+import pytest
+
+from helpers import Hip, S, apply_setters
+
+pytestmark = pytest.mark.gpu
+WSPR = [S("enableAGC"), S("setAGCmode", 2), S("disableALSfilter"), S("disableNoiseBlanker"), S("setNoiseBlankerThresholdDb", 10.0),
+        S("setInputGain", 1.0), S("setOutputGain", 0.5), S("setIQgainBalance", 1.020), S("setAudioFilter", 2),
+        S("setDemodMode", 6), S("setMute", 0)]     # EXTRAS/BareBonesWSPR/BareBonesWSPR.ino:87-102,129
+
+
+def _mk(gpu, ao, n_ch, setters):
+    batch = gpu.AudioSDRBatch(n_ch)
+    orcs = [ao.OracleSDR() for _ in range(n_ch)]
+    apply_setters(batch, orcs, setters)
+    return batch, orcs
+
+
+def test_strided_rows_in_and_out(gpu, ao):
+    """Blocks 3..6 of 10-block input rows -> blocks 2..5 of 7-block output rows; everything else untouched."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, in_blk, out_blk, T = 19, 10, 7, 4
+    I, Q = make_iq(n_ch, in_blk, fc=6290.0, A=0.25, noise=0.02, impulse_every=300)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")])
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    dO = hip.malloc(n_ch * out_blk * 256)
+    hip.fill(dO, 0x5A, n_ch * out_blk * 256)
+    batch.update_device_strided(dI + 3 * 256, dQ + 3 * 256, dO + 2 * 256, T, in_blk, out_blk)
+    batch.synchronize()
+    got = hip.download(dO, (n_ch, out_blk, 128), np.int16)
+    for c in range(n_ch):
+        want = orcs[c].update(I[c, 3:3 + T], Q[c, 3:3 + T]).reshape(T, 128)
+        assert np.array_equal(got[c, 2:2 + T], want), "ch %d" % c
+    assert (got[:, :2] == 0x5A5A).all() and (got[:, 2 + T:] == 0x5A5A).all()
+    with pytest.raises(gpu.AsdrError, match="stride"):
+        batch.update_device_strided(dI, dQ, dO, 4, 3, 7)
+    with pytest.raises(gpu.AsdrError, match="aligned"):
+        batch.update_device_strided(dI + 2, dQ, dO, 1, in_blk, out_blk)
+    hip.free_all(); batch.close()
+
+
+def test_capture_sink_ragged_launches(gpu, ao):
+    """A WSPR-configured batch streamed into the capture sink in launches of 1, 5, 17 and 9 blocks: every
+    channel's row equals the oracle's block-by-block audio; position/overflow/rewind behave."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, total = 21, 32
+    I, Q = make_iq(n_ch, total, fc=6890.0 - 1500.0, A=0.02, noise=0.05)
+    batch, orcs = _mk(gpu, ao, n_ch, WSPR)
+    hip = Hip()
+    with pytest.raises(gpu.AsdrError, match="not open"):
+        batch.capture_update_device(0, 0, 1)
+    batch.capture_open(40)
+    assert batch.capture_capacity == 40 and batch.capture_position == 0
+    pos = 0
+    for T in (1, 5, 17, 9):
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        batch.capture_update_device(dI, dQ, T)
+        pos += T
+        assert batch.capture_position == pos
+    for c in range(n_ch):
+        want = orcs[c].update(I[c], Q[c])
+        assert np.array_equal(batch.capture_read(c), want), "ch %d" % c
+        assert np.array_equal(batch.capture_read(c, 6, 3), want[6 * 128:9 * 128])
+    # the sink is plain HBM: a decoder can read rows in place
+    whole = hip.download(batch.capture_device_ptr(), (n_ch, 40, 128), np.int16)
+    assert np.array_equal(whole[3, :total].reshape(-1), batch.capture_read(3))
+    # missing input appends nothing; overflow is refused without processing
+    batch.capture_update_device(0, dQ, 1)
+    assert batch.capture_position == total
+    dI, dQ = hip.upload(I[:, :9]), hip.upload(Q[:, :9])
+    with pytest.raises(gpu.AsdrError, match="overflow"):
+        batch.capture_update_device(dI, dQ, 9)
+    assert batch.capture_position == total
+    with pytest.raises(gpu.AsdrError, match="beyond"):
+        batch.capture_read(0, 30, 5)
+    # rewind keeps channel state: the next block continues the stream
+    batch.capture_rewind()
+    batch.capture_update_device(dI, dQ, 9)
+    for c in (0, n_ch - 1):
+        assert np.array_equal(batch.capture_read(c), orcs[c].update(I[c, :9], Q[c, :9]))
+    batch.capture_close()
+    assert batch.capture_device_ptr() == 0
+    hip.free_all(); batch.close()
+
+
+def test_capture_long_stream_from_resident_input(gpu, ao):
+    """512 blocks per channel streamed 64 at a time out of ONE resident input buffer (in_stride = 512) into the sink."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, total, T = 16, 512, 64
+    I, Q = make_iq(n_ch, total, fc=6890.0 - 1500.0 + 40.0, A=0.05, noise=0.05)
+    batch, orcs = _mk(gpu, ao, n_ch, WSPR)
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    batch.capture_open(total)
+    for pos in range(0, total, T):
+        batch.capture_update_device(dI + pos * 256, dQ + pos * 256, T, in_stride_blocks=total)
+    for c in (0, 7, 15):
+        assert np.array_equal(batch.capture_read(c), orcs[c].update(I[c], Q[c])), "ch %d" % c
+    hip.free_all(); batch.close()
