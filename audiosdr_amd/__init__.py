@@ -10,5 +10,7 @@ from .binding import (AGCfast, AGCmedium, AGCoff, AGCslow, ALL, AMmode, BLOCK, C
                       TAPS, USBmode, WSPRmode, AudioSDRBatch, AsdrError, audio2100, audio2300, audio2500, audio2700,
                       audio2900, audio3100, audio3300, audioAM, audioBypass, audioCW, audioWSPR, library_path,
                       load_library)
+from .front import (NO_DEVICE, AudioGrabberComplex256Batch, AudioIQgeneratorBatch, AudioSDRpreProcessorBatch,  # noqa: E402
+                    FRONT_EXPORTS)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,326 @@
+// asdr_front.hip -- gfx950 kernels of the AudioStream blocks around the AudioSDR hot path (include/asdr_front.h):
+//   asdr_pre_kernel    AudioSDRpreProcessor::update()    (AudioSDRpreProcessor.cpp:46-138)
+//   asdr_iqgen_kernel  AudioIQgenerator::update()        (AudioIQgenerator.cpp:33-87)
+//   asdr_grab_kernel   AudioGrabberComplex256::update()  (AudioGrabberComplex256.cpp:50-72)
+// All three are HBM-streaming int16 work around a little float32 arithmetic; arithmetic order follows the reference
+// (built with -ffp-contract=off), the binary64 islands are evaluated in binary64.  One workgroup == one wave64, so
+// LDS hand-offs need only a wave barrier.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asdr_front_device.h"
+#include "asdr_front_tables.h"
+
+#define WAVE_SYNC() __syncthreads() /* workgroup == one wave: a wave barrier + LDS/VMEM waits */
+
+__constant__ float c_iq_taps[64];
+__constant__ float c_tw[64][2];
+
+extern "C" int asdr_front_upload_tables(void) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_iq_taps), asdr_iqgen_hilbert_taps, sizeof(asdr_iqgen_hilbert_taps)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_tw), asdr_fft128_tw, sizeof(asdr_fft128_tw)) != hipSuccess) return -1;
+  return 0;
+}
+
+// (float)((double)s / 32767.0): correctly rounded binary64 quotient by the Markstein reciprocal form (mul + 2 fma;
+// exhaustively equal to true division for every int16, ao_front_check_div32767 in the CPU test-suite), then one
+// rounding to float32 -- the reference's `float(x)/32767.0` (AudioSDRpreProcessor.cpp:89-90, AudioIQgenerator.cpp:56).
+__device__ __forceinline__ float unit_scale(int s) {
+  const double x = (double)s, c = 32767.0, r = 1.0 / 32767.0;
+  const double q0 = x * r;
+  const double rem = __builtin_fma(-q0, c, x);
+  return (float)__builtin_fma(rem, r, q0);
+}
+
+union Raw8 { int4 v; int16_t s[8]; };
+__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
+
+// =====================================================================================================
+// AudioSDRpreProcessor: 16 lanes per channel (8 samples each; a DPP row is exactly one channel), 4 channels per wave.
+// Blocks of one call are processed in order because the detector may change the correction between blocks.
+// =====================================================================================================
+__device__ __forceinline__ int dpp_row_shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); }
+
+__global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
+  __shared__ float2 X[4][128];      // FFT work area, one row per channel of the wave
+  __shared__ float P[4][132];       // line powers 0..127 (+ the reference's buffer[128] at [128])
+  __shared__ float2 TW[64];
+  const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
+  const int ch = blockIdx.x * 4 + r;
+  const bool valid = ch < a.n_channels;
+  TW[lane] = make_float2(c_tw[lane][0], c_tw[lane][1]);
+  asdr_pre_state_t st;
+  if (valid) st = a.state[ch];      // every lane of the row keeps a copy; all of them update it identically
+  else { st.correction = 0; st.saved_sample = 0; st.failure_count = 0; st.success_count = 0; st.auto_detect = 0; st.swap = 0;
+         st.max_line = 0; st.strong = 0; st.max_power = 0.f; st.avg_power = 0.f; st.ratio = 0.f; }
+  int corr = st.correction, saved = st.saved_sample, fail = st.failure_count, succ = st.success_count;
+  int autodet = valid ? st.auto_detect : 0;
+  const int swap = st.swap;
+  const int brl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);   // bitrev4(l)
+  WAVE_SYNC();
+
+#pragma unroll 1
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    Raw8 ri, rq;
+    ri.v = rq.v = make_int4(0, 0, 0, 0);
+    if (valid) {
+      const size_t io = ((size_t)ch * a.in_stride + blk) * ASDR_N + 8 * l;
+      ri.v = *reinterpret_cast<const int4 *>(a.in_i + io);
+      rq.v = *reinterpret_cast<const int4 *>(a.in_q + io);
+    }
+    int xi[8], xq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xi[j] = ri.s[j]; xq[j] = rq.s[j]; }
+
+    // ---- single-sample I/Q skew compensation, .cpp:62-72 -----------------------------------------------
+    {
+      const int prev_i = dpp_row_shr1_i(xi[7]), prev_q = dpp_row_shr1_i(xq[7]);   // left neighbour's last sample
+      const int tail_i = __shfl(xi[7], 15, 16), tail_q = __shfl(xq[7], 15, 16);   // the row's sample 127
+      if (corr == 1) {            // I delayed by one sample; sample 127 is carried to the next block
+#pragma unroll
+        for (int j = 7; j > 0; --j) xi[j] = xi[j - 1];
+        xi[0] = (l == 0) ? saved : prev_i;
+        saved = tail_i;
+      } else if (corr == -1) {    // Q delayed by one sample -- but the carried Q sample is written to I[0] (.cpp:69)
+        const int q0 = xq[0];
+#pragma unroll
+        for (int j = 7; j > 0; --j) xq[j] = xq[j - 1];
+        xq[0] = (l == 0) ? q0 : prev_q;
+        if (l == 0) xi[0] = saved;
+        saved = tail_q;
+      }
+    }
+
+    // ---- skew detector, .cpp:82-122: image ratio of the strongest line of a 128-point FFT ---------------
+    if (__any(autodet)) {
+      if (autodet) {
+        // x[n] -> X[bitrev7(n)], n = 8l + j: bitrev7 = bitrev3(j) << 4 | bitrev4(l)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int brj = ((j & 1) << 2) | (j & 2) | ((j & 4) >> 2);
+          X[r][(brj << 4) | brl] = make_float2(unit_scale(xi[j]), unit_scale(xq[j]));
+        }
+      }
+      WAVE_SYNC();
+      // radix-2 decimation-in-time, 7 stages x 64 butterflies per channel, 4 per lane; arithmetic of ao_fft128
+#pragma unroll
+      for (int s = 1; s <= 7; ++s) {
+        const int h = 1 << (s - 1);
+        if (autodet) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = l + 16 * q;
+            const int j = b & (h - 1), k = (b >> (s - 1)) << s;
+            const float2 w = TW[j << (7 - s)];
+            const float2 u = X[r][k + j], v = X[r][k + j + h];
+            const float p0 = w.x * v.x, p1 = w.y * v.y, p2 = w.x * v.y, p3 = w.y * v.x;
+            const float tr = p0 - p1, ti = p2 + p3;
+            X[r][k + j] = make_float2(u.x + tr, u.y + ti);
+            X[r][k + j + h] = make_float2(u.x - tr, u.y - ti);
+          }
+        }
+        WAVE_SYNC();
+      }
+      if (autodet) {              // arm_cmplx_mag_squared_f32, .cpp:94
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float2 x = X[r][8 * l + j];
+          const float p = x.x * x.x, q = x.y * x.y;
+          P[r][8 * l + j] = p + q;
+        }
+        if (l == 0) P[r][128] = X[r][64].x;   // what the reference's buffer[128] holds after the in-place magnitude pass
+      }
+      WAVE_SYNC();
+      if (autodet) {
+        // .cpp:96-105: sequential float sum and first-maximum scan over lines 5..122, every lane of the row redundantly
+        // (same LDS addresses -> broadcast reads; no result hand-off needed)
+        float avg = 0.0f, mx = 0.0f;
+        int line = 0;
+#pragma unroll 2
+        for (int i = 5; i < 123; ++i) {
+          const float p = P[r][i];
+          avg += p;
+          if (p > mx) { line = i; mx = p; }
+        }
+        avg /= 118.0f;
+        const float ratio = mx / P[r][128 - line];                       // .cpp:107
+        int strong = 0;
+        if ((double)mx > 10.0 * (double)avg) {                            // .cpp:109
+          strong = 1;
+          if ((double)ratio < 10.0) fail = (int16_t)(fail + 1); else fail = 0;   // .cpp:110-111
+          if (fail > 10) {                                                 // .cpp:112-117
+            corr = (int16_t)(corr + 1);
+            if (corr > 1) corr = -1;
+            fail = 0; succ = 0;
+          }
+          succ = (int16_t)(succ + 1);                                      // .cpp:118
+        }
+        if (succ > 1000) autodet = 0;                                      // .cpp:120-122
+        st.max_line = line; st.strong = strong; st.max_power = mx; st.avg_power = avg; st.ratio = ratio;
+      }
+      WAVE_SYNC();
+    }
+
+    // ---- I/Q swap (.cpp:127-133) and store -----------------------------------------------------------------
+    if (valid) {
+      Raw8 oi, oq;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { oi.s[j] = (int16_t)(swap ? xq[j] : xi[j]); oq.s[j] = (int16_t)(swap ? xi[j] : xq[j]); }
+      const size_t oo = ((size_t)ch * a.out_stride + blk) * ASDR_N + 8 * l;
+      *reinterpret_cast<int4 *>(a.out_i + oo) = oi.v;
+      *reinterpret_cast<int4 *>(a.out_q + oo) = oq.v;
+    }
+  }
+  if (valid && l == 0) {
+    st.correction = (int16_t)corr; st.saved_sample = (int16_t)saved; st.failure_count = (int16_t)fail; st.success_count = (int16_t)succ;
+    st.auto_detect = autodet;
+    a.state[ch] = st;
+  }
+}
+
+extern "C" int asdr_launch_pre(const PreArgs *a, void *stream) {
+  const int grid = (a->n_channels + 3) / 4;
+  hipLaunchKernelGGL(asdr_pre_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =====================================================================================================
+// AudioIQgenerator: 8 channels per wave, 8 lanes per channel, 16 output samples per lane.  The 3-block delay
+// line (384 floats) of each channel lives in LDS for the whole call and slides by one block per iteration.
+//   Q[i] = sum_k c[k] * (w[255 + i - 2k] - w[i + 2k + 1]),  k ascending, float32 (.cpp:65-73);  I[i] = w[128 + i] (.cpp:75)
+// The folded FIR runs on register windows: for the 8 same-parity outputs of a lane and 16 consecutive taps, both
+// operand streams are 23-entry stride-2 windows of the delay line.
+// =====================================================================================================
+#define IQ_STRIDE 388   /* 97 sixteen-byte slots == 1 (mod 16): the 8 channel rows start on different LDS slots */
+
+__global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
+  __shared__ float W[8 * IQ_STRIDE];
+  const int lane = threadIdx.x, c8 = lane >> 3, s8 = lane & 7;
+  const int ch = blockIdx.x * 8 + c8;
+  const bool valid = ch < a.n_channels;
+  float *w = W + c8 * IQ_STRIDE;
+  const int i0 = 16 * s8;
+  const int chc = valid ? ch : 0;   // clamped: lanes of a padding channel read channel 0 and discard
+  const float gain_i = a.gains[2 * chc], gain_q = a.gains[2 * chc + 1];
+  {
+    const float4 *h = reinterpret_cast<const float4 *>(a.hist + (size_t)chc * 256 + 32 * s8);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) reinterpret_cast<float4 *>(w + 32 * s8)[q] = h[q];
+  }
+
+#pragma unroll 1
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    {   // newest block -> w[256..383], scaled (.cpp:56)
+      Raw8 r0, r1;
+      r0.v = r1.v = make_int4(0, 0, 0, 0);
+      if (valid) {
+        const int4 *p = reinterpret_cast<const int4 *>(a.in + ((size_t)ch * a.in_stride + blk) * ASDR_N + i0);
+        r0.v = p[0]; r1.v = p[1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { w[256 + i0 + j] = unit_scale(r0.s[j]); w[256 + i0 + 8 + j] = unit_scale(r1.s[j]); }
+    }
+    WAVE_SYNC();
+    float acc[2][8];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[par][e] = 0.0f;
+#pragma unroll 1
+      for (int kc = 0; kc < 4; ++kc) {
+        // output i = i0 + par + 2e, tap k = 16kc + kk:  A = w[255 + i - 2k] = Aw[e - kk + 15],  B = w[i + 2k + 1] = Bw[e + kk]
+        const float *pa = w + (255 + i0 + par - 32 * kc - 30);
+        const float *pb = w + (i0 + par + 1 + 32 * kc);
+        float Aw[23], Bw[23];
+#pragma unroll
+        for (int t = 0; t < 23; ++t) { Aw[t] = pa[2 * t]; Bw[t] = pb[2 * t]; }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const float c = c_iq_taps[16 * kc + kk];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = Aw[e - kk + 15] - Bw[e + kk];
+            const float pr = c * d;
+            acc[par][e] += pr;
+          }
+        }
+      }
+    }
+    if (valid) {   // .cpp:78-82: (int16_t)(float * 32767.0 * gain) in binary64; v_cvt_i32_f64 saturates like the ARM target
+      int vi[16], vq[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float iv = w[128 + i0 + j];
+        const float qv = acc[j & 1][j >> 1];
+        vi[j] = (int)(((double)iv * 32767.0) * (double)gain_i);
+        vq[j] = (int)(((double)qv * 32767.0) * (double)gain_q);
+      }
+      Raw8 oi[2], oq[2];   // (int16_t) keeps the low half, like the reference's cast
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        oi[h].v = make_int4(pack16(vi[8 * h], vi[8 * h + 1]), pack16(vi[8 * h + 2], vi[8 * h + 3]), pack16(vi[8 * h + 4], vi[8 * h + 5]), pack16(vi[8 * h + 6], vi[8 * h + 7]));
+        oq[h].v = make_int4(pack16(vq[8 * h], vq[8 * h + 1]), pack16(vq[8 * h + 2], vq[8 * h + 3]), pack16(vq[8 * h + 4], vq[8 * h + 5]), pack16(vq[8 * h + 6], vq[8 * h + 7]));
+      }
+      const size_t oo = ((size_t)ch * a.out_stride + blk) * ASDR_N + i0;
+      int4 *po = reinterpret_cast<int4 *>(a.out_i + oo), *pq = reinterpret_cast<int4 *>(a.out_q + oo);
+      po[0] = oi[0].v; po[1] = oi[1].v; pq[0] = oq[0].v; pq[1] = oq[1].v;
+    }
+    WAVE_SYNC();
+    // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383];
+    // source and destination of each phase are disjoint, 16 floats per lane
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const float4 *src = reinterpret_cast<const float4 *>(w + 128 * (ph + 1) + 16 * s8);
+      float4 *dst = reinterpret_cast<float4 *>(w + 128 * ph + 16 * s8);
+      const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+      dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3;
+      WAVE_SYNC();
+    }
+  }
+  if (valid) {
+    float4 *h = reinterpret_cast<float4 *>(a.hist + (size_t)ch * 256 + 32 * s8);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[q] = reinterpret_cast<const float4 *>(w + 32 * s8)[q];
+  }
+}
+
+extern "C" int asdr_launch_iqgen(const IqgenArgs *a, void *stream) {
+  const int grid = (a->n_channels + 7) / 8;
+  hipLaunchKernelGGL(asdr_iqgen_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =====================================================================================================
+// AudioGrabberComplex256: one wave per channel, two complex samples per lane and half buffer.  Only the blocks
+// that can still be visible after the call are touched: the last pair completed by this call (-> _outBuffer and
+// _buffer) and a trailing unpaired block (-> first half of _buffer).
+// =====================================================================================================
+__device__ __forceinline__ int2 interleave2(int i2, int q2) {   // (i0,i1),(q0,q1) -> (i0,q0),(i1,q1)
+  return make_int2((i2 & 0xFFFF) | (q2 << 16), ((unsigned)i2 >> 16) | (q2 & 0xFFFF0000));
+}
+
+__global__ __launch_bounds__(64) void asdr_grab_kernel(GrabArgs a) {
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  const int total = a.parity + a.n_blocks, n_pairs = total >> 1;
+  int2 *buf = reinterpret_cast<int2 *>(a.buffer + (size_t)ch * 512);       // 128 int2: [0..63] first half, [64..127] second
+  int2 *outb = reinterpret_cast<int2 *>(a.out_buffer + (size_t)ch * 512);
+  const size_t row = (size_t)ch * a.in_stride * ASDR_N;
+  auto load_block = [&](int blk) {
+    const int i2 = *reinterpret_cast<const int *>(a.in_i + row + (size_t)blk * ASDR_N + 2 * lane);
+    const int q2 = *reinterpret_cast<const int *>(a.in_q + row + (size_t)blk * ASDR_N + 2 * lane);
+    return interleave2(i2, q2);
+  };
+  if (n_pairs >= 1) {
+    const int e = 2 * n_pairs - 1 - a.parity;                  // block (of this call) that completes the last pair
+    const int2 second = load_block(e);
+    const int2 first = (e >= 1) ? load_block(e - 1) : buf[lane];   // its first half may predate this call
+    outb[lane] = first; outb[64 + lane] = second;               // .cpp:63-65
+    buf[lane] = first; buf[64 + lane] = second;
+  }
+  if (total & 1) buf[lane] = load_block(a.n_blocks - 1);        // trailing unpaired block, .cpp:59
+}
+
+extern "C" int asdr_launch_grab(const GrabArgs *a, void *stream) {
+  hipLaunchKernelGGL(asdr_grab_kernel, dim3(a->n_channels), dim3(64), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

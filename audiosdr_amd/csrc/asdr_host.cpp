@@ -291,7 +291,7 @@ int read_small(asdr_batch *b, int ch, ChanSmall &s) {
   if (!b || ch < 0 || ch >= b->n) return fail("bad channel");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
-  if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
   if (apply_resets(b, b->stream) != 0) return -1;
   HIPCHK(hipMemcpy(&s, b->d_small + ch, sizeof s, hipMemcpyDeviceToHost));
@@ -303,6 +303,10 @@ int read_small(asdr_batch *b, int ch, ChanSmall &s) {
 extern "C" {
 
 const char *asdr_last_error(void) { return g_err.c_str(); }
+}  // extern "C"
+// shared with asdr_front_host.cpp (internal C++ linkage, not part of the C ABI)
+int asdr_internal_fail(const std::string &m) { return fail(m); }
+extern "C" {
 const char *asdr_version(void) { return "asdr-hip 0.1 (gfx950, wave64, -ffp-contract=off)"; }
 
 asdr_batch_t *asdr_create(int n_channels, int device) {
@@ -459,7 +463,7 @@ int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, 
   if (n_blocks == 0) return 0;
   if (!host_out) return fail("null output");
   HIPCHK(hipSetDevice(b->device));
-  if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipMemcpy(host_out, b->d_capture + ((size_t)ch * b->capture_cap + first_block) * ASDR_N,
                    (size_t)n_blocks * ASDR_N * sizeof(int16_t), hipMemcpyDeviceToHost));
   return 0;
@@ -494,7 +498,7 @@ int asdr_synchronize(asdr_batch_t *b) {
   if (!b) return fail("null batch");
   if (b->device == ASDR_NO_DEVICE) return 0;
   HIPCHK(hipSetDevice(b->device));
-  if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }

@@ -1,0 +1,218 @@
+/* asdr_front_oracle.c -- see asdr_front_oracle.h.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED. */
+#include "asdr_front_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../audiosdr_amd/csrc/asdr_front_tables.h"
+#include "asdr_oracle.h"
+
+#define N_BLOCK 128
+
+/* ------------------------------------------------------------------------------------------ */
+/* AudioSDRpreProcessor                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+struct ao_pre {
+  float buffer[256];          /* .h:73 */
+  int16_t I2Scorrection;      /* .h:76 = 0 */
+  int16_t savedSample;        /* .h:77 = 0 */
+  int16_t failureCount;       /* .h:78 = 0 */
+  int16_t successCount;       /* .h:79 = 0 */
+  int IQswap;                 /* .h:80 = false */
+  int autoDetectFlag;         /* .h:82 = false */
+  int max_line, strong;
+  float max_power, avg_power, ratio;
+};
+
+ao_pre_t *ao_pre_create(void) { return (ao_pre_t *)calloc(1, sizeof(ao_pre_t)); }
+void ao_pre_destroy(ao_pre_t *p) { free(p); }
+
+static unsigned bitrev7(unsigned n) {
+  unsigned r = 0;
+  for (int b = 0; b < 7; b++) r |= ((n >> b) & 1u) << (6 - b);
+  return r;
+}
+
+void ao_fft128(float *buf) {
+  float x[256];
+  memcpy(x, buf, sizeof x);
+  for (unsigned n = 0; n < 128; n++) { unsigned r = bitrev7(n); buf[2 * r] = x[2 * n]; buf[2 * r + 1] = x[2 * n + 1]; }
+  for (int s = 1; s <= 7; s++) {
+    const int m = 1 << s, h = m >> 1, step = 128 / m;
+    for (int k = 0; k < 128; k += m)
+      for (int j = 0; j < h; j++) {
+        const float wr = asdr_fft128_tw[j * step][0], wi = asdr_fft128_tw[j * step][1];
+        float *u = buf + 2 * (k + j), *v = buf + 2 * (k + j + h);
+        const float p0 = wr * v[0], p1 = wi * v[1], p2 = wr * v[1], p3 = wi * v[0];
+        const float tr = p0 - p1, ti = p2 + p3;
+        const float ur = u[0], ui = u[1];
+        u[0] = ur + tr; u[1] = ui + ti;
+        v[0] = ur - tr; v[1] = ui - ti;
+      }
+  }
+}
+
+void ao_pre_update(ao_pre_t *p, int16_t *I, int16_t *Q) {
+  /* skew compensation, .cpp:62-72 */
+  if (p->I2Scorrection == 1) {
+    int16_t temp = I[N_BLOCK - 1];
+    for (int i = N_BLOCK - 1; i > 0; i--) I[i] = I[i - 1];
+    I[0] = p->savedSample;
+    p->savedSample = temp;
+  } else if (p->I2Scorrection == -1) {
+    int16_t temp = Q[N_BLOCK - 1];
+    for (int i = N_BLOCK - 1; i > 0; i--) Q[i] = Q[i - 1];
+    I[0] = p->savedSample;            /* .cpp:69: the saved Q sample lands in blockI->data[0]; Q[0] keeps its value */
+    p->savedSample = temp;
+  }
+  /* detector, .cpp:82-122 */
+  if (p->autoDetectFlag) {
+    const int n_FFT = 128, min = 5;
+    int maxLine = 0;
+    float *buffer = p->buffer;
+    for (int i = 0; i < 128; i++) {   /* .cpp:88-91: float / double literal -> binary64 division, stored float */
+      buffer[2 * i] = (float)((double)(float)I[i] / 32767.0);
+      buffer[2 * i + 1] = (float)((double)(float)Q[i] / 32767.0);
+    }
+    ao_fft128(buffer);                /* stands in for arm_cfft_f32(&arm_cfft_sR_f32_len128, buffer, 0, 1), .cpp:93 */
+    for (int i = 0; i < 128; i++) {   /* arm_cmplx_mag_squared_f32, .cpp:94: real*real + imag*imag */
+      const float re = buffer[2 * i], im = buffer[2 * i + 1];
+      const float a = re * re, b = im * im;
+      buffer[i] = a + b;              /* in place is safe: element i is written after elements 2i, 2i+1 are read */
+    }
+    float average_power = 0.0f, maximum_power = 0.0f;
+    for (int i = min; i < (n_FFT - min); i++) {     /* .cpp:98-104 */
+      average_power += buffer[i];
+      if (buffer[i] > maximum_power) { maxLine = i; maximum_power = buffer[i]; }
+    }
+    average_power /= (float)(n_FFT - 2 * min);      /* .cpp:105 */
+    const float imbalance_ratio = maximum_power / buffer[n_FFT - maxLine];   /* .cpp:107 (buffer[128] when no line won) */
+    p->max_line = maxLine; p->max_power = maximum_power; p->avg_power = average_power; p->ratio = imbalance_ratio;
+    p->strong = 0;
+    if ((double)maximum_power > 10.0 * (double)average_power) {              /* .cpp:109, spectralAvgMultiplier */
+      p->strong = 1;
+      if ((double)imbalance_ratio < 10.0) p->failureCount++;                 /* .cpp:110, minImbalanceRatio */
+      else p->failureCount = 0;
+      if (p->failureCount > 10) {                                            /* .cpp:112, maxFailureCount */
+        p->I2Scorrection++;
+        if (p->I2Scorrection > 1) p->I2Scorrection = -1;
+        p->failureCount = 0;
+        p->successCount = 0;
+      }
+      p->successCount++;                                                     /* .cpp:118 */
+    }
+    if (p->successCount > 1000) p->autoDetectFlag = 0;                       /* .cpp:120-122, maxSuccessCount */
+  }
+  /* swap, .cpp:127-133 */
+  if (p->IQswap) {
+    for (int i = 0; i < 128; i++) { int16_t t = I[i]; I[i] = Q[i]; Q[i] = t; }
+  }
+}
+
+void ao_pre_startAutoI2SerrorDetection(ao_pre_t *p) { p->autoDetectFlag = 1; p->I2Scorrection = 0; p->failureCount = 0; p->successCount = 0; }
+void ao_pre_stopAutoI2SerrorDetection(ao_pre_t *p) { p->autoDetectFlag = 0; p->I2Scorrection = 0; }
+int ao_pre_getAutoI2SerrorDetectionStatus(const ao_pre_t *p) { return p->autoDetectFlag; }
+void ao_pre_setI2SerrorCompensation(ao_pre_t *p, int correction) { p->I2Scorrection = (int16_t)correction; p->autoDetectFlag = 0; }
+int16_t ao_pre_getI2SerrorCompensation(const ao_pre_t *p) { return p->I2Scorrection; }
+void ao_pre_swapIQ(ao_pre_t *p, int swap) { p->IQswap = swap ? 1 : 0; }
+
+void ao_pre_get_state(const ao_pre_t *p, ao_pre_state_t *s) {
+  s->correction = p->I2Scorrection; s->saved_sample = p->savedSample; s->failure_count = p->failureCount;
+  s->success_count = p->successCount; s->auto_detect = p->autoDetectFlag; s->swap = p->IQswap;
+  s->max_line = p->max_line; s->strong = p->strong; s->max_power = p->max_power; s->avg_power = p->avg_power; s->ratio = p->ratio;
+}
+const float *ao_pre_power_spectrum(const ao_pre_t *p) { return p->buffer; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* AudioIQgenerator                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+struct ao_iqgen {
+  float bufferI[3 * N_BLOCK];   /* .cpp:37-38: function-static in the reference, i.e. ONE pair of delay lines shared by */
+  float bufferQ[3 * N_BLOCK];   /* every instance of the class; one instance == one oracle object here             */
+  float gainI, gainQ;           /* .h:69-70 = 1.0 */
+};
+
+ao_iqgen_t *ao_iqgen_create(void) {
+  ao_iqgen_t *g = (ao_iqgen_t *)calloc(1, sizeof *g);
+  if (g) { g->gainI = 1.0f; g->gainQ = 1.0f; }
+  return g;
+}
+void ao_iqgen_destroy(ao_iqgen_t *g) { free(g); }
+void ao_iqgen_setGainBalance(ao_iqgen_t *g, float balance) { g->gainI = balance; g->gainQ = (float)(1.0 / (double)balance); }
+const float *ao_iqgen_hilbert_taps(void) { return asdr_iqgen_hilbert_taps; }
+
+void ao_iqgen_update(ao_iqgen_t *g, const int16_t *in, int16_t *outI, int16_t *outQ) {
+  const int hilbertFilterLength = 257, hilbertDelay = 128;   /* .h:85-86 */
+  float Idata[N_BLOCK], Qdata[N_BLOCK];
+  for (int i = 0; i < N_BLOCK; i++) {                        /* .cpp:52-60 */
+    const float v = (float)((double)(float)in[i] / 32767.0);
+    g->bufferI[i] = g->bufferI[N_BLOCK + i];
+    g->bufferI[N_BLOCK + i] = g->bufferI[2 * N_BLOCK + i];
+    g->bufferI[2 * N_BLOCK + i] = v;
+    g->bufferQ[i] = g->bufferQ[N_BLOCK + i];
+    g->bufferQ[N_BLOCK + i] = g->bufferQ[2 * N_BLOCK + i];
+    g->bufferQ[2 * N_BLOCK + i] = v;
+  }
+  for (int i = 0; i < N_BLOCK; i++) {                        /* .cpp:65-76 */
+    float acc = 0.0f;
+    for (int k = 0; k < hilbertFilterLength / 4; k++) {
+      const int indx1 = (2 * N_BLOCK + i) - (2 * k + 1);
+      const int indx2 = (2 * N_BLOCK + i) - hilbertFilterLength + 2 * (k + 1);
+      const float d = g->bufferQ[indx1] - g->bufferQ[indx2];
+      const float pr = asdr_iqgen_hilbert_taps[k] * d;
+      acc += pr;
+    }
+    Qdata[i] = acc;
+    Idata[i] = g->bufferI[2 * N_BLOCK + i - hilbertDelay];
+  }
+  for (int i = 0; i < N_BLOCK; i++) {                        /* .cpp:78-82: float * 32767.0 * float in binary64 */
+    outI[i] = (int16_t)ao_f64_to_i32(((double)Idata[i] * 32767.0) * (double)g->gainI);
+    outQ[i] = (int16_t)ao_f64_to_i32(((double)Qdata[i] * 32767.0) * (double)g->gainQ);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* AudioGrabberComplex256                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+struct ao_grab {
+  int16_t buffer[512], outBuffer[512];
+  uint16_t buffStart;
+  int dataBufferValid, transferringData, newDataIsAvailable;   /* .h:58-60 (valid has no initialiser: zero, as static storage) */
+};
+ao_grab_t *ao_grab_create(void) { return (ao_grab_t *)calloc(1, sizeof(ao_grab_t)); }
+void ao_grab_destroy(ao_grab_t *g) { free(g); }
+void ao_grab_update(ao_grab_t *g, const int16_t *I, const int16_t *Q) {
+  if (!g->transferringData) {
+    int16_t *dst = g->buffer + g->buffStart;
+    for (int i = 0; i < N_BLOCK; i++) { *dst++ = I[i]; *dst++ = Q[i]; }     /* .cpp:39-47 */
+    g->buffStart = (uint16_t)((g->buffStart + 256) % 512);
+    if (g->buffStart == 0) {
+      g->dataBufferValid = 0;
+      memcpy(g->outBuffer, g->buffer, sizeof g->outBuffer);
+      g->newDataIsAvailable = 1;
+      g->dataBufferValid = 1;
+    }
+  }
+}
+int ao_grab_newDataAvailable(const ao_grab_t *g) { return g->newDataIsAvailable; }
+void ao_grab_grab(ao_grab_t *g, int16_t *destination) {
+  if (g->dataBufferValid) {
+    g->transferringData = 1;
+    memcpy(destination, g->outBuffer, sizeof g->outBuffer);
+  }
+  g->transferringData = 0;
+  g->newDataIsAvailable = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int ao_front_check_div32767(void) {
+  int bad = 0;
+  const double c = 32767.0, r = 1.0 / 32767.0;
+  for (int s = -32768; s < 32768; s++) {
+    const double x = (double)(float)s, q0 = x * r, rem = fma(-q0, c, x), q = fma(rem, r, q0);
+    const float a = (float)q, b = (float)(x / c);
+    if (memcmp(&a, &b, 4) != 0) bad++;
+  }
+  return bad;
+}

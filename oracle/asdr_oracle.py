@@ -27,13 +27,22 @@ TAPS = ["SCALED_I", "SCALED_Q", "NB_I", "NB_Q", "IF_I", "IF_Q", "MIX_I", "MIX_Q"
 def build(force=False):
     """Compile the oracle with gcc (seconds).  Building the checker is not using it."""
     src = os.path.join(_HERE, "asdr_oracle.c")
-    deps = [src, os.path.join(_HERE, "asdr_oracle.h"),
-            os.path.join(_HERE, "..", "audiosdr_amd", "csrc", "asdr_tables.h")]
+    deps = [src, os.path.join(_HERE, "asdr_oracle.h"), os.path.join(_HERE, "asdr_front_oracle.c"),
+            os.path.join(_HERE, "asdr_front_oracle.h"),
+            os.path.join(_HERE, "..", "audiosdr_amd", "csrc", "asdr_tables.h"),
+            os.path.join(_HERE, "..", "audiosdr_amd", "csrc", "asdr_front_tables.h")]
     if not force and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "libasdr_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+class PreState(C.Structure):
+    """ao_pre_state_t (asdr_front_oracle.h)."""
+    _fields_ = [("correction", C.c_int16), ("saved_sample", C.c_int16), ("failure_count", C.c_int16), ("success_count", C.c_int16),
+                ("auto_detect", C.c_int32), ("swap", C.c_int32), ("max_line", C.c_int32), ("strong", C.c_int32),
+                ("max_power", C.c_float), ("avg_power", C.c_float), ("ratio", C.c_float)]
 
 
 _lib = None
@@ -102,6 +111,27 @@ def lib():
     L.ao_check_sin_interp_f32.restype = i32
     L.ao_bench_run.argtypes = [i32, i32, i32, i16p, i16p, i16p, i32]
     L.ao_bench_run.restype = C.c_double
+    # blocks around the hot path (asdr_front_oracle.h)
+    L.ao_pre_create.restype = vp; L.ao_pre_destroy.argtypes = [vp]
+    L.ao_pre_update.argtypes = [vp, i16p, i16p]
+    for n in ("startAutoI2SerrorDetection", "stopAutoI2SerrorDetection"):
+        getattr(L, "ao_pre_" + n).argtypes = [vp]
+    L.ao_pre_getAutoI2SerrorDetectionStatus.argtypes = [vp]; L.ao_pre_getAutoI2SerrorDetectionStatus.restype = i32
+    L.ao_pre_setI2SerrorCompensation.argtypes = [vp, i32]
+    L.ao_pre_getI2SerrorCompensation.argtypes = [vp]; L.ao_pre_getI2SerrorCompensation.restype = C.c_int16
+    L.ao_pre_swapIQ.argtypes = [vp, i32]
+    L.ao_pre_get_state.argtypes = [vp, C.POINTER(PreState)]
+    L.ao_pre_power_spectrum.argtypes = [vp]; L.ao_pre_power_spectrum.restype = fp
+    L.ao_fft128.argtypes = [fp]
+    L.ao_iqgen_create.restype = vp; L.ao_iqgen_destroy.argtypes = [vp]
+    L.ao_iqgen_update.argtypes = [vp, i16p, i16p, i16p]
+    L.ao_iqgen_setGainBalance.argtypes = [vp, f32]
+    L.ao_iqgen_hilbert_taps.restype = fp
+    L.ao_grab_create.restype = vp; L.ao_grab_destroy.argtypes = [vp]
+    L.ao_grab_update.argtypes = [vp, i16p, i16p]
+    L.ao_grab_newDataAvailable.argtypes = [vp]; L.ao_grab_newDataAvailable.restype = i32
+    L.ao_grab_grab.argtypes = [vp, i16p]
+    L.ao_front_check_div32767.restype = i32
     _lib = L
     return L
 
@@ -194,3 +224,117 @@ def biquad_cascade(coefs, state, x):
     y = np.empty_like(x)
     lib().ao_biquad_cascade_df1(_fp(coefs), _fp(state), coefs.size // 5, _fp(x), _fp(y), x.size)
     return y, state
+
+
+# --- the blocks around the hot path (asdr_front_oracle.h) ---
+class OraclePreProcessor:
+    """One reference-equivalent AudioSDRpreProcessor (AudioSDRpreProcessor.h:49-84)."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = self._L.ao_pre_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ao_pre_destroy(self._h)
+            self._h = None
+
+    def update(self, I, Q):
+        """I, Q: int16 [n_blocks*128]; returns the conditioned (I, Q) (the reference rewrites its blocks in place)."""
+        I = np.array(I, dtype=np.int16).reshape(-1).copy()
+        Q = np.array(Q, dtype=np.int16).reshape(-1).copy()
+        assert I.size == Q.size and I.size % BLOCK == 0
+        for b in range(I.size // BLOCK):
+            self._L.ao_pre_update(self._h, _i16p(I[b * BLOCK:]), _i16p(Q[b * BLOCK:]))
+        return I, Q
+
+    def startAutoI2SerrorDetection(self):
+        self._L.ao_pre_startAutoI2SerrorDetection(self._h)
+
+    def stopAutoI2SerrorDetection(self):
+        self._L.ao_pre_stopAutoI2SerrorDetection(self._h)
+
+    def getAutoI2SerrorDetectionStatus(self):
+        return int(self._L.ao_pre_getAutoI2SerrorDetectionStatus(self._h))
+
+    def setI2SerrorCompensation(self, correction):
+        self._L.ao_pre_setI2SerrorCompensation(self._h, int(correction))
+
+    def getI2SerrorCompensation(self):
+        return int(self._L.ao_pre_getI2SerrorCompensation(self._h))
+
+    def swapIQ(self, swap):
+        self._L.ao_pre_swapIQ(self._h, 1 if swap else 0)
+
+    def state(self):
+        s = PreState()
+        self._L.ao_pre_get_state(self._h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in PreState._fields_}
+
+    def power_spectrum(self):
+        return np.ctypeslib.as_array(self._L.ao_pre_power_spectrum(self._h), shape=(128,)).copy()
+
+
+class OracleIQgenerator:
+    """One reference-equivalent AudioIQgenerator (AudioIQgenerator.h:48-106)."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = self._L.ao_iqgen_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ao_iqgen_destroy(self._h)
+            self._h = None
+
+    def setGainBalance(self, balance):
+        self._L.ao_iqgen_setGainBalance(self._h, float(balance))
+
+    def update(self, x):
+        """x: int16 [n_blocks*128] real input; returns (I, Q) int16 of the same length."""
+        x = np.ascontiguousarray(x, dtype=np.int16).reshape(-1)
+        assert x.size % BLOCK == 0
+        I, Q = np.empty_like(x), np.empty_like(x)
+        for b in range(x.size // BLOCK):
+            self._L.ao_iqgen_update(self._h, _i16p(x[b * BLOCK:]), _i16p(I[b * BLOCK:]), _i16p(Q[b * BLOCK:]))
+        return I, Q
+
+
+class OracleGrabber:
+    """One reference-equivalent AudioGrabberComplex256 (AudioGrabberComplex256.h:44-63)."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = self._L.ao_grab_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ao_grab_destroy(self._h)
+            self._h = None
+
+    def update(self, I, Q):
+        I = np.ascontiguousarray(I, dtype=np.int16).reshape(-1)
+        Q = np.ascontiguousarray(Q, dtype=np.int16).reshape(-1)
+        for b in range(I.size // BLOCK):
+            self._L.ao_grab_update(self._h, _i16p(I[b * BLOCK:]), _i16p(Q[b * BLOCK:]))
+
+    def newDataAvailable(self):
+        return int(self._L.ao_grab_newDataAvailable(self._h))
+
+    def grab(self, destination=None):
+        d = np.zeros(512, dtype=np.int16) if destination is None else destination
+        self._L.ao_grab_grab(self._h, _i16p(d))
+        return d
+
+
+def fft128(x):
+    """This project's float32 128-point FFT of a complex vector (see asdr_front_oracle.h)."""
+    buf = np.empty(256, dtype=np.float32)
+    x = np.asarray(x)
+    buf[0::2] = x.real.astype(np.float32); buf[1::2] = x.imag.astype(np.float32)
+    lib().ao_fft128(_fp(buf))
+    return buf[0::2].astype(np.complex64) + 1j * buf[1::2]
+
+
+def iqgen_hilbert_taps():
+    return np.ctypeslib.as_array(lib().ao_iqgen_hilbert_taps(), shape=(64,)).copy()
