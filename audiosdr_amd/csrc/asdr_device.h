@@ -122,4 +122,9 @@ typedef struct {
   ChainConsts k;
 } UpdateArgs;
 
+/* instantiations of the update kernel (asdr_launch_update) */
+#define ASDR_KERNEL_PLAIN 0
+#define ASDR_KERNEL_SAM 1
+#define ASDR_KERNEL_ALS 2
+
 #endif /* ASDR_DEVICE_H_ */

@@ -20,7 +20,7 @@
 #include "asdr_tables.h"
 
 extern "C" int asdr_kernels_upload_tables(void);
-extern "C" int asdr_launch_update(const UpdateArgs *a, int with_als, hipStream_t stream);
+extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int n_rows, hipStream_t stream);
 
 namespace {
@@ -112,6 +112,7 @@ struct asdr_batch {
   std::vector<SlotInfo> sched;
   bool params_dirty = true, reset_pending = true, agc_pool_dirty = true;
   bool any_als = false;          // some channel has the ALS filter enabled -> larger-LDS kernel instantiation
+  bool any_sam = false;          // some channel is in SAM mode -> instantiation with the sine table in LDS
   // device
   ChanParams *d_params = nullptr;
   ChanSmall *d_small = nullptr;
@@ -237,8 +238,8 @@ int flush(asdr_batch *b, hipStream_t stream) {
   }
   if (b->params_dirty) {
     for (int i = 0; i < rows; i++) fill_params(b->ch[i], b->hp[i]);
-    b->any_als = false;
-    for (int i = 0; i < b->n; i++) b->any_als = b->any_als || b->ch[i].als_en;
+    b->any_als = false; b->any_sam = false;
+    for (int i = 0; i < b->n; i++) { b->any_als = b->any_als || b->ch[i].als_en; b->any_sam = b->any_sam || b->ch[i].mode == ASDR_SAMmode; }
     std::vector<int32_t> order(b->n);
     for (int i = 0; i < b->n; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(),
@@ -407,7 +408,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = b->ev0, e1 = b->ev1;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   HIPCHK(hipEventRecord(e0, stream));
-  if (asdr_launch_update(&a, b->any_als ? 1 : 0, stream) != 0) return fail("update kernel launch failed");
+  if (asdr_launch_update(&a, b->any_als ? ASDR_KERNEL_ALS : (b->any_sam ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN), stream) != 0) return fail("update kernel launch failed");
   HIPCHK(hipEventRecord(e1, stream));
   b->ev_valid = (e0 == b->ev0);
   b->last_stream = stream;

@@ -26,20 +26,14 @@
 
 // ---- per-channel LDS layout (floats) --------------------------------------------------------------
 // Two instantiations: STRIDE 388 (no channel of the batch uses the ALS filter; 11 waves/CU fit) and 516 (ALS).
-// 388 = 97 sixteen-byte slots == 1 (mod 16): the 8 channels' rows start on different LDS slots.  (A layout that also
-// removes the 2-way conflict between the two sample parities of the Hilbert reads, -DASDR_STRIDE=420 -DASDR_XQ1=224,
-// measured 7 % slower in the same process: profiles/README.md.)
+// 388 = 97 sixteen-byte slots == 1 (mod 16): the 8 channels' rows start on different LDS slots.
 #define W0 0       // working row A: I, later the mono audio
 #define W1 128     // working row B: Q
 #define PH 256     // mixer phase sequence [256,384)
-#define XQ0 0      // Hilbert history, de-interleaved, overlays W0/W1/PH once the mixer has consumed them:
-#ifndef ASDR_XQ1
-#define ASDR_XQ1 192
-#endif
+#define XP 0       // Hilbert history x[1..383] in natural order at [0,383), overlays W0/W1/PH once the mixer has consumed them
 #ifndef ASDR_STRIDE
 #define ASDR_STRIDE 388
 #endif
-#define XQ1 ASDR_XQ1   //   X0 = odd samples [0,192), X1 = even samples shifted by one [192,384)
 #define SCR0 387   // SAM lock flag (last, unused word of the AGC table row; never live together)
 // noise-blanker overlay (dead before the rows above are written)
 #define NB_MAG 0   // envelope of detection indices 78..255: mag[0..177]; later overlaid by the mask
@@ -56,6 +50,8 @@
 #define SCR1 513     // ALS error broadcast word
 
 #define PI_D 3.1415926535897932384626433832795 /* Arduino.h PI (double) */
+
+typedef float v2f __attribute__((ext_vector_type(2)));   // one aligned VGPR pair: operand of v_pk_mul_f32 / v_pk_add_f32
 
 // Build-time ablation mask for profiling builds (DESIGN.md "ablation"); the shipped library uses 0.
 #ifndef ASDR_ABLATE
@@ -108,9 +104,11 @@ __device__ __forceinline__ uint32_t sin_index(float phase, float two_pi, double 
 // AudioSDR.h:365-369: val1 + (((val2 - val1) * (float)delta) / 256.0).  The double divide-by-256 is exact and the
 // double sum of two floats this close in exponent is exact, so the single final rounding equals the float32 sum
 // (checked for all 65,536 table phases by the CPU test-suite).
+// `sine` = the wave's LDS copy of the table, or nullptr = read the __constant__ table through L1 (saves 1 KB of LDS
+// per wave; used when no channel runs the PLL, whose per-sample dependent lookups want the LDS latency).
 __device__ __forceinline__ float sin_lut(const float *sine, uint32_t ip) {
   const uint32_t idx = ip >> 8, d = ip & 0xFFu;
-  const float v1 = sine[idx], v2 = sine[idx + 1];
+  const float v1 = sine ? sine[idx] : c_sine[idx], v2 = sine ? sine[idx + 1] : c_sine[idx + 1];
   return v1 + ((v2 - v1) * (float)d) * (1.0f / 256.0f);
 }
 __device__ __forceinline__ float sin_f32(const float *sine, float phase, float two_pi, double inv_two_pi) {
@@ -269,11 +267,11 @@ __device__ __forceinline__ uint32_t mask_encode(float v) {
 // =====================================================================================================
 // Pointwise stages work LDS-resident in two 8-sample pieces per lane (`#pragma unroll 1` loops), so no 16-wide
 // register array is carried from one stage to the next.
-template <int STRIDE, bool HAS_ALS>
+template <int STRIDE, bool HAS_ALS, bool SINE_LDS>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds) {
   const int lane = threadIdx.x, c8 = lane >> 3, s8_ = lane & 7;
-  float *sine = lds + 8 * STRIDE;
-  for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
+  float *const sine = SINE_LDS ? lds + 8 * STRIDE : nullptr;
+  if (SINE_LDS) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   const int4 slot = *reinterpret_cast<const int4 *>(a.sched + blockIdx.x * 8 + c8);   // {channel, mode, flags, -}
   const int ch_ = slot.x;
@@ -610,8 +608,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (is_ssb) { load8(L + W1 + k0, qn); load8(L + W1 + k0 + 8, qn + 8); }   // own mixed Q samples, written above
       WAVE_SYNC();   // every lane has consumed W0/W1/PH: the history may now overlay them
       if (is_ssb) {
-        // history sample m' = B + k0 + j (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1, 256: this
-        // block): odd m' -> X0[(m'-1)/2], even m' -> X1[(m'-2)/2] (m' = 0 is never used)
+        // history sample x[m'] with m' = B + k0 + j (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1,
+        // 256: this block) is stored at L[XP + m' - 1] (x[0] is never used): natural order shifted by one float, so
+        // that every operand pair (x[odd], x[odd+1]) of the FIR is an 8-byte-aligned LDS pair.
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
           float qo[8], qm[8];
@@ -620,63 +619,61 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int m = k0 + 8 * h + j;
-            if (j & 1) { L[XQ0 + (m - 1) / 2] = qo[j]; L[XQ0 + (128 + m - 1) / 2] = qm[j]; }
-            else { if (m >= 2) L[XQ1 + (m - 2) / 2] = qo[j]; L[XQ1 + (128 + m - 2) / 2] = qm[j]; }
+            if (m >= 1) L[XP + m - 1] = qo[j];
+            L[XP + 127 + m] = qm[j];
           }
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int m = k0 + j;
-          if (j & 1) L[XQ0 + (256 + m - 1) / 2] = qn[j]; else L[XQ1 + (256 + m - 2) / 2] = qn[j];
-        }
+        for (int j = 0; j < 16; ++j) L[XP + 255 + k0 + j] = qn[j];
         store8(hq + hs * 128 + k0, qn); store8(hq + hs * 128 + k0 + 8, qn + 8);   // newest replaces oldest (after its load)
         if (lead) S->hil_slot = hs ^ 1u;
       }
       WAVE_SYNC();
-      float acc[16];
+      v2f acc2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
       if (ABL_ON(ABL_HIL) && is_ssb) {
-        // lane (par, g): outputs i = 2*(16g + j) + par, j = 0..15:
-        //   Q[i] = sum_k h[k] * (X[127 + 16g + j - k] - X[16g + j + k]),  k ascending, accumulate from 0.0
-        const int par = s8 & 1, g = s8 >> 1;
-        const float *X = L + (par ? XQ1 : XQ0);
-        // two passes of 8 outputs keep the register windows at 24 + 24 floats.  (A packed v_pk_*_f32 formulation of
-        // this loop -- half the instructions, bit-identical -- measured 10 % SLOWER end to end: profiles/README.md.)
-#pragma unroll
-        for (int p8 = 0; p8 < 2; ++p8) {
-          float a8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a8[j] = 0.0f;
+        // This lane's 16 outputs i = k0 + 2e, k0 + 2e + 1 (e = 0..7), two per packed FP32 instruction:
+        //   Q[i] = sum_k h[k] * (x[255 + i - 2k] - x[i + 2k + 1]),  k ascending, accumulate from 0.0   (:99-110)
+        // With PX[p] = (x[2p+1], x[2p+2]) the operands of the output pair e are PX[127 + k0/2 + e - k] and
+        // PX[k0/2 + e + k]: per chunk of 8 taps two contiguous 15-pair register windows (ds_read_b128).  v_pk_mul_f32 /
+        // v_pk_add_f32 round each half exactly like the scalar ops, so the result is bit-identical to the scalar loop.
+        const v2f *PX = reinterpret_cast<const v2f *>(L + XP);
+        const int p0 = k0 >> 1;
 #pragma unroll 1
-          for (int kc = 0; kc < 4; ++kc) {
-            float dw[24], uw[24];   // dw[m] = X[112 + 16(g-kc) + 8*p8 + m], uw[m] = X[16(g+kc) + 8*p8 + m]
-            const float *dp = X + 112 + 16 * (g - kc) + 8 * p8, *up = X + 16 * (g + kc) + 8 * p8;
-            load8(dp, dw); load8(dp + 8, dw + 8); load8(dp + 16, dw + 16);
-            load8(up, uw); load8(up + 8, uw + 8); load8(up + 16, uw + 16);
+        for (int kc = 0; kc < 8; ++kc) {
+          v2f dw[16], uw[16];   // dw[t] = PX[120 + p0 - 8kc + t], uw[t] = PX[p0 + 8kc + t]  (t = 0..14 used)
+          const float4 *dp = reinterpret_cast<const float4 *>(PX + 120 + p0 - 8 * kc);
+          const float4 *up = reinterpret_cast<const float4 *>(PX + p0 + 8 * kc);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-              const float hk = c_hilbert[16 * kc + kk];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) a8[j] += hk * (dw[15 + j - kk] - uw[j + kk]);
-              SCHED_FENCE();
-            }
+          for (int q = 0; q < 8; ++q) {
+            const float4 d4 = dp[q], u4 = up[q];
+            dw[2 * q] = (v2f){d4.x, d4.y}; dw[2 * q + 1] = (v2f){d4.z, d4.w};
+            uw[2 * q] = (v2f){u4.x, u4.y}; uw[2 * q + 1] = (v2f){u4.z, u4.w};
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[8 * p8 + j] = a8[j];
+          for (int kk = 0; kk < 8; ++kk) {
+            const float hk = c_hilbert[8 * kc + kk];
+            const v2f hk2 = (v2f){hk, hk};
+            v2f d[8];   // the 8 pair-chains of a tap are independent: issue them interleaved (no dependent back-to-back pk ops)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = dw[7 + e - kk] - uw[e + kk];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = hk2 * d[e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc2[e] += d[e];
+            SCHED_FENCE();
+          }
         }
       }
-      WAVE_SYNC();   // all history reads done: the outputs may overwrite the start of X0 (= row W0)
-      if (is_ssb) {
-        const int par = s8 & 1, g = s8 >> 1;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) L[W0 + 2 * (16 * g + j) + par] = acc[j];
-      }
-      WAVE_SYNC();
+      WAVE_SYNC();   // all history reads done: the audio may overwrite the start of the history (= row W0)
       if (is_ssb) {   // sideband combine (:115-118) with the delayed I = previous block's mixed I (ring slot hs^1)
-#pragma unroll 1
+#pragma unroll
         for (int h = 0; h < 2; ++h) {
           float qh[8], idl[8], au[8];
           load8(hi_ring + (hs ^ 1u) * 128 + 8 * h, idl);
-          load8(L + W0 + k0 + 8 * h, qh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qh[j] = acc2[4 * h + (j >> 1)][j & 1];
 #pragma unroll
           for (int j = 0; j < 8; ++j) au[j] = sub_q ? (idl[j] - qh[j]) : (idl[j] + qh[j]);
           store8(L + W0 + k0 + 8 * h, au);
@@ -920,15 +917,21 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #undef P
 }
 
-// no channel of the batch has the ALS filter enabled: 388 floats of LDS per channel
+// no channel of the batch has the ALS filter or the SAM PLL enabled: 388 floats of LDS per channel, sine table through L1
+// (12,416 B per wave -> 12 waves/CU at 168 VGPRs)
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false>(a, lds);
+}
+// some channel is in SAM mode: the PLL's per-sample dependent sin/cos lookups read a per-wave LDS copy of the table
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel_sam(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE + 260];
-  asdr_update_body<ASDR_STRIDE, false>(a, lds);
+  asdr_update_body<ASDR_STRIDE, false, true>(a, lds);
 }
 // some channel uses the ALS filter: 516 floats per channel (256-sample ALS history + 128 taps in LDS)
 extern "C" __global__ __launch_bounds__(64, 2) void asdr_update_kernel_als(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * 516 + 260];
-  asdr_update_body<516, true>(a, lds);
+  asdr_update_body<516, true, true>(a, lds);
 }
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
@@ -962,11 +965,12 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
   }
 }
 
-// `with_als`: some channel of the batch has the ALS filter enabled -> the larger-LDS instantiation
-extern "C" int asdr_launch_update(const UpdateArgs *a, int with_als, hipStream_t stream) {
+// `variant`: ASDR_KERNEL_PLAIN / _SAM (a channel runs the PLL: sine table in LDS) / _ALS (a channel runs the ALS filter: larger LDS)
+extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (with_als) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a);
+  if (variant == ASDR_KERNEL_ALS) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a);
+  else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3(n_waves), dim3(64), 0, stream, *a);
   else hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
