@@ -305,7 +305,17 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int *Li = reinterpret_cast<int *>(L);
     const int k0 = 16 * s8;
     const bool lead = (s8 == 0);
+#ifdef ASDR_TIMELINE
+    // profiling build (tools/timeline.py): lane 0 of a few waves timestamps the phase boundaries into the taps buffer
+    const int tl_slot = (blockIdx.x == 0) ? 0 : ((blockIdx.x == 2731) ? 1 : ((blockIdx.x == 5461) ? 2 : ((blockIdx.x == 8191) ? 3 : -1)));
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(a.taps) + 32 * (tl_slot < 0 ? 0 : tl_slot);
+#define TL(i) do { if (a.taps != nullptr && tl_slot >= 0 && lane == 0) tl[i] = clock64(); } while (0)
+    const bool tap_on = false;
+    TL(0);
+#else
+#define TL(i) do { } while (0)
     const bool tap_on = (a.taps != nullptr) && valid && (blk == a.n_blocks - 1);
+#endif
     float *tap_base = tap_on ? a.taps + (size_t)ch * ASDR_N + k0 : nullptr;
     const size_t tap_stride = (size_t)a.n_channels * ASDR_N;
 #define TAP8(id, h, v) do { if (tap_on) store8(tap_base + (size_t)(id) * tap_stride + 8 * (h), v); } while (0)
@@ -358,6 +368,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
 
+    TL(1);
     // ---- impulse noise blanker, AudioSDR.cpp:606-650 ------------------------------------------------------
     // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
     // in HBM holds them; output = mask x oldest (2 blocks late).
@@ -392,6 +403,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
       }
       WAVE_SYNC();
+      TL(2);
       if (nb_en && lead) {   // sequential: threshold test against the running average (:627-635), 8 samples per trip
         float avg = S->nb_avg;
         const float thr = P.nb_threshold;
@@ -427,6 +439,23 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         status = (status & ~ASDR_S_NB_DETECTED) | (cnt > 0 ? ASDR_S_NB_DETECTED : 0u);
       }
       WAVE_SYNC();
+      TL(3);
+      // Quiet fast path (wave-uniform): if no channel of the wave has a detection in this block and every carried mask
+      // entry is 1.0, the mask stays all ones -- no zeroing, no trailing ramp, the carried row is unchanged and the output is
+      // the oldest block times 1.0 (x * 1.0f == x for every float) -- so decode / zero / ramp / encode / multiply are skipped.
+      bool nb_quiet = true;
+      if (nb_en) {
+        nb_quiet = (Li[NB_CB + 55] == 0);                       // final detection count of the block (replicated bytes)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) nb_quiet = nb_quiet && (mkc[r] == 0x01010101u);
+      }
+#ifdef ASDR_NB_ALWAYS_SLOW
+      const bool nb_slow = true;
+#else
+      const bool nb_slow = __any(!nb_quiet);
+#endif
+      float mk[16];
+      if (nb_slow) {
       if (nb_en) {
         // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
         // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
@@ -476,7 +505,6 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
       }
       WAVE_SYNC();
-      float mk[16];
       {   // read this lane's mask values and carry mask[128..265(..271)] to the next call, before the rows are reused
         load8(L + NB_MSK + k0, mk); load8(L + NB_MSK + k0 + 8, mk + 8);
         if (nb_en) {
@@ -488,6 +516,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           }
         }
       }
+      }   // nb_slow
       WAVE_SYNC();
       {   // output = mask x oldest block (:646-649) -> IF filter rows; blanker-off channels pass their own input (x 1.0)
         const int4 *src4 = nb_en ? reinterpret_cast<const int4 *>(hist + ns * 256 + k0) : reinterpret_cast<const int4 *>(a.in_i + io);
@@ -500,13 +529,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           wi.v = make_int4(0, 0, 0, 0); wq.v = wi.v;
           if (nb_en || valid) { wi.v = src4[h]; wq.v = srq4[h]; }
           scale8(wi.s, goi, vi); scale8(wq.s, goq, vq);
+          if (nb_slow) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { const float mv = nb_en ? mk[8 * h + j] : 1.0f; vi[j] = mv * vi[j]; vq[j] = mv * vq[j]; }
+            for (int j = 0; j < 8; ++j) { const float mv = nb_en ? mk[8 * h + j] : 1.0f; vi[j] = mv * vi[j]; vq[j] = mv * vq[j]; }
+          }
           store8(L + W0 + k0 + 8 * h, vi); store8(L + W1 + k0 + 8 * h, vq);
         }
       }
     }
     WAVE_SYNC();
+    TL(4);
     TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1);
 
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
@@ -519,6 +551,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
     }
     WAVE_SYNC();
+    TL(5);
     TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1);
 
     // ---- SAM: quadrature PLL, AudioSDR.cpp:688-749 (sequential per channel) ---------------------------------
@@ -581,6 +614,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
     }
     WAVE_SYNC();
+    TL(6);
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
     // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
     float *hi_ring = a.hil_i + (size_t)ch * 256 + k0;
@@ -602,6 +636,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
 
+    TL(7);
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
     if (__any(is_ssb)) {
       float qn[16];
@@ -629,6 +664,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         if (lead) S->hil_slot = hs ^ 1u;
       }
       WAVE_SYNC();
+      TL(8);
       v2f acc2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
@@ -667,6 +703,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
       }
       WAVE_SYNC();   // all history reads done: the audio may overwrite the start of the history (= row W0)
+      TL(9);
       if (is_ssb) {   // sideband combine (:115-118) with the delayed I = previous block's mixed I (ring slot hs^1)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -733,6 +770,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       store8(L + W0 + k0, z); store8(L + W0 + k0 + 8, z);
     }
     WAVE_SYNC();
+    TL(10);
     TAP_ROW(ASDR_TAP_DEMOD, W0);
 
     // AGC scalars are requested here, one phase early (latency hides behind the audio-filter pipeline)
@@ -752,6 +790,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (on) *reinterpret_cast<float4 *>(&S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       WAVE_SYNC();
     }
+    TL(11);
     TAP_ROW(ASDR_TAP_AUDIO_FILT, W0);
 
     // ---- AGC, AudioSDR.cpp:404-436 --------------------------------------------------------------------------
@@ -769,6 +808,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = t4[r]; }
       }
       WAVE_SYNC();
+      TL(12);
       if (agc_en && lead) {
         float old_abs = agc_old0;
         uint32_t hc = agc_hc0;
@@ -804,6 +844,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
       }
       WAVE_SYNC();
+      TL(13);
       if (agc_en) {
         const float sg = P.agc_static_gain;
 #pragma unroll 1
@@ -824,6 +865,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
     }
+    TL(14);
     TAP_ROW(ASDR_TAP_AGC, W0);
 
     // ---- ALS adaptive notch / peak filter, AudioSDR.cpp:324-352 (516-float instantiation only) -----------------
@@ -913,6 +955,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     if (lead) S->status = status;
     WAVE_SYNC();
+    TL(15);
   }
 #undef P
 }
