@@ -38,8 +38,10 @@
 // noise-blanker overlay (dead before the rows above are written)
 #define NB_MAG 0   // envelope of detection indices 78..255: mag[0..177]; later overlaid by the mask
 #define NB_MSK 0   // mask[0..265(..271)]
+#define NB_B 178   // [178,356): beta*mag[t] from the envelope pass, overwritten in place by avg[t] (the running average BEFORE
+                   // sample t) by the sequential pass; dead once the detection flags are in registers
 #define NB_CB 272  // 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count after
-                   // detection index t (0..177), CB[202..222] = final count
+                   // detection index t (0..177), CB[202..222] = final count  (written after NB_B is dead)
 // AGC overlay
 #define AGC_GV 128   // per sample: the envelope value whose compressor gain applies (-1 = gain carried in)
 #define AGC_TAB 256  // this channel's gain table (row of 132 floats)
@@ -161,7 +163,9 @@ __device__ __forceinline__ float agc_compress(const float *tab, float abs_val) {
 }
 
 __device__ __forceinline__ float dpp_row_shr1(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+  // bound_ctrl = true: the lane without a source (lane 0 of a 16-lane row; always a stage-0 lane, which ignores the value)
+  // reads 0 and no `old` operand has to be materialised, so the move folds into its consumer (v_cndmask_b32_dpp)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
 }
 
 // ---- 4-stage DF1 biquad cascade as a lane pipeline -------------------------------------------------
@@ -389,14 +393,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           wi.v = mid4[h]; wq.v = mid4[16 + h];
           scale8(wi.s, gmi, vi); scale8(wq.s, gmq, vq);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { L[NB_MAG + 50 + k0 + 8 * h + j] = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]); if ((j & 3) == 3) SCHED_FENCE(); }
+          for (int j = 0; j < 8; ++j) {
+            const float mg = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]);
+            L[NB_MAG + 50 + k0 + 8 * h + j] = mg; L[NB_B + 50 + k0 + 8 * h + j] = K.nb_beta * mg;
+            if ((j & 3) == 3) SCHED_FENCE();
+          }
           if (k0 + 8 * h + 7 >= 78) {   // only samples 78..127 of the oldest block are re-scanned
             wi.v = old4[h]; wq.v = old4[16 + h];
             scale8(wi.s, goi, vi); scale8(wq.s, goq, vq);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int k = k0 + 8 * h + j;
-              if (k >= 78) L[NB_MAG + k - 78] = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]);
+              if (k >= 78) { const float mg = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]); L[NB_MAG + k - 78] = mg; L[NB_B + k - 78] = K.nb_beta * mg; }
               if ((j & 3) == 3) SCHED_FENCE();
             }
           }
@@ -404,39 +412,75 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       TL(2);
-      if (nb_en && lead) {   // sequential: threshold test against the running average (:627-635), 8 samples per trip
+      if (nb_en && lead) {   // sequential: ONLY the running average (:633-634), which does not depend on the detections:
+                             // avg = alpha*avg + beta*mag, beta*mag staged by the envelope pass; avg[t] replaces it in place
         float avg = S->nb_avg;
-        const float thr = P.nb_threshold;
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int z = 0; z < 6; ++z) Li[NB_CB + z] = 0;
 #pragma unroll 1
         for (int t = 0; t < 176; t += 8) {
-          float m[8];
-          load8(L + NB_MAG + t, m);
-          uint32_t w0 = 0, w1 = 0;
+          float bm[8], av[8];
+          load8(L + NB_B + t, bm);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            cnt += (m[u] > avg * thr) ? 1u : 0u;
-            if (u < 4) w0 |= cnt << (8 * u); else w1 |= cnt << (8 * (u - 4));
-            avg = K.nb_alpha * avg + K.nb_beta * m[u];
-          }
-          *reinterpret_cast<uint2 *>(Li + NB_CB + 6 + (t >> 2)) = make_uint2(w0, w1);   // bytes 24+t .. 24+t+7
+          for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u]; }
+          store8(L + NB_B + t, av);
         }
-        uint32_t w = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float m = L[NB_MAG + 176 + u];
-          cnt += (m > avg * thr) ? 1u : 0u;
-          w |= cnt << (8 * u);
-          avg = K.nb_alpha * avg + K.nb_beta * m;
-        }
-        Li[NB_CB + 50] = w | (cnt << 16) | (cnt << 24);                                  // bytes 200..203
-#pragma unroll
-        for (int z = 51; z < 56; ++z) Li[NB_CB + z] = cnt * 0x01010101u;                 // bytes 204..223
+        for (int u = 0; u < 2; ++u) { const float bmu = L[NB_B + 176 + u]; L[NB_B + 176 + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
         S->nb_avg = avg;
         S->nb_slot = ns_mid;
-        status = (status & ~ASDR_S_NB_DETECTED) | (cnt > 0 ? ASDR_S_NB_DETECTED : 0u);
+      }
+      WAVE_SYNC();
+      // parallel: threshold test mag[t] > avg[t]*threshold (:628) for t = 24*s8 .. 24*s8+23 (lane 7: 168..177), running
+      // counts by a lane-local prefix plus an 8-lane scan
+      uint32_t det_w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+      uint32_t det_total = 0u;
+      if (nb_en) {
+        const float thr = P.nb_threshold;
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          float m[8], av[8];
+          if (s8 < 7 || q == 0) { load8(L + NB_MAG + 24 * s8 + 8 * q, m); load8(L + NB_B + 24 * s8 + 8 * q, av); }
+          else if (q == 1) {   // lane 7: t = 176, 177 only (the rows end at 178 + 178)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m[u] = 0.0f; av[u] = 0.0f; }
+            m[0] = L[NB_MAG + 176]; m[1] = L[NB_MAG + 177]; av[0] = L[NB_B + 176]; av[1] = L[NB_B + 177];
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m[u] = 0.0f; av[u] = 0.0f; }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool live = (s8 < 7) || (8 * q + u < 10);
+            cnt += (live && (m[u] > av[u] * thr)) ? 1u : 0u;
+            det_w[2 * q + (u >> 2)] |= cnt << (8 * (u & 3));   // lane-local running count (<= 24) in byte u of its word
+          }
+        }
+        // exclusive scan of the lane totals over the channel's 8 lanes (DPP row_shr inside the 16-lane row, masked by s8)
+        uint32_t inc = cnt;
+        { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); inc += (s8 >= 1) ? t1 : 0u; }
+        { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); inc += (s8 >= 2) ? t2 : 0u; }
+        { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true); inc += (s8 >= 4) ? t4 : 0u; }
+        const uint32_t base4 = (inc - cnt) * 0x01010101u;   // every byte stays <= 178: no carry between the bytes
+        det_total = inc;   // valid on lane 7: the block's detection count
+#pragma unroll
+        for (int w = 0; w < 6; ++w) det_w[w] += base4;
+      }
+      WAVE_SYNC();   // every lane has read its mag / avg: the counts may overwrite NB_B
+      if (nb_en) {
+        if (s8 < 7) {
+#pragma unroll
+          for (int w = 0; w < 6; w += 2) *reinterpret_cast<uint2 *>(Li + NB_CB + 6 + 6 * s8 + w) = make_uint2(det_w[w], det_w[w + 1]);   // bytes 24+24*s8 ..
+        } else {
+          const uint32_t fin = (det_total & 0xFFu) * 0x01010101u;
+          *reinterpret_cast<uint2 *>(Li + NB_CB + 48) = make_uint2(det_w[0], det_w[1]);                // bytes 192..199: t = 168..175
+          Li[NB_CB + 50] = (det_w[2] & 0xFFFFu) | (fin & 0xFFFF0000u);                                 // bytes 200..203: t = 176, 177, final, final
+#pragma unroll
+          for (int z = 51; z < 56; ++z) Li[NB_CB + z] = fin;                                           // bytes 204..223
+        }
+        if (lead) {
+#pragma unroll
+          for (int z = 0; z < 6; ++z) Li[NB_CB + z] = 0;                                               // bytes 0..23
+        }
       }
       WAVE_SYNC();
       TL(3);
@@ -446,6 +490,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       bool nb_quiet = true;
       if (nb_en) {
         nb_quiet = (Li[NB_CB + 55] == 0);                       // final detection count of the block (replicated bytes)
+        if (lead) status = (status & ~ASDR_S_NB_DETECTED) | (nb_quiet ? 0u : ASDR_S_NB_DETECTED);
 #pragma unroll
         for (int r = 0; r < 5; ++r) nb_quiet = nb_quiet && (mkc[r] == 0x01010101u);
       }

@@ -96,9 +96,9 @@ def main():
             report("C2 USB 64k x 1 block/launch", n_ch, 1, ms, {"parity": check(cfg, I, Q, got, [0, 777, 2047, 65535])})
             b.close()
         if "c2" in which:   # same chain with an impulse every 1000 samples in every channel: the blanker's general path
-            I, Q = tiled(n_ch, 12, 2048, fc=6290.0, A=0.25, impulse_every=1000)
+            I, Q = tiled(n_ch, 28, 2048, fc=6290.0, A=0.25, impulse_every=97)   # an impulse in (almost) every block
             b = A.AudioSDRBatch(n_ch); cfg(b)
-            ms, got = run_launches(b, I, Q, 1, 4, 8)
+            ms, got = run_launches(b, I, Q, 1, 20, 8)                             # the blanker's average has settled by block 20
             st = b.read_status()
             report("C2 USB 64k x 1 block/launch, impulsive input (blanker detecting in every channel)", n_ch, 1, ms,
                    {"parity": check(cfg, I, Q, got, [0, 777, 2047, 65535]), "channels_with_detection": int(st["nb_detected"].sum())})
