@@ -645,16 +645,22 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       float phase = is_ssb ? S->phase_ssb : S->phase_am;
       const float fs = is_ssb ? -P.freq_shift : -K.if_center;
       const float inc = fs * K.phase_inc_unit;
+      // `if (t > twoPI) t -= twoPI; else if (t < 0) t += twoPI;` (.h:514-517) with one test per sample: the phase stays in
+      // [0, twoPI], so for inc >= 0 only the first branch can fire and for inc < 0 only the second.  The test is written as
+      // (t with its sign flipped for inc < 0) > (twoPI or 0), and t - twoPI == t + (-twoPI) exactly.
+      const bool up = !(inc < 0.0f);
+      const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
+      const uint32_t flip = up ? 0u : 0x80000000u;
 #pragma unroll 1
-      for (int i = 0; i < ASDR_N; i += 4) {
-        float pv[4];
+      for (int i = 0; i < ASDR_N; i += 8) {
+        float pv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           pv[u] = phase;
-          const float t = phase + inc, t_dn = t - two_pi, t_up = t + two_pi;
-          phase = (t > two_pi) ? t_dn : ((t < 0.0f) ? t_up : t);   // if (> twoPI) -= twoPI; else if (< 0) += twoPI
+          const float t = phase + inc, tw = t + wrapv;
+          phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
         }
-        *reinterpret_cast<float4 *>(L + PH + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        store8(L + PH + i, pv);
       }
       if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
     }
@@ -858,6 +864,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float old_abs = agc_old0;
         uint32_t hc = agc_hc0;
         const float am_level = (float)(2.0 * (double)(carrier_fresh ? carrier_now : agc_carrier0));
+        const float am_clamped = (am_level > 1.0f) ? 1.0f : am_level;
         const float al_a = P.agc_alpha_att, be_a = P.agc_beta_att, al_r = P.agc_alpha_rel, be_r = P.agc_beta_rel;
         const uint32_t hang = P.agc_hang_count;
         float gv = -1.0f;   // envelope value governing the current gain; -1 = no update yet in this block
@@ -867,13 +874,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           load8(L + W0 + i, x);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            float av = is_am ? am_level : fabsf(x[u]);
-            av = (av > 1.0f) ? 1.0f : av;                  // if (absVal > 1.0) absVal = 1.0 (NaN-preserving like the reference)
+            const float ax = fabsf(x[u]);
+            const float av = is_am ? am_clamped : ((ax > 1.0f) ? 1.0f : ax);   // if (absVal > 1.0) absVal = 1.0 (NaN-preserving like the reference)
             const bool att = av > old_abs;                 // attack
             const bool idle = (hc == 0u);                  // not hanging: release when not attacking
-            const float v_att = al_a * old_abs + be_a * av;
-            const float v_rel = al_r * old_abs + be_r * av;
-            const float v_new = att ? v_att : v_rel;
+            const float al = att ? al_a : al_r, be = att ? be_a : be_r;   // only the branch that is taken is evaluated (:418 / :424)
+            const float pa = al * old_abs, pb = be * av;
+            const float v_new = pa + pb;
             const bool upd = att || idle;
             old_abs = upd ? v_new : old_abs;
             gv = upd ? v_new : gv;
