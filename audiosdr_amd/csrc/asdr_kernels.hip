@@ -857,6 +857,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; t4[r] = (q < 33) ? reinterpret_cast<const float4 *>(gtab)[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = t4[r]; }
+        // |x| clamped to 1.0 (:410-411) for every sample, in parallel; the sequential pass below replaces it in place by the
+        // governing envelope value
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          float au[8], av8[8];
+          load8(L + W0 + k0 + 8 * h, au);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float ax = fabsf(au[j]); av8[j] = (ax > 1.0f) ? 1.0f : ax; }   // NaN-preserving like the reference
+          store8(L + AGC_GV + k0 + 8 * h, av8);
+        }
       }
       WAVE_SYNC();
       TL(12);
@@ -871,11 +881,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll 1
         for (int i = 0; i < ASDR_N; i += 8) {
           float x[8], gvv[8];
-          load8(L + W0 + i, x);
+          load8(L + AGC_GV + i, x);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const float ax = fabsf(x[u]);
-            const float av = is_am ? am_clamped : ((ax > 1.0f) ? 1.0f : ax);   // if (absVal > 1.0) absVal = 1.0 (NaN-preserving like the reference)
+            const float av = is_am ? am_clamped : x[u];   // AM: twice the carrier level stands in for |x| (:407-409)
             const bool att = av > old_abs;                 // attack
             const bool idle = (hc == 0u);                  // not hanging: release when not attacking
             const float al = att ? al_a : al_r, be = att ? be_a : be_r;   // only the branch that is taken is evaluated (:418 / :424)
