@@ -266,6 +266,17 @@ __device__ __forceinline__ uint32_t mask_encode(float v) {
 
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Per-channel rows addressed as (uniform base) + (32-bit byte offset): the offset stays in ONE VGPR and the access uses
+// the scalar-base addressing mode, instead of a 64-bit pointer in two VGPRs per array.  Valid because every state array is
+// smaller than 4 GiB (1,048,577 rows of at most 1.5 KiB).
+template <typename T>
+__device__ __forceinline__ T *row_ptr(T *base, uint32_t byte_off) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 #define WAVE_SYNC() __syncthreads() /* workgroup == one wave: lowers to a wave barrier + LDS/VMEM waits */
 
 // =====================================================================================================
@@ -303,8 +314,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int s8 = s8_; asm volatile("" : "+v"(s8));
     int loff = loff_; asm volatile("" : "+v"(loff));
     int ch = ch_; asm volatile("" : "+v"(ch));
-    const ChanParams *Pp = a.params + ch;
-    ChanSmall *S = a.small + ch;
+    const ChanParams *Pp = row_ptr(a.params, (uint32_t)ch * (uint32_t)sizeof(ChanParams));
+    ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
     float *L = lds + loff;
     int *Li = reinterpret_cast<int *>(L);
     const int k0 = 16 * s8;
@@ -334,8 +345,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const size_t io = ((size_t)ch * a.in_stride + blk) * ASDR_N + k0;       // this lane's 16 input samples
     const size_t io_out = ((size_t)ch * a.out_stride + blk) * ASDR_N + k0;  // ... and its 16 output samples (capture rows may be longer)
     const bool nb_wave = ABL_ON(ABL_NB) && __any(nb_en);   // wave-uniform: some channel of this wave has the blanker on
-    int16_t *hist = a.nb_hist + (size_t)ch * 768;              // 3 slots x {I,Q} x 128 raw int16 samples
-    uint32_t *mrow = reinterpret_cast<uint32_t *>(a.nb_mask + (size_t)ch * ASDR_NB_MASK_ROW) + 5 * s8;   // this lane's 20 mask codes
+    int16_t *hist = row_ptr(a.nb_hist, (uint32_t)ch * 1536u);  // 3 slots x {I,Q} x 128 raw int16 samples
+    uint32_t *mrow = reinterpret_cast<uint32_t *>(row_ptr(a.nb_mask, (uint32_t)ch * ASDR_NB_MASK_ROW + 20u * (uint32_t)s8));   // this lane's 20 mask codes
 
     // ---- load + input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
     // With a blanker in the wave, the blanker's delay line is kept as RAW int16 samples plus the gains that were in
@@ -668,8 +679,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     TL(6);
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
     // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
-    float *hi_ring = a.hil_i + (size_t)ch * 256 + k0;
-    float *hq = a.hil_q + (size_t)ch * 256;
+    float *hi_ring = row_ptr(a.hil_i, (uint32_t)ch * 1024u + 4u * (uint32_t)k0);
+    float *hq = row_ptr(a.hil_q, (uint32_t)ch * 1024u);
     if (ABL_ON(ABL_MIX) && do_mix) {
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
