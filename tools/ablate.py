@@ -19,8 +19,10 @@ VDIR = os.path.join(ROOT, "audiosdr_amd", "variants")
 PHASES = {"NB": 1, "IF": 2, "SAM": 4, "MIX": 8, "HIL": 16, "ENV": 32, "AF": 64, "AGC": 128, "ALS": 256}
 VARIANTS = {"full": 0, "no_NB": 1, "no_IF": 2, "no_MIX": 8, "no_HIL": 16, "no_AF": 64, "no_AGC": 128,
             "io_only": 511}
-EXTRA = {"full_w2": ["-DASDR_WAVES_PER_EU=2"],   # same code, 256-VGPR budget (8 waves/CU)
-         "chunk4": ["-DASDR_PIPE_CHUNK=4"]}   # biquad pipeline with 4-sample chunks (35 steps)
+EXTRA = {"full_w2": ["-DASDR_WAVES_PER_EU=2"],       # same code, 256-VGPR budget (8 waves/CU)
+         "chunk4": ["-DASDR_PIPE_CHUNK=4"],          # biquad pipeline with 4-sample chunks (35 steps)
+         "nb_general": ["-DASDR_NB_ALWAYS_SLOW"]}    # blanker always on its general path (no quiet fast path)
+# Any other libasdr_<name>.so dropped into audiosdr_amd/variants/ (e.g. a build of an older commit) is timed as well.
 
 
 def build():
