@@ -144,7 +144,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
-                       "channels_per_gpu": n_ch, "block": BLOCK, "sharding": "channels, no collective"},
+                       "channels_per_gpu": n_ch, "block": BLOCK, "sharding": "channels, no collective",
+                       "input": "tone + LCG noise per channel, no impulses: the blanker runs (envelope, average, threshold) but detects "
+                                "nothing, so its mask stays all ones; with an impulse in every block of every channel the same chain "
+                                "is ~8 % slower (tools/bench_configs.py c2)"},
             "roofline": {"bound": "hbm", "kernel": "asdr_update_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BLOCK * n_ch,
