@@ -264,6 +264,36 @@ __device__ __forceinline__ uint32_t mask_encode(float v) {
   return c;
 }
 
+// ALS FIR (AudioSDR.cpp:331-335): y = sum_{q < M} w[q] * x[top - q], q ascending, every product and sum separately rounded.
+// CHECKED = false requires every index top - q (q < M) to lie inside the 256-sample history; CHECKED = true reads 0.0
+// outside it (DESIGN.md "defined differences").  Four taps per ds_read_b128 of w.
+template <bool CHECKED>
+__device__ __forceinline__ float als_dot(const float *w, const float *x, int top, int M) {
+  float y = 0.0f;
+  int q = 0;
+#pragma unroll 1
+  for (; q + 4 <= M; q += 4) {
+    const float4 w4 = *reinterpret_cast<const float4 *>(w + q);
+    const int t = top - q;
+    float x0, x1, x2, x3;
+    if (CHECKED) {
+      x0 = (t >= 0 && t < 256) ? x[t] : 0.0f; x1 = (t - 1 >= 0 && t - 1 < 256) ? x[t - 1] : 0.0f;
+      x2 = (t - 2 >= 0 && t - 2 < 256) ? x[t - 2] : 0.0f; x3 = (t - 3 >= 0 && t - 3 < 256) ? x[t - 3] : 0.0f;
+    } else {
+      x0 = x[t]; x1 = x[t - 1]; x2 = x[t - 2]; x3 = x[t - 3];
+    }
+    float p;
+    p = w4.x * x0; y += p; p = w4.y * x1; y += p; p = w4.z * x2; y += p; p = w4.w * x3; y += p;
+  }
+  for (; q < M; ++q) {
+    const int t = top - q;
+    const float xv = CHECKED ? ((t >= 0 && t < 256) ? x[t] : 0.0f) : x[t];
+    const float p = w[q] * xv;
+    y += p;
+  }
+  return y;
+}
+
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Per-channel rows addressed as (uniform base) + (32-bit byte offset): the offset stays in ONE VGPR and the access uses
@@ -957,12 +987,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         WAVE_SYNC();
 #define ALS_HIST(idx) (((idx) >= 0 && (idx) < 256) ? L[ALS_X + (idx)] : 0.0f)
+        // every history index i - D - q (i = 128..255, q < M) is inside [0, 256) iff D >= 0 and D + M <= 129: true for the
+        // reference's defaults (M 55, D 3) and checked per wave
+        const bool als_safe = __all(!als_en || (D >= 0 && D + M <= 129));
         if (__any(als_en && !adaptive)) {
           if (als_en && !adaptive) {
             for (int j = 0; j < 16; ++j) {
               const int i = 128 + k0 + j;
-              float y = 0.0f;
-              for (int q = 0; q < M; ++q) y += L[ALS_W + q] * ALS_HIST(i - D - q);
+              const float y = als_safe ? als_dot<false>(L + ALS_W, L + ALS_X, i - D, M) : als_dot<true>(L + ALS_W, L + ALS_X, i - D, M);
               const float e = L[ALS_X + i] - y;
               L[ALS_OUT + k0 + j] = notch ? e : y;
             }
@@ -978,8 +1010,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             const bool mine = als_en && adaptive && (s8 < cntn);
             if (mine) {
               const int i = 128 + n;
-              float y = 0.0f;
-              for (int q = 0; q < M; ++q) y += L[ALS_W + q] * ALS_HIST(i - D - q);
+              const float y = als_safe ? als_dot<false>(L + ALS_W, L + ALS_X, i - D, M) : als_dot<true>(L + ALS_W, L + ALS_X, i - D, M);
               const float e = L[ALS_X + i] - y;
               L[ALS_OUT + n] = notch ? e : y;
               if ((n & 3) == 0) L[SCR1] = e;
@@ -989,9 +1020,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_en && adaptive && nu < ASDR_N) {
               const float e = L[SCR1];
               const int iu = 128 + nu;
-              for (int q = s8; q < M; q += 8) {
-                const float gq = e * ALS_HIST(iu - D - q);
-                L[ALS_W + q] += P.als_lambda * gq;
+              const float lam = P.als_lambda;
+              if (als_safe) {
+                for (int q = s8; q < M; q += 8) { const float gq = e * L[ALS_X + iu - D - q]; const float dq = lam * gq; L[ALS_W + q] += dq; }
+              } else {
+                for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[ALS_W + q] += dq; }
               }
             }
             WAVE_SYNC();
