@@ -125,23 +125,21 @@ __device__ __forceinline__ float approx_atan(float z) {
   const float n1 = 0.97239411f, n2 = -0.19194795f;
   return (n1 + n2 * z * z) * z;
 }
+// The reference's branch tree (quadrant by quadrant, one division per branch) evaluated branch-free with ONE division:
+// every lane performs exactly the operations of the branch it would have taken (the operands of the division are
+// selected first; -a - half_pi == -a + (-half_pi) and a - PI == a + (-PI) exactly), the other results are discarded.
 __device__ __forceinline__ float approx_atan2(float y, float x, float half_pi) {
-  if (x != 0.0f) {
-    if (fabsf(x) > fabsf(y)) {
-      float z = y / x;
-      if (x > 0.0f) return approx_atan(z);
-      else if (y >= 0.0f) return (float)((double)approx_atan(z) + PI_D);
-      else return (float)((double)approx_atan(z) - PI_D);
-    } else {
-      float z = x / y;
-      if (y > 0.0f) return -approx_atan(z) + half_pi;
-      else return -approx_atan(z) - half_pi;
-    }
-  } else {
-    if (y > 0.0f) return half_pi;
-    else if (y < 0.0f) return -half_pi;
-  }
-  return 0.0f;
+  const bool xnz = (x != 0.0f);
+  const bool big = fabsf(x) > fabsf(y);
+  const float num = big ? y : x, den = big ? x : y;
+  const float z = num / den;
+  const float a = approx_atan(z);
+  const double pis = (y >= 0.0f) ? PI_D : -PI_D;
+  const float a_pi = (float)((double)a + pis);
+  const float r_big = (x > 0.0f) ? a : a_pi;                               // |x| > |y|
+  const float r_small = -a + ((y > 0.0f) ? half_pi : -half_pi);            // |x| <= |y|, x != 0
+  const float r_x0 = (y > 0.0f) ? half_pi : ((y < 0.0f) ? -half_pi : 0.0f);   // x == 0
+  return xnz ? (big ? r_big : r_small) : r_x0;
 }
 // AudioSDR.h:434-446, n_iter = 1
 __device__ __forceinline__ float fast_sqrt1(float x) {
@@ -648,26 +646,33 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float d0 = S->pll_d0, d1 = S->pll_d1, phase_est = S->pll_phase_est, pfreq = S->pll_freq;
         bool locked = false;
 #pragma unroll 1
-        for (int i = 0; i < ASDR_N; ++i) {
-          const float x_re = L[W0 + i], x_im = L[W1 + i];
-          const float d_re = x_re * y_re + x_im * y_im;
-          const float d_im = x_im * y_re - x_re * y_im;
-          const float err = approx_atan2(d_im, d_re, K.half_pi_f);
-          d1 = d0;
-          d0 = err - K.pll_a1 * d1;
-          const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
-          phase_est = (float)((double)phase_est + (double)(filt + prev_filt) / 2.0);
-          prev_filt = filt;
-          while ((double)phase_est >= PI_D) phase_est -= two_pi;
-          while ((double)phase_est < -PI_D) phase_est += two_pi;
-          y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
-          y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
-          pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
-          locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
-          if (locked) {
-            L[W0 + i] = x_re * y_re + x_im * y_im;
-            L[W1 + i] = -x_re * y_im + x_im * y_re;
+        for (int i = 0; i < ASDR_N; i += 4) {
+          float xr[4], xi[4];
+          { const float4 r4 = *reinterpret_cast<const float4 *>(L + W0 + i), i4 = *reinterpret_cast<const float4 *>(L + W1 + i);
+            xr[0] = r4.x; xr[1] = r4.y; xr[2] = r4.z; xr[3] = r4.w; xi[0] = i4.x; xi[1] = i4.y; xi[2] = i4.z; xi[3] = i4.w; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float x_re = xr[u], x_im = xi[u];
+            const float d_re = x_re * y_re + x_im * y_im;
+            const float d_im = x_im * y_re - x_re * y_im;
+            const float err = approx_atan2(d_im, d_re, K.half_pi_f);
+            d1 = d0;
+            d0 = err - K.pll_a1 * d1;
+            const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
+            phase_est = (float)((double)phase_est + (double)(filt + prev_filt) / 2.0);
+            prev_filt = filt;
+            while ((double)phase_est >= PI_D) phase_est -= two_pi;
+            while ((double)phase_est < -PI_D) phase_est += two_pi;
+            y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
+            y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
+            pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
+            locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
+            const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
+            xr[u] = locked ? o_re : x_re;      // rotated sample while locked (:720-723), else the sample stays
+            xi[u] = locked ? o_im : x_im;
           }
+          *reinterpret_cast<float4 *>(L + W0 + i) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+          *reinterpret_cast<float4 *>(L + W1 + i) = make_float4(xi[0], xi[1], xi[2], xi[3]);
         }
         S->pll_y_re = y_re; S->pll_y_im = y_im; S->pll_prev_filt = prev_filt;
         S->pll_d0 = d0; S->pll_d1 = d1; S->pll_phase_est = phase_est; S->pll_freq = pfreq;
