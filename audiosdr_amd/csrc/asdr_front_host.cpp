@@ -20,11 +20,8 @@ int fail(const std::string &m) { return asdr_internal_fail(m); }
     if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));              \
   } while (0)
 
-bool g_tables_ok = false;
-int ensure_tables() {
-  if (g_tables_ok) return 0;
+int ensure_tables() {   // __constant__ tables are per device: (re)uploaded for the current device at every create (a few hundred bytes)
   if (asdr_front_upload_tables() != 0) return fail("front-end table upload failed");
-  g_tables_ok = true;
   return 0;
 }
 
