@@ -15,10 +15,12 @@
 
 __constant__ float c_iq_taps[64];
 __constant__ float c_tw[64][2];
+__constant__ float c_tw256[128][2];
 
 extern "C" int asdr_front_upload_tables(void) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_iq_taps), asdr_iqgen_hilbert_taps, sizeof(asdr_iqgen_hilbert_taps)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_tw), asdr_fft128_tw, sizeof(asdr_fft128_tw)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_tw256), asdr_fft256_tw, sizeof(asdr_fft256_tw)) != hipSuccess) return -1;
   return 0;
 }
 
@@ -322,5 +324,68 @@ __global__ __launch_bounds__(64) void asdr_grab_kernel(GrabArgs a) {
 
 extern "C" int asdr_launch_grab(const GrabArgs *a, void *stream) {
   hipLaunchKernelGGL(asdr_grab_kernel, dim3(a->n_channels), dim3(64), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =====================================================================================================
+// Panadapter spectrum of the grabber buffers: 4 channels per wave, 16 lanes per channel, 16 points per lane; 256-point
+// radix-2 DIT FFT in LDS with the arithmetic of ao_fft256 (oracle/asdr_front_oracle.c), then Re^2 + Im^2.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void asdr_grab_spectrum_kernel(const int16_t *out_buffer, float *power, int n_channels) {
+  __shared__ float2 X[4][256];
+  __shared__ float2 TW[128];
+  const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
+  const int ch = blockIdx.x * 4 + r;
+  const bool valid = ch < n_channels;
+  TW[lane] = make_float2(c_tw256[lane][0], c_tw256[lane][1]);
+  TW[64 + lane] = make_float2(c_tw256[64 + lane][0], c_tw256[64 + lane][1]);
+  // point n = 16*l + j (j = 0..15) -> X[bitrev8(n)]: bitrev8 = bitrev4(j) << 4 | bitrev4(l)
+  const int brl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
+  if (valid) {
+    const int4 *src = reinterpret_cast<const int4 *>(out_buffer + (size_t)ch * 512 + 32 * l);   // 16 complex int16 = 64 B
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Raw8 w; w.v = src[q];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = 4 * q + t;
+        const int brj = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);
+        X[r][(brj << 4) | brl] = make_float2((float)w.s[2 * t] * (1.0f / 32768.0f), (float)w.s[2 * t + 1] * (1.0f / 32768.0f));
+      }
+    }
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int s = 1; s <= 8; ++s) {
+    const int h = 1 << (s - 1);
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int b = l + 16 * q;
+        const int j = b & (h - 1), k = (b >> (s - 1)) << s;
+        const float2 w = TW[j << (8 - s)];
+        const float2 u = X[r][k + j], v = X[r][k + j + h];
+        const float p0 = w.x * v.x, p1 = w.y * v.y, p2 = w.x * v.y, p3 = w.y * v.x;
+        const float tr = p0 - p1, ti = p2 + p3;
+        X[r][k + j] = make_float2(u.x + tr, u.y + ti);
+        X[r][k + j + h] = make_float2(u.x - tr, u.y - ti);
+      }
+    }
+    WAVE_SYNC();
+  }
+  if (valid) {
+    float *dst = power + (size_t)ch * 256 + 16 * l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float pw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const float2 x = X[r][16 * l + 4 * q + t]; const float a = x.x * x.x, b = x.y * x.y; pw[t] = a + b; }
+      reinterpret_cast<float4 *>(dst)[q] = make_float4(pw[0], pw[1], pw[2], pw[3]);
+    }
+  }
+}
+
+extern "C" int asdr_launch_grab_spectrum(const int16_t *out_buffer, float *power, int n_channels, void *stream) {
+  hipLaunchKernelGGL(asdr_grab_spectrum_kernel, dim3((n_channels + 3) / 4), dim3(64), 0, (hipStream_t)stream, out_buffer, power, n_channels);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

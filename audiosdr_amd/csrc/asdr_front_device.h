@@ -39,6 +39,7 @@ int asdr_front_upload_tables(void);
 int asdr_launch_pre(const PreArgs *a, void *stream);
 int asdr_launch_iqgen(const IqgenArgs *a, void *stream);
 int asdr_launch_grab(const GrabArgs *a, void *stream);
+int asdr_launch_grab_spectrum(const int16_t *out_buffer, float *power, int n_channels, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -308,6 +308,7 @@ float asdr_iqgen_last_kernel_ms(asdr_iqgen_t *g) { return g ? dev_last_ms(*g) : 
 // ============================== AudioGrabberComplex256 ==============================
 struct asdr_grab_batch : DevBase {
   int16_t *d_buffer = nullptr, *d_out = nullptr;
+  float *d_spec = nullptr;          // staging for the host-destination spectrum call
   int parity = 0;                   // _buffStart / 256: identical for every channel, updates are batch-wide
   bool valid = false;               // _dataBufferValid
   std::vector<uint8_t> new_data;    // _newDataIsAvailable per channel
@@ -335,6 +336,7 @@ void asdr_grab_destroy(asdr_grab_t *g) {
   dev_fini(*g);
   if (g->d_buffer) hipFree(g->d_buffer);
   if (g->d_out) hipFree(g->d_out);
+  if (g->d_spec) hipFree(g->d_spec);
   delete g;
 }
 int asdr_grab_n_channels(const asdr_grab_t *g) { return g ? g->n : 0; }
@@ -407,6 +409,33 @@ int asdr_grab_grab_all(asdr_grab_t *g, int16_t *destination) {
 }
 
 const int16_t *asdr_grab_device_ptr(asdr_grab_t *g) { return g ? g->d_out : nullptr; }
+
+int asdr_grab_power_spectrum_device(asdr_grab_t *g, float *dDestination, void *stream_) {
+  if (!g) return fail("null batch");
+  if (g->device == ASDR_NO_DEVICE) return fail(kNoDevice);
+  if (!dDestination) return fail("null destination");
+  if (((uintptr_t)dDestination & 15u) != 0) return fail("asdr_grab_power_spectrum_device: device pointers must be 16-byte aligned");
+  if (!g->valid) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIPCHK(hipSetDevice(g->device));
+  if (stream != g->last_stream) HIPCHK(hipStreamSynchronize(g->last_stream));   // the buffers were written on the update stream
+  if (asdr_launch_grab_spectrum(g->d_out, dDestination, g->n, stream) != 0) return fail("spectrum kernel launch failed");
+  return 1;
+}
+
+int asdr_grab_power_spectrum(asdr_grab_t *g, float *destination) {
+  if (!g) return fail("null batch");
+  if (g->device == ASDR_NO_DEVICE) return fail(kNoDevice);
+  if (!destination) return fail("null destination");
+  if (!g->valid) return 0;
+  HIPCHK(hipSetDevice(g->device));
+  const size_t bytes = (size_t)g->n * 256 * sizeof(float);
+  if (!g->d_spec) HIPCHK(hipMalloc(&g->d_spec, bytes));
+  if (asdr_grab_power_spectrum_device(g, g->d_spec, g->stream) != 1) return -1;
+  HIPCHK(hipMemcpyAsync(destination, g->d_spec, bytes, hipMemcpyDeviceToHost, g->stream));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  return 1;
+}
 int asdr_grab_synchronize(asdr_grab_t *g) { return g ? dev_sync(*g) : fail("null batch"); }
 
 }  // extern "C"

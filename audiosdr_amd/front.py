@@ -17,7 +17,7 @@ FRONT_EXPORTS = ["asdr_pre_create", "asdr_pre_destroy", "asdr_pre_n_channels", "
                  "asdr_iqgen_update_device", "asdr_iqgen_synchronize", "asdr_iqgen_setGainBalance", "asdr_iqgen_last_kernel_ms",
                  "asdr_grab_create", "asdr_grab_destroy", "asdr_grab_n_channels", "asdr_grab_update", "asdr_grab_update_device",
                  "asdr_grab_newDataAvailable", "asdr_grab_grab", "asdr_grab_grab_all", "asdr_grab_device_ptr",
-                 "asdr_grab_synchronize"]
+                 "asdr_grab_synchronize", "asdr_grab_power_spectrum", "asdr_grab_power_spectrum_device"]
 
 
 class PreState(C.Structure):
@@ -66,6 +66,8 @@ def _lib():
     L.asdr_grab_grab.argtypes = [vp, i, i16p]; L.asdr_grab_grab.restype = i
     L.asdr_grab_grab_all.argtypes = [vp, i16p]; L.asdr_grab_grab_all.restype = i
     L.asdr_grab_device_ptr.argtypes = [vp]; L.asdr_grab_device_ptr.restype = vp
+    L.asdr_grab_power_spectrum.argtypes = [vp, C.POINTER(C.c_float)]; L.asdr_grab_power_spectrum.restype = i
+    L.asdr_grab_power_spectrum_device.argtypes = [vp, vp, vp]; L.asdr_grab_power_spectrum_device.restype = i
     _typed = True
     return L
 
@@ -202,3 +204,11 @@ class AudioGrabberComplex256Batch(_Batch):
 
     def device_ptr(self):
         return int(self._L.asdr_grab_device_ptr(self._h) or 0)
+
+    def power_spectrum(self):
+        """(valid, float32 [n_channels][256]): |FFT256|^2 of every channel's buffer, natural bin order (panadapter)."""
+        d = np.zeros((self.n_channels, 256), dtype=np.float32)
+        return self._chk(self._L.asdr_grab_power_spectrum(self._h, d.ctypes.data_as(C.POINTER(C.c_float)))), d
+
+    def power_spectrum_device(self, dDst, stream=0):
+        return self._chk(self._L.asdr_grab_power_spectrum_device(self._h, C.c_void_p(dDst), C.c_void_p(stream)))

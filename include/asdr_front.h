@@ -97,6 +97,15 @@ int asdr_grab_grab_all(asdr_grab_t *g, int16_t *destination /* [n_channels][512]
 /* the output buffers in HBM, [n_channels][512] int16 (valid after the first complete pair), for device-side consumers */
 const int16_t *asdr_grab_device_ptr(asdr_grab_t *g);
 int asdr_grab_synchronize(asdr_grab_t *g);
+/* Panadapter: power spectrum of every channel's output buffer on the device, |FFT256((re + j*im) / 32768)|^2 in natural bin
+ * order (bins 128..255 = negative frequencies), float32 [n_channels][256].  Not a function of the reference library (its
+ * example sketches transform the grabbed samples in application code): the arithmetic is this
+ * project's radix-2 float32 FFT, stated in oracle/asdr_front_oracle.h.  Returns 1 if buffers were valid (spectra written),
+ * 0 if no complete buffer exists yet (destination untouched), < 0 on error.
+ *  _power_spectrum        : host destination, synchronous.
+ *  _power_spectrum_device : device destination (16-byte aligned), asynchronous on `stream`. */
+int asdr_grab_power_spectrum(asdr_grab_t *g, float *destination /* [n_channels][256] */);
+int asdr_grab_power_spectrum_device(asdr_grab_t *g, float *dDestination, void *stream);
 
 #ifdef __cplusplus
 }

@@ -205,6 +205,36 @@ void ao_grab_grab(ao_grab_t *g, int16_t *destination) {
   g->newDataIsAvailable = 0;
 }
 
+static unsigned bitrev8(unsigned n) {
+  unsigned r = 0;
+  for (int b = 0; b < 8; b++) r |= ((n >> b) & 1u) << (7 - b);
+  return r;
+}
+void ao_fft256(float *buf) {
+  float x[512];
+  memcpy(x, buf, sizeof x);
+  for (unsigned n = 0; n < 256; n++) { unsigned r = bitrev8(n); buf[2 * r] = x[2 * n]; buf[2 * r + 1] = x[2 * n + 1]; }
+  for (int s = 1; s <= 8; s++) {
+    const int m = 1 << s, h = m >> 1, step = 256 / m;
+    for (int k = 0; k < 256; k += m)
+      for (int j = 0; j < h; j++) {
+        const float wr = asdr_fft256_tw[j * step][0], wi = asdr_fft256_tw[j * step][1];
+        float *u = buf + 2 * (k + j), *v = buf + 2 * (k + j + h);
+        const float p0 = wr * v[0], p1 = wi * v[1], p2 = wr * v[1], p3 = wi * v[0];
+        const float tr = p0 - p1, ti = p2 + p3;
+        const float ur = u[0], ui = u[1];
+        u[0] = ur + tr; u[1] = ui + ti;
+        v[0] = ur - tr; v[1] = ui - ti;
+      }
+  }
+}
+void ao_grab_power_spectrum(const int16_t *buffer, float *power) {
+  float x[512];
+  for (int i = 0; i < 512; i++) x[i] = (float)buffer[i] * (1.0f / 32768.0f);
+  ao_fft256(x);
+  for (int k = 0; k < 256; k++) { const float a = x[2 * k] * x[2 * k], b = x[2 * k + 1] * x[2 * k + 1]; power[k] = a + b; }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 int ao_front_check_div32767(void) {
   int bad = 0;

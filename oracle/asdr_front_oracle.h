@@ -71,6 +71,13 @@ void ao_grab_update(ao_grab_t *g, const int16_t *blockI, const int16_t *blockQ);
 int ao_grab_newDataAvailable(const ao_grab_t *g);                                          /* .cpp:75-77 */
 void ao_grab_grab(ao_grab_t *g, int16_t *destination /* [512] */);                         /* .cpp:80-90 */
 
+/* Panadapter spectrum of one grabber buffer (NOT part of the reference library -- its example sketches run an FFT on the
+ * grabbed samples in application code; SURVEY.md 8(f) row 4 asks for a device-side version): x[n] = (re + j*im) / 32768
+ * (exact in float32), this project's 256-point FFT (ao_fft256: same radix-2 DIT arithmetic as ao_fft128 with
+ * asdr_fft256_tw), power[k] = Re^2 + Im^2, k = 0..255 in natural order (k >= 128 are the negative frequencies). */
+void ao_fft256(float *buf /* [512] */);
+void ao_grab_power_spectrum(const int16_t *buffer /* [512] interleaved re, im */, float *power /* [256] */);
+
 /* exhaustive: (float)((double)s / 32767.0) == (float)(Markstein reciprocal form) for all int16 s (count of mismatches) */
 int ao_front_check_div32767(void);
 

@@ -132,6 +132,8 @@ def lib():
     L.ao_grab_newDataAvailable.argtypes = [vp]; L.ao_grab_newDataAvailable.restype = i32
     L.ao_grab_grab.argtypes = [vp, i16p]
     L.ao_front_check_div32767.restype = i32
+    L.ao_fft256.argtypes = [fp]
+    L.ao_grab_power_spectrum.argtypes = [i16p, fp]
     _lib = L
     return L
 
@@ -334,6 +336,14 @@ def fft128(x):
     buf[0::2] = x.real.astype(np.float32); buf[1::2] = x.imag.astype(np.float32)
     lib().ao_fft128(_fp(buf))
     return buf[0::2].astype(np.complex64) + 1j * buf[1::2]
+
+
+def grab_power_spectrum(buffer):
+    """|FFT256|^2 of one grabber buffer (int16 [512], interleaved re/im), this project's float32 FFT; natural bin order."""
+    b = np.ascontiguousarray(buffer, dtype=np.int16).reshape(512)
+    out = np.empty(256, dtype=np.float32)
+    lib().ao_grab_power_spectrum(_i16p(b), _fp(out))
+    return out
 
 
 def iqgen_hilbert_taps():

@@ -329,3 +329,21 @@ def test_pre_control_plane_without_a_device(A, ao):
         g.close()
     with pytest.raises(A.AsdrError):
         A.AudioSDRpreProcessorBatch(0, device=A.NO_DEVICE)
+
+
+def test_grabber_power_spectrum_oracle_matches_float64_fft(ao):
+    """Panadapter spectrum (this project's 256-point float32 FFT on the grabber buffer / 32768) vs numpy's float64 FFT;
+    a complex tone lands in its bin, a negative-frequency tone in bin 256 - k."""
+    rng = np.random.default_rng(11)
+    b = rng.integers(-20000, 20000, 512).astype(np.int16)
+    P = ao.grab_power_spectrum(b)
+    x = (b[0::2].astype(np.float64) + 1j * b[1::2]) / 32768.0
+    R = np.abs(np.fft.fft(x)) ** 2
+    assert np.abs(P - R).max() <= 2e-6 * R.max()
+    n = np.arange(256)
+    for k in (5, 200):
+        z = 0.5 * np.exp(2j * np.pi * k * n / 256)
+        buf = np.empty(512, dtype=np.int16)
+        buf[0::2] = np.round(32767 * z.real); buf[1::2] = np.round(32767 * z.imag)
+        P = ao.grab_power_spectrum(buf)
+        assert int(np.argmax(P)) == k and P[k] > 1e4 * np.delete(P, k).max()
