@@ -294,6 +294,10 @@ __device__ __forceinline__ float als_dot(const float *w, const float *x, int top
 
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A register array that is written under a condition and read later under the same condition must still be DEFINED on every
+// path of the block-loop iteration: otherwise its value "from the previous iteration" is formally live around the whole loop
+// body and pins its registers everywhere (tools/isa_liveness.py found 32 such VGPRs).
+#define DEFINE_ALL_PATHS(arr, n) do { _Pragma("unroll") for (int z_ = 0; z_ < (n); ++z_) (arr)[z_] = 0.0f; } while (0)
 // Per-channel rows addressed as (uniform base) + (32-bit byte offset): the offset stays in ONE VGPR and the access uses
 // the scalar-base addressing mode, instead of a 64-bit pointer in two VGPRs per array.  Valid because every state array is
 // smaller than 4 GiB (1,048,577 rows of at most 1.5 KiB).
@@ -416,7 +420,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
     // in HBM holds them; output = mask x oldest (2 blocks late).
     if (nb_wave) {
-      uint32_t mkc[5];
+      uint32_t mkc[5] = {0u, 0u, 0u, 0u, 0u};   // defined on every path (see DEFINE_ALL_PATHS below)
       if (nb_en) {
         const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + k0), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + k0);
         const double gmi = (double)S->nb_gain[ns_mid][0], gmq = (double)S->nb_gain[ns_mid][1];
@@ -539,6 +543,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const bool nb_slow = __any(!nb_quiet);
 #endif
       float mk[16];
+      DEFINE_ALL_PATHS(mk, 16);
       if (nb_slow) {
       if (nb_en) {
         // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
@@ -571,6 +576,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       float ev[17];
+      DEFINE_ALL_PATHS(ev, 17);
       if (nb_en) {   // trailing-edge ramp (:637-644; only the first branch is reachable).  An edge at i
                      // writes mask[i-7..i-1] only, which later iterations never read: read all, then write.
 #pragma unroll
@@ -737,6 +743,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
     if (__any(is_ssb)) {
       float qn[16];
+      DEFINE_ALL_PATHS(qn, 16);
       if (is_ssb) { load8(L + W1 + k0, qn); load8(L + W1 + k0 + 8, qn + 8); }   // own mixed Q samples, written above
       WAVE_SYNC();   // every lane has consumed W0/W1/PH: the history may now overlay them
       if (is_ssb) {
