@@ -19,6 +19,7 @@
 // in binary64 here too, so the int16 output is bit-identical to the CPU restatement.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "asdr_device.h"
 #include "asdr_tables.h"
@@ -78,11 +79,21 @@ typedef float v2f __attribute__((ext_vector_type(2)));   // one aligned VGPR pai
 __constant__ float c_bq_pool[ASDR_N_BQ_TABLES][ASDR_BQ_COEFS];
 __constant__ float c_hilbert[ASDR_HILBERT_TAPS];
 __constant__ float c_sine[ASDR_SINE_TABLE_LEN];
+__constant__ float c_mask_val[8];       // blanker mask: code -> value
+__constant__ uint8_t c_mask_code[64];  // blanker mask: bits 20..25 of the value -> code
 
 extern "C" int asdr_kernels_upload_tables(void) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_bq_pool), asdr_bq_pool, sizeof(asdr_bq_pool)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_hilbert), asdr_hilbert_taps, sizeof(asdr_hilbert_taps)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_sine), asdr_sine_table, sizeof(asdr_sine_table)) != hipSuccess) return -1;
+  {   // blanker mask codes (AudioSDR.cpp:608, 623, 630: the mask only ever holds these seven values)
+    const float val[8] = {0.0f, 1.0f, (float)0.933, (float)0.750, (float)0.500, (float)0.250, (float)0.067, 1.0f};
+    uint8_t code[64];
+    for (int i = 0; i < 64; i++) code[i] = 1;
+    for (int c = 0; c < 7; c++) { uint32_t b; memcpy(&b, &val[c], 4); code[(b >> 20) & 0x3F] = (uint8_t)c; }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mask_val), val, sizeof val) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mask_code), code, sizeof code) != hipSuccess) return -1;
+  }
   return 0;
 }
 
@@ -249,17 +260,15 @@ __device__ __forceinline__ void scale8(const int16_t *s, double g, float *out) {
   }
 }
 // The blanker mask only ever holds {0, 1, .933, .750, .500, .250, .067} (AudioSDR.cpp:608, 623, 630): one byte each in HBM.
-__device__ __forceinline__ float mask_decode(uint32_t c) {
-  float v = (c == 0u) ? 0.0f : 1.0f;
-  v = (c == 2u) ? (float)0.933 : v; v = (c == 3u) ? (float)0.750 : v; v = (c == 4u) ? (float)0.500 : v;
-  v = (c == 5u) ? (float)0.250 : v; v = (c == 6u) ? (float)0.067 : v;
-  return v;
-}
+// Both directions go through small tables in constant memory (gathers through L1): the blanker's general path is rare, and
+// select chains on seven float literals made the compiler keep ~30 literals in VGPRs for the whole kernel.
+// Code -> value: c_mask_val[code].  Value -> code: bits 20..25 of the float are distinct for the seven values
+// (0.0: 0x00, 0.067: 0x18, 0.25: 0x28, 0.5: 0x30, 0.75: 0x34, 0.933: 0x36, 1.0: 0x38); any other value maps to code 1 like
+// the select chain did.
+__device__ __forceinline__ float mask_decode(uint32_t c) { return c_mask_val[c & 7u]; }
 __device__ __forceinline__ uint32_t mask_encode(float v) {
-  uint32_t c = (v == 0.0f) ? 0u : 1u;
-  c = (v == (float)0.933) ? 2u : c; c = (v == (float)0.750) ? 3u : c; c = (v == (float)0.500) ? 4u : c;
-  c = (v == (float)0.250) ? 5u : c; c = (v == (float)0.067) ? 6u : c;
-  return c;
+  const uint32_t code = c_mask_code[(__float_as_uint(v) >> 20) & 0x3Fu];
+  return (c_mask_val[code] == v) ? code : 1u;   // exact match only (any other non-zero value is code 1)
 }
 
 // ALS FIR (AudioSDR.cpp:331-335): y = sum_{q < M} w[q] * x[top - q], q ascending, every product and sum separately rounded.
