@@ -70,7 +70,7 @@ typedef struct {
   uint32_t agc_hang_counter;
   float pll_y_re, pll_y_im, pll_prev_filt;      /* AudioSDR.cpp:690-692 statics */
   float pll_d0, pll_d1, pll_phase_est, pll_freq; /* delay0, delay1, phase_est, _PLLfreq */
-  uint32_t nb_slot, hil_slot;         /* ring positions (oldest slot) */
+  uint32_t nb_slot_unused, hil_slot;  /* hil_slot: Hilbert ring parity (the blanker ring position is batch-wide: UpdateArgs.nb_phase) */
   uint32_t status;                    /* ASDR_S_* bits */
   float nb_gain[3][2];                /* input gains {I,Q} in force when each noise-blanker ring slot was written */
   uint32_t pad_[9];
@@ -116,6 +116,7 @@ typedef struct {
   const int16_t *in_i, *in_q;
   int16_t *out;
   int32_t n_blocks;       /* blocks per channel processed by this call */
+  uint32_t nb_phase;      /* blocks processed by the batch so far, mod 3: oldest slot of every channel's blanker ring */
   int32_t in_stride;      /* row stride of I and Q in blocks (>= n_blocks; == n_blocks for the packed layout) */
   int32_t out_stride;     /* row stride of out in blocks (a capture row holds many calls' worth) */
   float *taps;            /* NULL or [ASDR_N_TAPS][n_channels][128] */

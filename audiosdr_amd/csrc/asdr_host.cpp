@@ -133,6 +133,7 @@ struct asdr_batch {
   std::vector<hipEvent_t> tev;   // optional per-launch event pairs (asdr_kernel_timing_begin)
   size_t tev_used = 0;
   hipStream_t last_stream = nullptr;
+  uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
   ChainConsts k{};
 };
 
@@ -262,6 +263,7 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
   a.als_x = b->d_als_x; a.als_w = b->d_als_w; a.agc_tab = b->d_agc_tab;
   a.sched = b->d_sched; a.n_sched = ((b->n + 7) / 8) * 8; a.n_channels = b->n;
   a.taps = b->taps_on ? b->d_taps : nullptr;
+  a.nb_phase = b->nb_phase;
   a.k = b->k;
 }
 
@@ -412,6 +414,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   HIPCHK(hipEventRecord(e1, stream));
   b->ev_valid = (e0 == b->ev0);
   b->last_stream = stream;
+  b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
   return 0;
 }
 

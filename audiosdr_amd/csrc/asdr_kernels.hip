@@ -37,12 +37,12 @@
 #endif
 #define SCR0 387   // SAM lock flag (last, unused word of the AGC table row; never live together)
 // noise-blanker overlay (dead before the rows above are written)
-#define NB_MAG 0   // envelope of detection indices 78..255: mag[0..177]; later overlaid by the mask
-#define NB_MSK 0   // mask[0..265(..271)]
-#define NB_B 178   // [178,356): beta*mag[t] from the envelope pass, overwritten in place by avg[t] (the running average BEFORE
-                   // sample t) by the sequential pass; dead once the detection flags are in registers
-#define NB_CB 272  // 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count after
-                   // detection index t (0..177), CB[202..222] = final count  (written after NB_B is dead)
+#define NB_B 2     // [2,180): beta*mag[t] of detection indices 78..255 (t = 0..177) from the envelope pass, overwritten in place by
+                   // avg[t] (the running average BEFORE sample t) by the sequential pass; dead once the detection flags are in
+                   // registers.  (Offset 2: t = 50 + k0 and t = k0 - 78 + 2 fall on 16-byte slots; words 0, 1 are padding.)
+#define NB_MSK 0   // general path only: mask[0..265(..271)], overlays the dead B row
+#define NB_CB 272  // general path only: 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count
+                   // after detection index t (0..177), CB[202..222] = final count (overlays the PH row: phases are recomputed)
 // AGC overlay
 #define AGC_GV 128   // per sample: the envelope value whose compressor gain applies (-1 = gain carried in)
 #define AGC_TAB 256  // this channel's gain table (row of 132 floats)
@@ -97,6 +97,12 @@ extern "C" int asdr_kernels_upload_tables(void) {
   return 0;
 }
 
+// keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
+#ifdef ASDR_NO_FENCE
+#define SCHED_FENCE() do { } while (0)
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // ---- scalar helpers (AudioSDR.h:358-446) ------------------------------------------------------------
 // Correctly rounded binary64 quotient x / c for a constant c with r = RN(1/c) (Markstein): q0 = RN(x*r),
 // rem = x - c*q0 exactly (fma), q = RN(q0 + rem*r) == RN(x/c).  Replaces the ~30-instruction IEEE f64 division
@@ -256,7 +262,7 @@ __device__ __forceinline__ void scale8(const int16_t *s, double g, float *out) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     out[j] = (float)(div_by_const((double)s[j], 32767.0, 1.0 / 32767.0) * g);
-    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    if ((j & 1) == 1) SCHED_FENCE();
   }
 }
 // The blanker mask only ever holds {0, 1, .933, .750, .500, .250, .067} (AudioSDR.cpp:608, 623, 630): one byte each in HBM.
@@ -302,7 +308,6 @@ __device__ __forceinline__ float als_dot(const float *w, const float *x, int top
 }
 
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
-#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // A register array that is written under a condition and read later under the same condition must still be DEFINED on every
 // path of the block-loop iteration: otherwise its value "from the previous iteration" is formally live around the whole loop
 // body and pins its registers everywhere (tools/isa_liveness.py found 32 such VGPRs).
@@ -379,7 +384,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                                   store8(tap_base + (size_t)(id) * tap_stride + 8 * h_, tv_); } } } while (0)
 
     uint32_t status = S->status;
-    const uint32_t ns = S->nb_slot % 3u, hs = S->hil_slot & 1u;   // oldest NB ring slot (of 3), Hilbert ring parity
+    // Ring positions.  The blanker ring advances once per processed block for EVERY channel (a batch-wide block counter):
+    // enabling the blanker or changing its threshold resets all three slots (AudioSDR.cpp:653-682), so a channel whose
+    // blanker was off meanwhile never sees a stale position -- and no load has to wait for a per-channel slot word.
+    const uint32_t ns = (a.nb_phase + (uint32_t)blk) % 3u, hs = S->hil_slot & 1u;   // oldest NB ring slot (of 3), Hilbert ring parity
     const uint32_t ns_mid = (ns + 1u) % 3u, ns_new = (ns + 2u) % 3u;
     float carrier_now = 0.0f;   // set by the envelope path when it runs in this block
     bool carrier_fresh = false;
@@ -389,23 +397,46 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int16_t *hist = row_ptr(a.nb_hist, (uint32_t)ch * 1536u);  // 3 slots x {I,Q} x 128 raw int16 samples
     uint32_t *mrow = reinterpret_cast<uint32_t *>(row_ptr(a.nb_mask, (uint32_t)ch * ASDR_NB_MASK_ROW + 20u * (uint32_t)s8));   // this lane's 20 mask codes
 
-    // ---- load + input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
-    // With a blanker in the wave, the blanker's delay line is kept as RAW int16 samples plus the gains that were in
-    // force when each block arrived: the scaled float is an exact function of (sample, gain), so re-scaling on
-    // read reproduces the reference's stored floats bit for bit at a quarter of the HBM traffic.
+    // ---- every load of the blanker is issued here, together with the input (no dependent address) ----------
     union Raw8 { int4 v; int16_t s[8]; };
-    Raw8 ri[2], rq[2];
+    Raw8 ri[2], rq[2], roi[2], roq[2], rmi[2], rmq[2];
     ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
+    roi[0].v = roi[1].v = roq[0].v = roq[1].v = rmi[0].v = rmi[1].v = rmq[0].v = rmq[1].v = make_int4(0, 0, 0, 0);
+    uint32_t mkc[5] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};   // defined on every path
     if (valid) {
       const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
       const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
       ri[0].v = pi[0]; ri[1].v = pi[1]; rq[0].v = pq[0]; rq[1].v = pq[1];
     }
     const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
+    float g_oi = gain_i, g_oq = gain_q, g_mi = 0.0f, g_mq = 0.0f, nb_avg0 = 0.0f;
+    if (nb_wave && nb_en) {
+      const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + k0), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + k0);
+      roi[0].v = old4[0]; roi[1].v = old4[1]; roq[0].v = old4[16]; roq[1].v = old4[17];   // Q row starts 128 samples = 16 int4 later
+      rmi[0].v = mid4[0]; rmi[1].v = mid4[1]; rmq[0].v = mid4[16]; rmq[1].v = mid4[17];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) mkc[r] = mrow[r];   // codes of the carried mask[128..265]
+      g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
+      nb_avg0 = S->nb_avg;
+    }
+    // mixer phase and increment (AudioSDR.h:508-512) of the modes whose mixer does not depend on this block's data
+    const bool mix_early = is_ssb || is_am;
+    float mphase = 0.0f, minc = 0.0f;
+    if (mix_early) {
+      mphase = is_ssb ? S->phase_ssb : S->phase_am;
+      const float fs = is_ssb ? -P.freq_shift : -K.if_center;
+      minc = fs * K.phase_inc_unit;
+    }
+    bool ph_ready = false;   // this channel's phase sequence is in its PH row
+
+    // ---- input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
+    // With a blanker in the wave, the blanker's delay line is kept as RAW int16 samples plus the gains that were in
+    // force when each block arrived: the scaled float is an exact function of (sample, gain), so re-scaling on
+    // read reproduces the reference's stored floats bit for bit at a quarter of the HBM traffic.
     if (nb_wave) {
       if (nb_en) {   // newest block -> third ring slot, with its gains
         int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + k0);
-        ni[0] = ri[0].v; ni[1] = ri[1].v; ni[16] = rq[0].v; ni[17] = rq[1].v;   // Q row starts 128 samples = 16 int4 later
+        ni[0] = ri[0].v; ni[1] = ri[1].v; ni[16] = rq[0].v; ni[17] = rq[1].v;
         if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
       }
       if (tap_on) {
@@ -429,212 +460,222 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
     // in HBM holds them; output = mask x oldest (2 blocks late).
     if (nb_wave) {
-      uint32_t mkc[5] = {0u, 0u, 0u, 0u, 0u};   // defined on every path (see DEFINE_ALL_PATHS below)
-      if (nb_en) {
-        const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + k0), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + k0);
-        const double gmi = (double)S->nb_gain[ns_mid][0], gmq = (double)S->nb_gain[ns_mid][1];
-        const double goi = (double)S->nb_gain[ns][0], goq = (double)S->nb_gain[ns][1];
-        // mask codes of the carried mask[128..265] requested now, consumed after the sequential pass
+      // This lane's 16 samples of the OLDEST block, scaled once: they are the blanker's output (before masking) and, for
+      // samples 78..127, part of the re-scanned envelope (:627).  Blanker-off channels pass their own input.
+      float vio[16], vqo[16], mgm[16], mgt[16];
+      if (!nb_en) {
 #pragma unroll
-        for (int r = 0; r < 5; ++r) mkc[r] = mrow[r];
-        // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628)
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          Raw8 wi, wq;
-          float vi[8], vq[8];
-          wi.v = mid4[h]; wq.v = mid4[16 + h];
-          scale8(wi.s, gmi, vi); scale8(wq.s, gmq, vq);
+        for (int h = 0; h < 2; ++h) { roi[h].v = ri[h].v; roq[h].v = rq[h].v; }
+      }
+      // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628): t = 50 + k of the middle
+      // block on every lane, t = k - 78 of the oldest block on the lanes that own k >= 78.  beta * envelope goes to the B row
+      // (index NB_B + t) for the sequential pass; the envelopes themselves stay in registers for the threshold test.
+      const bool own_tail = (k0 >= 64);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float vim[8], vqm[8], bm8[8];
+        scale8(roi[h].s, (double)g_oi, vio + 8 * h); scale8(roq[h].s, (double)g_oq, vqo + 8 * h);
+        scale8(rmi[h].s, (double)g_mi, vim); scale8(rmq[h].s, (double)g_mq, vqm);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          mgm[8 * h + j] = fast_sqrt1(vim[j] * vim[j] + vqm[j] * vqm[j]); bm8[j] = K.nb_beta * mgm[8 * h + j];
+          if ((j & 3) == 3) SCHED_FENCE();
+        }
+        if (nb_en) store8(L + NB_B + 50 + k0 + 8 * h, bm8);
+        if (own_tail) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float mg = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]);
-            L[NB_MAG + 50 + k0 + 8 * h + j] = mg; L[NB_B + 50 + k0 + 8 * h + j] = K.nb_beta * mg;
+            mgt[8 * h + j] = fast_sqrt1(vio[8 * h + j] * vio[8 * h + j] + vqo[8 * h + j] * vqo[8 * h + j]); bm8[j] = K.nb_beta * mgt[8 * h + j];
             if ((j & 3) == 3) SCHED_FENCE();
           }
-          if (k0 + 8 * h + 7 >= 78) {   // only samples 78..127 of the oldest block are re-scanned
-            wi.v = old4[h]; wq.v = old4[16 + h];
-            scale8(wi.s, goi, vi); scale8(wq.s, goq, vq);
+          // index NB_B + k - 78 = k0 + 8h + j - 76: the two words below NB_B take the (unused) values of k = 76, 77
+          if (nb_en && k0 + 8 * h >= 72) { if (k0 + 8 * h >= 76) store8(L + k0 + 8 * h - 76, bm8); else *reinterpret_cast<float4 *>(L + k0 + 8 * h - 72) = make_float4(bm8[4], bm8[5], bm8[6], bm8[7]); }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int k = k0 + 8 * h + j;
-              if (k >= 78) { const float mg = fast_sqrt1(vi[j] * vi[j] + vq[j] * vq[j]); L[NB_MAG + k - 78] = mg; L[NB_B + k - 78] = K.nb_beta * mg; }
-              if ((j & 3) == 3) SCHED_FENCE();
-            }
-          }
+          for (int j = 0; j < 8; ++j) mgt[8 * h + j] = 0.0f;
         }
       }
       WAVE_SYNC();
       TL(2);
-      if (nb_en && lead) {   // sequential: ONLY the running average (:633-634), which does not depend on the detections:
-                             // avg = alpha*avg + beta*mag, beta*mag staged by the envelope pass; avg[t] replaces it in place
-        float avg = S->nb_avg;
+      // sequential, one lane per channel: the running average (:633-634), which does not depend on the detections:
+      // avg = alpha*avg + beta*mag; avg[t] (the average BEFORE sample t) replaces beta*mag[t] in place.  The mixer's phase
+      // recurrence (AudioSDR.h:513-518) is an independent dependent chain and rides in the same loop.
+      if (lead) {
+        float avg = nb_avg0, phase = mphase;
+        // `if (t > twoPI) t -= twoPI; else if (t < 0) t += twoPI;` (.h:514-517) with one test per sample: the phase stays in
+        // [0, twoPI], so for inc >= 0 only the first branch can fire and for inc < 0 only the second.  The test is written as
+        // (t with its sign flipped for inc < 0) > (twoPI or 0), and t - twoPI == t + (-twoPI) exactly.
+        const bool up = !(minc < 0.0f);
+        const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
+        const uint32_t flip = up ? 0u : 0x80000000u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const float bmu = L[NB_B + u]; L[NB_B + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
+        float bm[8];
+        load8(L + NB_B + 2, bm);
 #pragma unroll 1
-        for (int t = 0; t < 176; t += 8) {
-          float bm[8], av[8];
-          load8(L + NB_B + t, bm);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u]; }
-          store8(L + NB_B + t, av);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const float bmu = L[NB_B + 176 + u]; L[NB_B + 176 + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
-        S->nb_avg = avg;
-        S->nb_slot = ns_mid;
-      }
-      WAVE_SYNC();
-      // parallel: threshold test mag[t] > avg[t]*threshold (:628) for t = 24*s8 .. 24*s8+23 (lane 7: 168..177), running
-      // counts by a lane-local prefix plus an 8-lane scan
-      uint32_t det_w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-      uint32_t det_total = 0u;
-      if (nb_en) {
-        const float thr = P.nb_threshold;
-        uint32_t cnt = 0u;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          float m[8], av[8];
-          if (s8 < 7 || q == 0) { load8(L + NB_MAG + 24 * s8 + 8 * q, m); load8(L + NB_B + 24 * s8 + 8 * q, av); }
-          else if (q == 1) {   // lane 7: t = 176, 177 only (the rows end at 178 + 178)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { m[u] = 0.0f; av[u] = 0.0f; }
-            m[0] = L[NB_MAG + 176]; m[1] = L[NB_MAG + 177]; av[0] = L[NB_B + 176]; av[1] = L[NB_B + 177];
-          } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { m[u] = 0.0f; av[u] = 0.0f; }
-          }
+        for (int c = 0; c < 16; ++c) {   // both chains in ONE basic block: the scheduler interleaves them
+          float av[8], bn[8], pv[8];
+          load8(L + NB_B + 2 + 8 * (c + 1), bn);   // next chunk, a step ahead
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const bool live = (s8 < 7) || (8 * q + u < 10);
-            cnt += (live && (m[u] > av[u] * thr)) ? 1u : 0u;
-            det_w[2 * q + (u >> 2)] |= cnt << (8 * (u & 3));   // lane-local running count (<= 24) in byte u of its word
+            av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u];
+            pv[u] = phase;
+            const float t = phase + minc, tw = t + wrapv;
+            phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+          }
+          store8(L + PH + 8 * c, pv);
+          store8(L + NB_B + 2 + 8 * c, av);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bm[u] = bn[u];
+        }
+#pragma unroll 1
+        for (int c = 16; c < 22; ++c) {
+          float av[8], bn[8];
+          load8(L + NB_B + 2 + 8 * ((c < 21) ? c + 1 : c), bn);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u]; }
+          store8(L + NB_B + 2 + 8 * c, av);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bm[u] = bn[u];
+        }
+        if (nb_en) S->nb_avg = avg;
+        if (mix_early) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
+      }
+      ph_ready = mix_early;
+      WAVE_SYNC();
+      // parallel: threshold test mag[t] > avg[t]*threshold (:628) on the lanes that hold the envelopes
+      uint32_t fm = 0u, ft = 0u;   // detection flags: bit j <-> this lane's sample k0 + j of the middle / of the oldest block
+      if (nb_en) {
+        const float thr = P.nb_threshold;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float av[8];
+          load8(L + NB_B + 50 + k0 + 8 * h, av);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fm |= (mgm[8 * h + j] > av[j] * thr) ? (1u << (8 * h + j)) : 0u;
+          if (own_tail && k0 + 8 * h >= 72) {
+            if (k0 + 8 * h >= 76) load8(L + k0 + 8 * h - 76, av);
+            else { const float4 t4 = *reinterpret_cast<const float4 *>(L + k0 + 8 * h - 72); av[0] = av[1] = av[2] = av[3] = 0.0f; av[4] = t4.x; av[5] = t4.y; av[6] = t4.z; av[7] = t4.w; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ft |= ((k0 + 8 * h + j >= 78) && (mgt[8 * h + j] > av[j] * thr)) ? (1u << (8 * h + j)) : 0u;
           }
         }
-        // exclusive scan of the lane totals over the channel's 8 lanes (DPP row_shr inside the 16-lane row, masked by s8)
-        uint32_t inc = cnt;
-        { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); inc += (s8 >= 1) ? t1 : 0u; }
-        { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); inc += (s8 >= 2) ? t2 : 0u; }
-        { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true); inc += (s8 >= 4) ? t4 : 0u; }
-        const uint32_t base4 = (inc - cnt) * 0x01010101u;   // every byte stays <= 178: no carry between the bytes
-        det_total = inc;   // valid on lane 7: the block's detection count
-#pragma unroll
-        for (int w = 0; w < 6; ++w) det_w[w] += base4;
       }
-      WAVE_SYNC();   // every lane has read its mag / avg: the counts may overwrite NB_B
-      if (nb_en) {
-        if (s8 < 7) {
-#pragma unroll
-          for (int w = 0; w < 6; w += 2) *reinterpret_cast<uint2 *>(Li + NB_CB + 6 + 6 * s8 + w) = make_uint2(det_w[w], det_w[w + 1]);   // bytes 24+24*s8 ..
-        } else {
-          const uint32_t fin = (det_total & 0xFFu) * 0x01010101u;
-          *reinterpret_cast<uint2 *>(Li + NB_CB + 48) = make_uint2(det_w[0], det_w[1]);                // bytes 192..199: t = 168..175
-          Li[NB_CB + 50] = (det_w[2] & 0xFFFFu) | (fin & 0xFFFF0000u);                                 // bytes 200..203: t = 176, 177, final, final
-#pragma unroll
-          for (int z = 51; z < 56; ++z) Li[NB_CB + z] = fin;                                           // bytes 204..223
-        }
-        if (lead) {
-#pragma unroll
-          for (int z = 0; z < 6; ++z) Li[NB_CB + z] = 0;                                               // bytes 0..23
-        }
-      }
-      WAVE_SYNC();
       TL(3);
       // Quiet fast path (wave-uniform): if no channel of the wave has a detection in this block and every carried mask
       // entry is 1.0, the mask stays all ones -- no zeroing, no trailing ramp, the carried row is unchanged and the output is
-      // the oldest block times 1.0 (x * 1.0f == x for every float) -- so decode / zero / ramp / encode / multiply are skipped.
-      bool nb_quiet = true;
-      if (nb_en) {
-        nb_quiet = (Li[NB_CB + 55] == 0);                       // final detection count of the block (replicated bytes)
-        if (lead) status = (status & ~ASDR_S_NB_DETECTED) | (nb_quiet ? 0u : ASDR_S_NB_DETECTED);
+      // the oldest block times 1.0 (x * 1.0f == x for every float) -- so counts / decode / zero / ramp / encode / multiply are skipped.
+      const unsigned long long det_bal = __ballot((fm | ft) != 0u);
+      const bool ch_det = ((uint32_t)(det_bal >> (8 * c8)) & 0xFFu) != 0u;   // some lane of this channel saw a detection
+      bool nb_quiet = !ch_det;
+      if (nb_en && lead) status = (status & ~ASDR_S_NB_DETECTED) | (ch_det ? ASDR_S_NB_DETECTED : 0u);
 #pragma unroll
-        for (int r = 0; r < 5; ++r) nb_quiet = nb_quiet && (mkc[r] == 0x01010101u);
-      }
+      for (int r = 0; r < 5; ++r) nb_quiet = nb_quiet && (mkc[r] == 0x01010101u);
 #ifdef ASDR_NB_ALWAYS_SLOW
       const bool nb_slow = true;
 #else
       const bool nb_slow = __any(!nb_quiet);
 #endif
-      float mk[16];
-      DEFINE_ALL_PATHS(mk, 16);
       if (nb_slow) {
-      if (nb_en) {
-        // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
-        // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
-        // lane s8 decodes mask entries 20*s8 .. 20*s8+19 (entries >= 138 are padding)
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const int e = 20 * s8 + 4 * r;
-          if (e < ASDR_NB_MASK_USED + 2)
-            *reinterpret_cast<float4 *>(L + NB_MSK + e) = make_float4(mask_decode(mkc[r] & 0xFFu), mask_decode((mkc[r] >> 8) & 0xFFu),
-                                                                       mask_decode((mkc[r] >> 16) & 0xFFu), mask_decode(mkc[r] >> 24));
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;
-      }
-      WAVE_SYNC();
-      if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are 0.0, so order-free:
-                     // mask[m] is hit iff a detection index lies in [m-10, m+10] iff CB[m-44] - CB[m-65] > 0
-        const uint8_t *cb = reinterpret_cast<const uint8_t *>(Li + NB_CB);
-        const int m0 = 68 + s8 * 25;
-#pragma unroll
-        for (int g5 = 0; g5 < 25; g5 += 5) {
-          int hi[5], lo[5];
-#pragma unroll
-          for (int r = 0; r < 5; ++r) { hi[r] = cb[m0 - 44 + g5 + r]; lo[r] = cb[m0 - 65 + g5 + r]; }
-#pragma unroll
-          for (int r = 0; r < 5; ++r) if (m0 + g5 + r <= 265 && hi[r] - lo[r] > 0) L[NB_MSK + m0 + g5 + r] = 0.0f;
-          SCHED_FENCE();
-        }
-      }
-      WAVE_SYNC();
-      float ev[17];
-      DEFINE_ALL_PATHS(ev, 17);
-      if (nb_en) {   // trailing-edge ramp (:637-644; only the first branch is reachable).  An edge at i
-                     // writes mask[i-7..i-1] only, which later iterations never read: read all, then write.
-#pragma unroll
-        for (int j = 0; j < 17; ++j) ev[j] = L[NB_MSK + 127 + k0 + j];
-      }
-      WAVE_SYNC();
-      if (nb_en) {
-        const float trans_dn[7] = {(float)0.933, (float)0.750, (float)0.500, (float)0.250, (float)0.067, 0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (ev[j + 1] == 1.0f && ev[j] == 0.0f) {
-            const int i = 128 + k0 + j;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) L[NB_MSK + i - 7 + q] = trans_dn[q];
-          }
-        }
-      }
-      WAVE_SYNC();
-      {   // read this lane's mask values and carry mask[128..265(..271)] to the next call, before the rows are reused
-        load8(L + NB_MSK + k0, mk); load8(L + NB_MSK + k0 + 8, mk + 8);
+        float mk[16];
+        DEFINE_ALL_PATHS(mk, 16);
+        ph_ready = false;          // the count bytes below overlay the PH row: the phase sequence is recomputed after the blanker
+        WAVE_SYNC();               // every lane has read its averages: the B row is dead
         if (nb_en) {
+          // running detection counts as bytes: CB[0..23] = 0, CB[24 + t] = detections up to and including index t (t = 0..177),
+          // CB[202..223] = the block's total.  Order of t: oldest-block samples 78..127 (lanes 4..7), then the middle block.
+          const uint32_t cnt_t = (uint32_t)__builtin_popcount(ft), cnt_m = (uint32_t)__builtin_popcount(fm);
+          uint32_t inc_t = cnt_t, inc_m = cnt_m;   // inclusive scans over the channel's 8 lanes (DPP row_shr inside the 16-lane row, masked by s8)
+          { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_t, 0x111, 0xF, 0xF, true); inc_t += (s8 >= 1) ? t1 : 0u; }
+          { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_t, 0x112, 0xF, 0xF, true); inc_t += (s8 >= 2) ? t2 : 0u; }
+          { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_t, 0x114, 0xF, 0xF, true); inc_t += (s8 >= 4) ? t4 : 0u; }
+          { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_m, 0x111, 0xF, 0xF, true); inc_m += (s8 >= 1) ? t1 : 0u; }
+          { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_m, 0x112, 0xF, 0xF, true); inc_m += (s8 >= 2) ? t2 : 0u; }
+          { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_m, 0x114, 0xF, 0xF, true); inc_m += (s8 >= 4) ? t4 : 0u; }
+          const uint32_t tot_t = (uint32_t)__shfl((int)inc_t, (lane & ~7) | 7), tot_m = (uint32_t)__shfl((int)inc_m, (lane & ~7) | 7);
+          uint8_t *cbw = reinterpret_cast<uint8_t *>(Li + NB_CB);
+          uint32_t run = inc_t - cnt_t;
+          if (own_tail) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { run += (ft >> j) & 1u; if (k0 + j >= 78) cbw[24 + k0 + j - 78] = (uint8_t)run; }
+          }
+          run = tot_t + inc_m - cnt_m;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { run += (fm >> j) & 1u; cbw[24 + 50 + k0 + j] = (uint8_t)run; }
+          if (lead) {
+            const uint32_t fin = ((tot_t + tot_m) & 0xFFu) * 0x01010101u;
+#pragma unroll
+            for (int z = 0; z < 6; ++z) Li[NB_CB + z] = 0;                                               // bytes 0..23
+            cbw[202] = (uint8_t)fin; cbw[203] = (uint8_t)fin;
+#pragma unroll
+            for (int z = 51; z < 56; ++z) Li[NB_CB + z] = (int)fin;                                      // bytes 204..223
+          }
+          // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
+          // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
+          // lane s8 decodes mask entries 20*s8 .. 20*s8+19 (entries >= 138 are padding)
 #pragma unroll
           for (int r = 0; r < 5; ++r) {
-            const int e = 20 * s8 + 4 * r;   // entries >= 138 are padding: store code 1
-            const float4 mv = (e < ASDR_NB_MASK_USED + 2) ? *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-            mrow[r] = mask_encode(mv.x) | (mask_encode(mv.y) << 8) | (mask_encode(mv.z) << 16) | (mask_encode(mv.w) << 24);
+            const int e = 20 * s8 + 4 * r;
+            if (e < ASDR_NB_MASK_USED + 2)
+              *reinterpret_cast<float4 *>(L + NB_MSK + e) = make_float4(mask_decode(mkc[r] & 0xFFu), mask_decode((mkc[r] >> 8) & 0xFFu),
+                                                                         mask_decode((mkc[r] >> 16) & 0xFFu), mask_decode(mkc[r] >> 24));
           }
-        }
-      }
-      }   // nb_slow
-      WAVE_SYNC();
-      {   // output = mask x oldest block (:646-649) -> IF filter rows; blanker-off channels pass their own input (x 1.0)
-        const int4 *src4 = nb_en ? reinterpret_cast<const int4 *>(hist + ns * 256 + k0) : reinterpret_cast<const int4 *>(a.in_i + io);
-        const int4 *srq4 = nb_en ? src4 + 16 : reinterpret_cast<const int4 *>(a.in_q + io);
-        const double goi = nb_en ? (double)S->nb_gain[ns][0] : (double)gain_i, goq = nb_en ? (double)S->nb_gain[ns][1] : (double)gain_q;
-#pragma unroll   /* mk[] is a register array: h must be a compile-time index */
-        for (int h = 0; h < 2; ++h) {
-          Raw8 wi, wq;
-          float vi[8], vq[8];
-          wi.v = make_int4(0, 0, 0, 0); wq.v = wi.v;
-          if (nb_en || valid) { wi.v = src4[h]; wq.v = srq4[h]; }
-          scale8(wi.s, goi, vi); scale8(wq.s, goq, vq);
-          if (nb_slow) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float mv = nb_en ? mk[8 * h + j] : 1.0f; vi[j] = mv * vi[j]; vq[j] = mv * vq[j]; }
-          }
-          store8(L + W0 + k0 + 8 * h, vi); store8(L + W1 + k0 + 8 * h, vq);
+          for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;
         }
-      }
+        WAVE_SYNC();
+        if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are 0.0, so order-free:
+                       // mask[m] is hit iff a detection index lies in [m-10, m+10] iff CB[m-44] - CB[m-65] > 0
+          const uint8_t *cb = reinterpret_cast<const uint8_t *>(Li + NB_CB);
+          const int m0 = 68 + s8 * 25;
+#pragma unroll
+          for (int g5 = 0; g5 < 25; g5 += 5) {
+            int hi[5], lo[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) { hi[r] = cb[m0 - 44 + g5 + r]; lo[r] = cb[m0 - 65 + g5 + r]; }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) if (m0 + g5 + r <= 265 && hi[r] - lo[r] > 0) L[NB_MSK + m0 + g5 + r] = 0.0f;
+            SCHED_FENCE();
+          }
+        }
+        WAVE_SYNC();
+        float ev[17];
+        DEFINE_ALL_PATHS(ev, 17);
+        if (nb_en) {   // trailing-edge ramp (:637-644; only the first branch is reachable).  An edge at i
+                       // writes mask[i-7..i-1] only, which later iterations never read: read all, then write.
+#pragma unroll
+          for (int j = 0; j < 17; ++j) ev[j] = L[NB_MSK + 127 + k0 + j];
+        }
+        WAVE_SYNC();
+        if (nb_en) {
+          const float trans_dn[7] = {(float)0.933, (float)0.750, (float)0.500, (float)0.250, (float)0.067, 0.0f, 0.0f};
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            if (ev[j + 1] == 1.0f && ev[j] == 0.0f) {
+              const int i = 128 + k0 + j;
+#pragma unroll
+              for (int q = 0; q < 7; ++q) L[NB_MSK + i - 7 + q] = trans_dn[q];
+            }
+          }
+        }
+        WAVE_SYNC();
+        {   // read this lane's mask values and carry mask[128..265(..271)] to the next call, before the rows are reused
+          load8(L + NB_MSK + k0, mk); load8(L + NB_MSK + k0 + 8, mk + 8);
+          if (nb_en) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+              const int e = 20 * s8 + 4 * r;   // entries >= 138 are padding: store code 1
+              const float4 mv = (e < ASDR_NB_MASK_USED + 2) ? *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+              mrow[r] = mask_encode(mv.x) | (mask_encode(mv.y) << 8) | (mask_encode(mv.z) << 16) | (mask_encode(mv.w) << 24);
+            }
+          }
+        }
+        // output = mask x oldest block (:646-649)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float mv = nb_en ? mk[j] : 1.0f; vio[j] = mv * vio[j]; vqo[j] = mv * vqo[j]; }
+      }   // nb_slow
+      WAVE_SYNC();   // the B row / mask row is dead: the IF filter rows may overwrite it
+      store8(L + W0 + k0, vio); store8(L + W0 + k0 + 8, vio + 8); store8(L + W1 + k0, vqo); store8(L + W1 + k0 + 8, vqo + 8);
     }
     WAVE_SYNC();
     TL(4);
@@ -702,31 +743,48 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const bool do_mix = is_ssb || do_env;
 
     // ---- mixer phase sequence, AudioSDR.h:508-526 (phase accumulates sequentially in float) -----------------
-    if (do_mix && lead) {
-      float phase = is_ssb ? S->phase_ssb : S->phase_am;
-      const float fs = is_ssb ? -P.freq_shift : -K.if_center;
-      const float inc = fs * K.phase_inc_unit;
-      // `if (t > twoPI) t -= twoPI; else if (t < 0) t += twoPI;` (.h:514-517) with one test per sample: the phase stays in
-      // [0, twoPI], so for inc >= 0 only the first branch can fire and for inc < 0 only the second.  The test is written as
-      // (t with its sign flipped for inc < 0) > (twoPI or 0), and t - twoPI == t + (-twoPI) exactly.
-      const bool up = !(inc < 0.0f);
-      const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
-      const uint32_t flip = up ? 0u : 0x80000000u;
+    // Normally the sequence is already in the PH row (it rode in the blanker's sequential loop).  It is computed here for SAM
+    // channels that fall back to the envelope detector (their mixer runs only if the PLL ends the block unlocked, :132), when
+    // no channel of the wave runs the blanker, and after the blanker's general path (whose scratch overlays the PH row).
+    if (do_mix && !mix_early) { mphase = S->phase_am; minc = -K.if_center * K.phase_inc_unit; }
+    const bool ph_seq = do_mix && !ph_ready;
+    if (__any(ph_seq)) {
+      if (ph_seq && lead) {
+        float phase = mphase;
+        const bool up = !(minc < 0.0f);   // one wrap test per sample, see the blanker's sequential loop
+        const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
+        const uint32_t flip = up ? 0u : 0x80000000u;
 #pragma unroll 1
-      for (int i = 0; i < ASDR_N; i += 8) {
-        float pv[8];
+        for (int i = 0; i < ASDR_N; i += 8) {
+          float pv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          pv[u] = phase;
-          const float t = phase + inc, tw = t + wrapv;
-          phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+          for (int u = 0; u < 8; ++u) {
+            pv[u] = phase;
+            const float t = phase + minc, tw = t + wrapv;
+            phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+          }
+          store8(L + PH + i, pv);
         }
-        store8(L + PH + i, pv);
+        if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
       }
-      if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
+      WAVE_SYNC();
     }
-    WAVE_SYNC();
+    // Wave-uniform mixer: all 8 lanes of a channel hold the channel's carried phase and increment, so the wave can test whether
+    // EVERY channel mixes with the same pair -- true for receivers that were configured together, whose phases then stay
+    // identical for ever.  Then the 128 sin/cos pairs are evaluated once per wave (2 samples per lane, from channel 0's phase
+    // row, staged in the PH rows of channels 1 and 2) instead of 16 per lane.
+    const uint32_t ph_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mphase));
+    const uint32_t inc_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(minc));
+    const bool mix_uni = __all(do_mix && __float_as_uint(mphase) == ph_first && __float_as_uint(minc) == inc_first);
     TL(6);
+    if (ABL_ON(ABL_MIX) && mix_uni) {   // sin/cos of the wave's 128 phases, two per lane
+      const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane);
+      const float c0 = cos_f32(sine, p2.x, two_pi, K.inv_two_pi_d), s0 = sin_f32(sine, p2.x, two_pi, K.inv_two_pi_d);
+      const float c1 = cos_f32(sine, p2.y, two_pi, K.inv_two_pi_d), s1 = sin_f32(sine, p2.y, two_pi, K.inv_two_pi_d);
+      *reinterpret_cast<float2 *>(lds + STRIDE + PH + 2 * lane) = make_float2(c0, c1);
+      *reinterpret_cast<float2 *>(lds + 2 * STRIDE + PH + 2 * lane) = make_float2(s0, s1);
+      WAVE_SYNC();
+    }
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
     // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
     float *hi_ring = row_ptr(a.hil_i, (uint32_t)ch * 1024u + 4u * (uint32_t)k0);
@@ -734,14 +792,23 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ABL_ON(ABL_MIX) && do_mix) {
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
-        float ph[8], vi[8], vq[8], mi[8], mq[8];
-        load8(L + PH + k0 + 8 * h, ph); load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+        float cc[8], sn[8], vi[8], vq[8], mi[8], mq[8];
+        load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+        if (mix_uni) {
+          load8(lds + STRIDE + PH + k0 + 8 * h, cc); load8(lds + 2 * STRIDE + PH + k0 + 8 * h, sn);
+        } else {
+          float ph[8];
+          load8(L + PH + k0 + 8 * h, ph);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            cc[j] = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
+            if ((j & 1) == 1) SCHED_FENCE();
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float c = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d), sn = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
-          mi[j] = vi[j] * c - vq[j] * sn;
-          mq[j] = vq[j] * c + vi[j] * sn;
-          if ((j & 1) == 1) SCHED_FENCE();
+          mi[j] = vi[j] * cc[j] - vq[j] * sn[j];
+          mq[j] = vq[j] * cc[j] + vi[j] * sn[j];
         }
         store8(L + W0 + k0 + 8 * h, mi); store8(L + W1 + k0 + 8 * h, mq);
         if (is_ssb) store8(hi_ring + hs * 128 + 8 * h, mi);

@@ -122,6 +122,30 @@ def test_setters_between_blocks(gpu, ao):
     batch.close()
 
 
+def test_mixer_uniform_and_divergent_phases_in_one_wave(gpu, ao):
+    """The mixer computes the phase sequence and its sin/cos once per wave when all 8 channels of the wave carry the same
+    (phase, increment) and falls back to the per-channel path otherwise (AudioSDR.h:508-526).  16 channels start in two
+    different SSB modes (different phase increments), then all switch to USB: equal schedule keys put them in the same
+    waves with DIFFERENT carried phases.  A second batch keeps all 16 in USB from the start (uniform waves)."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, n_blk = 16, 7
+    I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.25, impulse_every=600)
+    for divergent in (True, False):
+        pre = [S("setDemodMode", 0, sel=lambda c: c % 2 == 0), S("setDemodMode", 1, sel=lambda c: c % 2 == 1)] if divergent else [S("setDemodMode", 1)]
+        batch, orcs = _mk(gpu, ao, n_ch, pre + [S("enableAudioFilter")], taps=True)
+        for b in range(n_blk):
+            if b == 2:
+                apply_setters(batch, orcs, [S("setDemodMode", 1)])
+            got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
+            taps = batch.read_taps()
+            for c in range(n_ch):
+                want = orcs[c].update(I[c, b], Q[c, b])
+                for t in ("MIX_I", "MIX_Q"):
+                    assert np.array_equal(f32_bits(taps[t][c]), f32_bits(orcs[c].tap(t))), "divergent=%s block %d ch %d tap %s" % (divergent, b, c, t)
+                assert np.array_equal(got[c], want), "divergent=%s block %d ch %d" % (divergent, b, c)
+        batch.close()
+
+
 def test_missing_input_guard(gpu, ao):
     """AudioSDR.cpp:48-56: a missing I or Q block -> return without processing; state does not advance."""
     import ctypes as C

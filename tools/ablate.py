@@ -42,7 +42,7 @@ def run(rounds=5, n_ch=65536):
     import audiosdr_amd as A
     from audiosdr_amd.synth import make_iq
     import torch
-    uniq = 4096
+    uniq = min(4096, n_ch)
     I, Q = make_iq(uniq, 2, fc=6290.0, A=0.25)
     I = np.tile(I, (n_ch // uniq, 1, 1)); Q = np.tile(Q, (n_ch // uniq, 1, 1))
     dI = [torch.from_numpy(np.ascontiguousarray(I[:, b])).cuda() for b in range(2)]
@@ -86,4 +86,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
     else:
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+        # ABLATE_NCH=65536,2048,8192,16384: also time smaller batches (1 wave/CU, 1 and 2 waves/SIMD) -> lone-wave latency
+        for n in [int(x) for x in os.environ.get("ABLATE_NCH", "65536").split(",")]:
+            print("== %d channels" % n)
+            run(int(sys.argv[2]) if len(sys.argv) > 2 else 5, n)

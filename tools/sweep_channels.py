@@ -7,7 +7,7 @@ import audiosdr_amd as A
 from audiosdr_amd.synth import make_iq
 import torch
 I, Q = make_iq(2048, 1, fc=6290.0, A=0.25)
-for waves_per_cu in [1, 2, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 20, 24, 32]:
+for waves_per_cu in [1, 2, 4, 6, 8, 10, 11, 12, 13, 14, 16, 18, 20, 22, 24, 25, 26, 28, 30, 32, 34, 36, 40, 48]:
     n_ch = 256 * waves_per_cu * 8
     reps = (n_ch + 2047) // 2048
     dI = torch.from_numpy(np.ascontiguousarray(np.tile(I, (reps, 1, 1))[:n_ch, 0])).cuda()
