@@ -27,6 +27,13 @@ def library_path():
     return os.path.join(_HERE, "libasdr_hip.so")
 
 
+def library_sha256(path=None):
+    """sha256 of the built library: stamps measurement files (profiles/pmc_latest.json) with the build they were taken from."""
+    import hashlib
+    with open(path or library_path(), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 # name -> (extra argtypes after (batch, ch), restype)
 _f, _i, _u = C.c_float, C.c_int, C.c_uint
 _SETTERS_VOID = ["init", "enableAudioFilter", "disableAudioFilter", "enableALSfilter", "disableALSfilter",

@@ -39,7 +39,7 @@
 // noise-blanker overlay (dead before the rows above are written)
 #define NB_B 2     // [2,180): beta*mag[t] of detection indices 78..255 (t = 0..177) from the envelope pass, overwritten in place by
                    // avg[t] (the running average BEFORE sample t) by the sequential pass; dead once the detection flags are in
-                   // registers.  (Offset 2: t = 50 + k0 and t = k0 - 78 + 2 fall on 16-byte slots; words 0, 1 are padding.)
+                   // registers.  (Offset 2: the lanes' pieces t = 50 + 8 s8 + 64h and t = 8 s8 - 14 fall on 16-byte slots; words 0, 1 are padding.)
 #define NB_MSK 0   // general path only: mask[0..265(..271)], overlays the dead B row
 #define NB_CB 272  // general path only: 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count
                    // after detection index t (0..177), CB[202..222] = final count (overlays the PH row: phases are recomputed)
@@ -97,11 +97,12 @@ extern "C" int asdr_kernels_upload_tables(void) {
   return 0;
 }
 
-// keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
-#ifdef ASDR_NO_FENCE
-#define SCHED_FENCE() do { } while (0)
-#else
+// Scheduling fences inside fully unrolled loops (they stop the scheduler from interleaving all iterations) were needed while
+// the kernel spilled; at the current register budget the unfenced schedule is 4 % faster (profiles/README.md, round 2).
+#ifdef ASDR_FENCE
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_FENCE() do { } while (0)
 #endif
 // ---- scalar helpers (AudioSDR.h:358-446) ------------------------------------------------------------
 // Correctly rounded binary64 quotient x / c for a constant c with r = RN(1/c) (Markstein): q0 = RN(x*r),
@@ -252,6 +253,11 @@ __device__ __forceinline__ void load8(const float *p, float *v) {
   const float4 a = q[0], b = q[1];
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+__device__ __forceinline__ void load4(const float *p, float *v) {
+  const float4 a = *reinterpret_cast<const float4 *>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ __forceinline__ void store4(float *p, const float *v) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void store8(float *p, const float *v) {
   float4 *q = reinterpret_cast<float4 *>(p);
   q[0] = make_float4(v[0], v[1], v[2], v[3]); q[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -364,7 +370,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
     float *L = lds + loff;
     int *Li = reinterpret_cast<int *>(L);
-    const int k0 = 16 * s8;
+    // Sample ownership.  Global rows are always touched in whole 16-byte pieces with the 8 lanes of a channel on 8 ADJACENT
+    // pieces, so that one wave-instruction reads or writes 128 contiguous bytes of each of its 8 rows (lanes on every second
+    // or fourth piece make every instruction touch every line of the rows: 2.9 instead of 7 TB/s, tools/ubench/mem_pattern.hip):
+    //   int16 rows (input, output, blanker ring): lane s8 owns samples kA + 64h + j   (h = 0, 1;  j < 8)
+    //   float rows (Hilbert rings, ALS rows):     lane s8 owns samples kF + 32m + j   (m = 0..3;  j < 4)
+    // Pointwise stages work on the kA map; the FIR stages own 16 contiguous outputs (k0) and exchange through LDS.
+    const int k0 = 16 * s8, kA = 8 * s8, kF = 4 * s8;
     const bool lead = (s8 == 0);
 #ifdef ASDR_TIMELINE
     // profiling build (tools/timeline.py): lane 0 of a few waves timestamps the phase boundaries into the taps buffer
@@ -377,11 +389,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #define TL(i) do { } while (0)
     const bool tap_on = (a.taps != nullptr) && valid && (blk == a.n_blocks - 1);
 #endif
-    float *tap_base = tap_on ? a.taps + (size_t)ch * ASDR_N + k0 : nullptr;
+    float *tap_base = tap_on ? a.taps + (size_t)ch * ASDR_N + kA : nullptr;
     const size_t tap_stride = (size_t)a.n_channels * ASDR_N;
-#define TAP8(id, h, v) do { if (tap_on) store8(tap_base + (size_t)(id) * tap_stride + 8 * (h), v); } while (0)
-#define TAP_ROW(id, rowoff) do { if (tap_on) { for (int h_ = 0; h_ < 2; ++h_) { float tv_[8]; load8(L + (rowoff) + k0 + 8 * h_, tv_); \
-                                  store8(tap_base + (size_t)(id) * tap_stride + 8 * h_, tv_); } } } while (0)
+#define TAP8(id, h, v) do { if (tap_on) store8(tap_base + (size_t)(id) * tap_stride + 64 * (h), v); } while (0)
+#define TAP4(id, m, v) do { if (tap_on) store4(tap_base - kA + kF + (size_t)(id) * tap_stride + 32 * (m), v); } while (0)
+#define TAP_ROW(id, rowoff) do { if (tap_on) { for (int h_ = 0; h_ < 2; ++h_) { float tv_[8]; load8(L + (rowoff) + kA + 64 * h_, tv_); \
+                                  store8(tap_base + (size_t)(id) * tap_stride + 64 * h_, tv_); } } } while (0)
 
     uint32_t status = S->status;
     // Ring positions.  The blanker ring advances once per processed block for EVERY channel (a batch-wide block counter):
@@ -391,11 +404,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const uint32_t ns_mid = (ns + 1u) % 3u, ns_new = (ns + 2u) % 3u;
     float carrier_now = 0.0f;   // set by the envelope path when it runs in this block
     bool carrier_fresh = false;
-    const size_t io = ((size_t)ch * a.in_stride + blk) * ASDR_N + k0;       // this lane's 16 input samples
-    const size_t io_out = ((size_t)ch * a.out_stride + blk) * ASDR_N + k0;  // ... and its 16 output samples (capture rows may be longer)
+    const size_t io = ((size_t)ch * a.in_stride + blk) * ASDR_N + kA;       // this lane's input samples: two pieces of 8
+    const size_t io_out = ((size_t)ch * a.out_stride + blk) * ASDR_N + kA;  // ... and its output samples (capture rows may be longer)
     const bool nb_wave = ABL_ON(ABL_NB) && __any(nb_en);   // wave-uniform: some channel of this wave has the blanker on
     int16_t *hist = row_ptr(a.nb_hist, (uint32_t)ch * 1536u);  // 3 slots x {I,Q} x 128 raw int16 samples
-    uint32_t *mrow = reinterpret_cast<uint32_t *>(row_ptr(a.nb_mask, (uint32_t)ch * ASDR_NB_MASK_ROW + 20u * (uint32_t)s8));   // this lane's 20 mask codes
+    uint32_t *mrow = reinterpret_cast<uint32_t *>(row_ptr(a.nb_mask, (uint32_t)ch * ASDR_NB_MASK_ROW + 4u * (uint32_t)s8));   // this lane's mask codes: dwords s8, s8 + 8, .. (entries 32r + 4 s8 ..)
 
     // ---- every load of the blanker is issued here, together with the input (no dependent address) ----------
     union Raw8 { int4 v; int16_t s[8]; };
@@ -406,16 +419,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (valid) {
       const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
       const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
-      ri[0].v = pi[0]; ri[1].v = pi[1]; rq[0].v = pq[0]; rq[1].v = pq[1];
+      ri[0].v = pi[0]; ri[1].v = pi[8]; rq[0].v = pq[0]; rq[1].v = pq[8];   // int4 #8 = 64 samples on
     }
     const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
     float g_oi = gain_i, g_oq = gain_q, g_mi = 0.0f, g_mq = 0.0f, nb_avg0 = 0.0f;
     if (nb_wave && nb_en) {
-      const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + k0), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + k0);
-      roi[0].v = old4[0]; roi[1].v = old4[1]; roq[0].v = old4[16]; roq[1].v = old4[17];   // Q row starts 128 samples = 16 int4 later
-      rmi[0].v = mid4[0]; rmi[1].v = mid4[1]; rmq[0].v = mid4[16]; rmq[1].v = mid4[17];
+      const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + kA), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + kA);
+      roi[0].v = old4[0]; roi[1].v = old4[8]; roq[0].v = old4[16]; roq[1].v = old4[24];   // Q row starts 128 samples = 16 int4 later
+      rmi[0].v = mid4[0]; rmi[1].v = mid4[8]; rmq[0].v = mid4[16]; rmq[1].v = mid4[24];
 #pragma unroll
-      for (int r = 0; r < 5; ++r) mkc[r] = mrow[r];   // codes of the carried mask[128..265]
+      for (int r = 0; r < 5; ++r) mkc[r] = mrow[8 * r];   // codes of the carried mask[128..265]
       g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
       nb_avg0 = S->nb_avg;
     }
@@ -435,8 +448,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // read reproduces the reference's stored floats bit for bit at a quarter of the HBM traffic.
     if (nb_wave) {
       if (nb_en) {   // newest block -> third ring slot, with its gains
-        int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + k0);
-        ni[0] = ri[0].v; ni[1] = ri[1].v; ni[16] = rq[0].v; ni[17] = rq[1].v;
+        int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + kA);
+        ni[0] = ri[0].v; ni[8] = ri[1].v; ni[16] = rq[0].v; ni[24] = rq[1].v;
         if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
       }
       if (tap_on) {
@@ -450,11 +463,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float xi[8], xq[8];
         scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
         TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq);
-        store8(L + W0 + k0 + 8 * h, xi); store8(L + W1 + k0 + 8 * h, xq);
+        store8(L + W0 + kA + 64 * h, xi); store8(L + W1 + kA + 64 * h, xq);
         SCHED_FENCE();
       }
     }
 
+    float4 if_s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float if_cf[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    bool if_pre = false;
     TL(1);
     // ---- impulse noise blanker, AudioSDR.cpp:606-650 ------------------------------------------------------
     // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
@@ -462,15 +478,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (nb_wave) {
       // This lane's 16 samples of the OLDEST block, scaled once: they are the blanker's output (before masking) and, for
       // samples 78..127, part of the re-scanned envelope (:627).  Blanker-off channels pass their own input.
-      float vio[16], vqo[16], mgm[16], mgt[16];
+      float vio[16], vqo[16], mgm[16], mgt[8];
       if (!nb_en) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) { roi[h].v = ri[h].v; roq[h].v = rq[h].v; }
       }
-      // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628): t = 50 + k of the middle
-      // block on every lane, t = k - 78 of the oldest block on the lanes that own k >= 78.  beta * envelope goes to the B row
-      // (index NB_B + t) for the sequential pass; the envelopes themselves stay in registers for the threshold test.
-      const bool own_tail = (k0 >= 64);
+      // envelope for detection indices i = 78..255 -> t = i - 78 (fast_sqrt_f32(I^2+Q^2, 1), :628): t = 50 + k for this lane's
+      // samples k of the middle block, t = k - 78 for its samples k >= 78 of the oldest block (the second piece, 64 + 8 s8 + j,
+      // of lanes s8 >= 1).  beta * envelope goes to the B row (index NB_B + t) for the sequential pass; the envelopes
+      // themselves stay in registers for the threshold test.
+      const bool own_tail = (s8 >= 1);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float vim[8], vqm[8], bm8[8];
@@ -481,22 +498,30 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           mgm[8 * h + j] = fast_sqrt1(vim[j] * vim[j] + vqm[j] * vqm[j]); bm8[j] = K.nb_beta * mgm[8 * h + j];
           if ((j & 3) == 3) SCHED_FENCE();
         }
-        if (nb_en) store8(L + NB_B + 50 + k0 + 8 * h, bm8);
-        if (own_tail) {
+        if (nb_en) store8(L + NB_B + 50 + kA + 64 * h, bm8);
+      }
+      if (own_tail) {
+        float bm8[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            mgt[8 * h + j] = fast_sqrt1(vio[8 * h + j] * vio[8 * h + j] + vqo[8 * h + j] * vqo[8 * h + j]); bm8[j] = K.nb_beta * mgt[8 * h + j];
-            if ((j & 3) == 3) SCHED_FENCE();
-          }
-          // index NB_B + k - 78 = k0 + 8h + j - 76: the two words below NB_B take the (unused) values of k = 76, 77
-          if (nb_en && k0 + 8 * h >= 72) { if (k0 + 8 * h >= 76) store8(L + k0 + 8 * h - 76, bm8); else *reinterpret_cast<float4 *>(L + k0 + 8 * h - 72) = make_float4(bm8[4], bm8[5], bm8[6], bm8[7]); }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) mgt[8 * h + j] = 0.0f;
+        for (int j = 0; j < 8; ++j) {
+          mgt[j] = fast_sqrt1(vio[8 + j] * vio[8 + j] + vqo[8 + j] * vqo[8 + j]); bm8[j] = K.nb_beta * mgt[j];
+          if ((j & 3) == 3) SCHED_FENCE();
         }
+        // index NB_B + k - 78 = 8 s8 + j - 12: lane 1 holds k = 72..79, of which 76, 77 land on the two padding words below NB_B
+        if (nb_en) { if (s8 >= 2) store8(L + kA - 12, bm8); else *reinterpret_cast<float4 *>(L) = make_float4(bm8[4], bm8[5], bm8[6], bm8[7]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mgt[j] = 0.0f;
       }
       WAVE_SYNC();
       TL(2);
+      if (ABL_ON(ABL_IF)) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
+        if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
+        const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
+#pragma unroll
+        for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
+        if_pre = true;
+      }
       // sequential, one lane per channel: the running average (:633-634), which does not depend on the detections:
       // avg = alpha*avg + beta*mag; avg[t] (the average BEFORE sample t) replaces beta*mag[t] in place.  The mixer's phase
       // recurrence (AudioSDR.h:513-518) is an independent dependent chain and rides in the same loop.
@@ -544,21 +569,22 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       ph_ready = mix_early;
       WAVE_SYNC();
       // parallel: threshold test mag[t] > avg[t]*threshold (:628) on the lanes that hold the envelopes
-      uint32_t fm = 0u, ft = 0u;   // detection flags: bit j <-> this lane's sample k0 + j of the middle / of the oldest block
+      uint32_t fm = 0u, ft = 0u;   // detection flags: bit 8h + j <-> this lane's sample kA + 64h + j of the middle block / bit j <-> 64 + kA + j of the oldest
       if (nb_en) {
         const float thr = P.nb_threshold;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float av[8];
-          load8(L + NB_B + 50 + k0 + 8 * h, av);
+          load8(L + NB_B + 50 + kA + 64 * h, av);
 #pragma unroll
           for (int j = 0; j < 8; ++j) fm |= (mgm[8 * h + j] > av[j] * thr) ? (1u << (8 * h + j)) : 0u;
-          if (own_tail && k0 + 8 * h >= 72) {
-            if (k0 + 8 * h >= 76) load8(L + k0 + 8 * h - 76, av);
-            else { const float4 t4 = *reinterpret_cast<const float4 *>(L + k0 + 8 * h - 72); av[0] = av[1] = av[2] = av[3] = 0.0f; av[4] = t4.x; av[5] = t4.y; av[6] = t4.z; av[7] = t4.w; }
+        }
+        if (own_tail) {
+          float av[8];
+          if (s8 >= 2) load8(L + kA - 12, av);
+          else { const float4 t4 = *reinterpret_cast<const float4 *>(L); av[0] = av[1] = av[2] = av[3] = 0.0f; av[4] = t4.x; av[5] = t4.y; av[6] = t4.z; av[7] = t4.w; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ft |= ((k0 + 8 * h + j >= 78) && (mgt[8 * h + j] > av[j] * thr)) ? (1u << (8 * h + j)) : 0u;
-          }
+          for (int j = 0; j < 8; ++j) ft |= ((64 + kA + j >= 78) && (mgt[j] > av[j] * thr)) ? (1u << j) : 0u;
         }
       }
       TL(3);
@@ -583,25 +609,30 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         WAVE_SYNC();               // every lane has read its averages: the B row is dead
         if (nb_en) {
           // running detection counts as bytes: CB[0..23] = 0, CB[24 + t] = detections up to and including index t (t = 0..177),
-          // CB[202..223] = the block's total.  Order of t: oldest-block samples 78..127 (lanes 4..7), then the middle block.
-          const uint32_t cnt_t = (uint32_t)__builtin_popcount(ft), cnt_m = (uint32_t)__builtin_popcount(fm);
-          uint32_t inc_t = cnt_t, inc_m = cnt_m;   // inclusive scans over the channel's 8 lanes (DPP row_shr inside the 16-lane row, masked by s8)
-          { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_t, 0x111, 0xF, 0xF, true); inc_t += (s8 >= 1) ? t1 : 0u; }
-          { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_t, 0x112, 0xF, 0xF, true); inc_t += (s8 >= 2) ? t2 : 0u; }
-          { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_t, 0x114, 0xF, 0xF, true); inc_t += (s8 >= 4) ? t4 : 0u; }
-          { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_m, 0x111, 0xF, 0xF, true); inc_m += (s8 >= 1) ? t1 : 0u; }
-          { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_m, 0x112, 0xF, 0xF, true); inc_m += (s8 >= 2) ? t2 : 0u; }
-          { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc_m, 0x114, 0xF, 0xF, true); inc_m += (s8 >= 4) ? t4 : 0u; }
-          const uint32_t tot_t = (uint32_t)__shfl((int)inc_t, (lane & ~7) | 7), tot_m = (uint32_t)__shfl((int)inc_m, (lane & ~7) | 7);
+          // CB[202..223] = the block's total.  Order of t: oldest-block samples 78..127 (second pieces of lanes 1..7), then the
+          // middle block's first pieces (samples 8 s8 + j of lanes 0..7), then its second pieces (64 + 8 s8 + j).
+          auto scan8 = [&](uint32_t v) {   // inclusive scan over the channel's 8 lanes (DPP row_shr inside the 16-lane row, masked by s8)
+            { const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); v += (s8 >= 1) ? t1 : 0u; }
+            { const uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); v += (s8 >= 2) ? t2 : 0u; }
+            { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); v += (s8 >= 4) ? t4 : 0u; }
+            return v;
+          };
+          const uint32_t cnt_t = (uint32_t)__builtin_popcount(ft), cnt_a = (uint32_t)__builtin_popcount(fm & 0xFFu), cnt_b = (uint32_t)__builtin_popcount(fm >> 8);
+          const uint32_t inc_t = scan8(cnt_t), inc_a = scan8(cnt_a), inc_b = scan8(cnt_b);
+          const int last = (lane & ~7) | 7;
+          const uint32_t tot_t = (uint32_t)__shfl((int)inc_t, last), tot_a = (uint32_t)__shfl((int)inc_a, last), tot_m = tot_a + (uint32_t)__shfl((int)inc_b, last);
           uint8_t *cbw = reinterpret_cast<uint8_t *>(Li + NB_CB);
           uint32_t run = inc_t - cnt_t;
           if (own_tail) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { run += (ft >> j) & 1u; if (k0 + j >= 78) cbw[24 + k0 + j - 78] = (uint8_t)run; }
+            for (int j = 0; j < 8; ++j) { run += (ft >> j) & 1u; if (64 + kA + j >= 78) cbw[24 + 64 + kA + j - 78] = (uint8_t)run; }
           }
-          run = tot_t + inc_m - cnt_m;
+          run = tot_t + inc_a - cnt_a;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) { run += (fm >> j) & 1u; cbw[24 + 50 + k0 + j] = (uint8_t)run; }
+          for (int j = 0; j < 8; ++j) { run += (fm >> j) & 1u; cbw[24 + 50 + kA + j] = (uint8_t)run; }
+          run = tot_t + tot_a + inc_b - cnt_b;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { run += (fm >> (8 + j)) & 1u; cbw[24 + 50 + 64 + kA + j] = (uint8_t)run; }
           if (lead) {
             const uint32_t fin = ((tot_t + tot_m) & 0xFFu) * 0x01010101u;
 #pragma unroll
@@ -612,16 +643,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           }
           // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
           // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
-          // lane s8 decodes mask entries 20*s8 .. 20*s8+19 (entries >= 138 are padding)
+          // lane s8 decodes mask entries 32r + 4 s8 .. + 3 of its five code words (entries >= 138 are padding)
 #pragma unroll
           for (int r = 0; r < 5; ++r) {
-            const int e = 20 * s8 + 4 * r;
+            const int e = 32 * r + 4 * s8;
             if (e < ASDR_NB_MASK_USED + 2)
               *reinterpret_cast<float4 *>(L + NB_MSK + e) = make_float4(mask_decode(mkc[r] & 0xFFu), mask_decode((mkc[r] >> 8) & 0xFFu),
                                                                          mask_decode((mkc[r] >> 16) & 0xFFu), mask_decode(mkc[r] >> 24));
           }
 #pragma unroll
-          for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;
+          for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;   /* any partition of 138..265 */
         }
         WAVE_SYNC();
         if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are 0.0, so order-free:
@@ -660,13 +691,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         WAVE_SYNC();
         {   // read this lane's mask values and carry mask[128..265(..271)] to the next call, before the rows are reused
-          load8(L + NB_MSK + k0, mk); load8(L + NB_MSK + k0 + 8, mk + 8);
+          load8(L + NB_MSK + kA, mk); load8(L + NB_MSK + kA + 64, mk + 8);
           if (nb_en) {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-              const int e = 20 * s8 + 4 * r;   // entries >= 138 are padding: store code 1
+              const int e = 32 * r + 4 * s8;   // entries >= 138 are padding: store code 1
               const float4 mv = (e < ASDR_NB_MASK_USED + 2) ? *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-              mrow[r] = mask_encode(mv.x) | (mask_encode(mv.y) << 8) | (mask_encode(mv.z) << 16) | (mask_encode(mv.w) << 24);
+              mrow[8 * r] = mask_encode(mv.x) | (mask_encode(mv.y) << 8) | (mask_encode(mv.z) << 16) | (mask_encode(mv.w) << 24);
             }
           }
         }
@@ -675,19 +706,38 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int j = 0; j < 16; ++j) { const float mv = nb_en ? mk[j] : 1.0f; vio[j] = mv * vio[j]; vqo[j] = mv * vqo[j]; }
       }   // nb_slow
       WAVE_SYNC();   // the B row / mask row is dead: the IF filter rows may overwrite it
-      store8(L + W0 + k0, vio); store8(L + W0 + k0 + 8, vio + 8); store8(L + W1 + k0, vqo); store8(L + W1 + k0 + 8, vqo + 8);
+      store8(L + W0 + kA, vio); store8(L + W0 + kA + 64, vio + 8); store8(L + W1 + kA, vqo); store8(L + W1 + kA + 64, vqo + 8);
     }
     WAVE_SYNC();
     TL(4);
     TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1);
 
+    float *hi_ring = row_ptr(a.hil_i, (uint32_t)ch * 1024u + 4u * (uint32_t)kF);   // float rows: pieces kF + 32m
+    float *hq_ring = row_ptr(a.hil_q, (uint32_t)ch * 1024u + 4u * (uint32_t)kF);
+    float hq_o[16], hq_m[16], idl[16];   // this lane's pieces (samples kF + 32m + j at [4m + j]) of the Hilbert rings
+    DEFINE_ALL_PATHS(hq_o, 16); DEFINE_ALL_PATHS(hq_m, 16); DEFINE_ALL_PATHS(idl, 16);
+    // Hilbert rings (two previous blocks of mixed Q, the delayed I) are requested before the pipeline: 48 registers that the
+    // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer
+    if (is_ssb) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        load4(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m);
+        load4(hq_ring + (hs ^ 1u) * 128 + 32 * m, hq_m + 4 * m);
+        load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);   // delayed I = previous block's mixed I (:111)
+      }
+    }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
     if (ABL_ON(ABL_IF)) {
       const int iq = s8 >> 2, st = s8 & 3;
       float sv[4];
-      const float4 s4 = *reinterpret_cast<const float4 *>(&S->if_state[iq][4 * st]);
-      sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
-      biquad_pipe(L + (iq ? W1 : W0), true, st, &c_bq_pool[P.if_table][5 * st], sv);
+      if (!if_pre) {
+        if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[iq][4 * st]);
+        const float *cf = &c_bq_pool[P.if_table][5 * st];
+#pragma unroll
+        for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
+      }
+      sv[0] = if_s4.x; sv[1] = if_s4.y; sv[2] = if_s4.z; sv[3] = if_s4.w;
+      biquad_pipe(L + (iq ? W1 : W0), true, st, if_cf, sv);
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
     }
     WAVE_SYNC();
@@ -787,60 +837,78 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
     // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
-    float *hi_ring = row_ptr(a.hil_i, (uint32_t)ch * 1024u + 4u * (uint32_t)k0);
-    float *hq = row_ptr(a.hil_q, (uint32_t)ch * 1024u);
     if (ABL_ON(ABL_MIX) && do_mix) {
 #pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        float cc[8], sn[8], vi[8], vq[8], mi[8], mq[8];
-        load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+      for (int m = 0; m < 4; ++m) {
+        float cc[4], sn[4], vi[4], vq[4], mi[4], mq[4];
+        load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
         if (mix_uni) {
-          load8(lds + STRIDE + PH + k0 + 8 * h, cc); load8(lds + 2 * STRIDE + PH + k0 + 8 * h, sn);
+          load4(lds + STRIDE + PH + kF + 32 * m, cc); load4(lds + 2 * STRIDE + PH + kF + 32 * m, sn);
         } else {
-          float ph[8];
-          load8(L + PH + k0 + 8 * h, ph);
+          float ph[4];
+          load4(L + PH + kF + 32 * m, ph);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < 4; ++j) {
             cc[j] = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
             if ((j & 1) == 1) SCHED_FENCE();
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
           mi[j] = vi[j] * cc[j] - vq[j] * sn[j];
           mq[j] = vq[j] * cc[j] + vi[j] * sn[j];
         }
-        store8(L + W0 + k0 + 8 * h, mi); store8(L + W1 + k0 + 8 * h, mq);
-        if (is_ssb) store8(hi_ring + hs * 128 + 8 * h, mi);
+        store4(L + W0 + kF + 32 * m, mi); store4(L + W1 + kF + 32 * m, mq);
+        if (is_ssb) store4(hi_ring + hs * 128 + 32 * m, mi);
       }
     }
 
+    // Requested here, consumed after the Hilbert FIR (their latency hides behind it): the audio filter's state and
+    // coefficient row, the AGC scalars and the index of the AGC table.
+    float4 af_s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float af_cf[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float agc_gain_in = 0.f, agc_old0 = 0.f, agc_carrier0 = 0.f;
+    uint32_t agc_hc0 = 0u;
+    int agc_tab_idx = 0;
+    if (ABL_ON(ABL_AF) && af_en) {
+      af_s4 = *reinterpret_cast<const float4 *>(&S->af_state[4 * (s8 & 3)]);
+      const float *cf = &c_bq_pool[P.audio_table][5 * (s8 & 3)];
+#pragma unroll
+      for (int z = 0; z < 5; ++z) af_cf[z] = cf[z];
+    }
+    if (ABL_ON(ABL_AGC) && agc_en) {
+      agc_gain_in = S->agc_gain; agc_old0 = S->agc_old_abs; agc_hc0 = S->agc_hang_counter; agc_carrier0 = S->am_carrier;
+      agc_tab_idx = P.agc_table;
+    }
     TL(7);
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
     if (__any(is_ssb)) {
-      float qn[16];
+      float qn[16];   // own pieces (samples kF + 32m + j at [4m + j]) of the mixed Q
       DEFINE_ALL_PATHS(qn, 16);
-      if (is_ssb) { load8(L + W1 + k0, qn); load8(L + W1 + k0 + 8, qn + 8); }   // own mixed Q samples, written above
+      if (is_ssb) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load4(L + W1 + kF + 32 * m, qn + 4 * m);   // mixed Q, written above by other lanes too (same wave: LDS is in order)
+      }
       WAVE_SYNC();   // every lane has consumed W0/W1/PH: the history may now overlay them
       if (is_ssb) {
-        // history sample x[m'] with m' = B + k0 + j (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1,
+        // history sample x[m'] with m' = B + k (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1,
         // 256: this block) is stored at L[XP + m' - 1] (x[0] is never used): natural order shifted by one float, so
         // that every operand pair (x[odd], x[odd+1]) of the FIR is an 8-byte-aligned LDS pair.
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          float qo[8], qm[8];
-          load8(hq + hs * 128 + k0 + 8 * h, qo);
-          load8(hq + (hs ^ 1u) * 128 + k0 + 8 * h, qm);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int m = k0 + 8 * h + j;
-            if (m >= 1) L[XP + m - 1] = qo[j];
-            L[XP + 127 + m] = qm[j];
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = kF + 32 * m + j;
+            if (k >= 1) L[XP + k - 1] = hq_o[4 * m + j];
+            L[XP + 127 + k] = hq_m[4 * m + j];
           }
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) L[XP + 255 + k0 + j] = qn[j];
-        store8(hq + hs * 128 + k0, qn); store8(hq + hs * 128 + k0 + 8, qn + 8);   // newest replaces oldest (after its load)
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) L[XP + 255 + kF + 32 * m + j] = qn[4 * m + j];
+          store4(hq_ring + hs * 128 + 32 * m, qn + 4 * m);   // newest replaces oldest (loaded before the IF pipeline)
+        }
         if (lead) S->hil_slot = hs ^ 1u;
       }
       WAVE_SYNC();
@@ -882,19 +950,22 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           }
         }
       }
-      WAVE_SYNC();   // all history reads done: the audio may overwrite the start of the history (= row W0)
+      WAVE_SYNC();   // all history reads done: rows W0/W1 may overwrite the start of the history
       TL(9);
-      if (is_ssb) {   // sideband combine (:115-118) with the delayed I = previous block's mixed I (ring slot hs^1)
+      if (is_ssb) {   // the FIR owns 16 contiguous outputs per lane; the combine works on the float-row pieces: hand over through W1
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float qh[8], idl[8], au[8];
-          load8(hi_ring + (hs ^ 1u) * 128 + 8 * h, idl);
+        for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
+      }
+      WAVE_SYNC();
+      if (is_ssb) {   // sideband combine (:115-118) with the delayed I
 #pragma unroll
-          for (int j = 0; j < 8; ++j) qh[j] = acc2[4 * h + (j >> 1)][j & 1];
+        for (int m = 0; m < 4; ++m) {
+          float qh[4], au[4];
+          load4(L + W1 + kF + 32 * m, qh);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) au[j] = sub_q ? (idl[j] - qh[j]) : (idl[j] + qh[j]);
-          store8(L + W0 + k0 + 8 * h, au);
-          TAP8(ASDR_TAP_MIX_I, h, idl); TAP8(ASDR_TAP_MIX_Q, h, qh);
+          for (int j = 0; j < 4; ++j) au[j] = sub_q ? (idl[4 * m + j] - qh[j]) : (idl[4 * m + j] + qh[j]);
+          store4(L + W0 + kF + 32 * m, au);
+          TAP4(ASDR_TAP_MIX_I, m, idl + 4 * m); TAP4(ASDR_TAP_MIX_Q, m, qh);
         }
       }
     }
@@ -915,11 +986,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
           float vi[8], vq[8], au[8];
-          load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+          load8(L + W0 + kA + 64 * h, vi); load8(L + W1 + kA + 64 * h, vq);
           TAP8(ASDR_TAP_MIX_I, h, vi); TAP8(ASDR_TAP_MIX_Q, h, vq);
 #pragma unroll
           for (int j = 0; j < 8; ++j) { au[j] = sqrtf(vi[j] * vi[j] + vq[j] * vq[j]); if ((j & 3) == 3) SCHED_FENCE(); }
-          store8(L + W0 + k0 + 8 * h, au);
+          store8(L + W0 + kA + 64 * h, au);
         }
       }
       WAVE_SYNC();
@@ -940,33 +1011,35 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
         float vi[8], vq[8];
-        load8(L + W0 + k0 + 8 * h, vi); load8(L + W1 + k0 + 8 * h, vq);
+        load8(L + W0 + kA + 64 * h, vi); load8(L + W1 + kA + 64 * h, vq);
         TAP8(ASDR_TAP_MIX_I, h, vi); TAP8(ASDR_TAP_MIX_Q, h, vq);
-        store8(L + W0 + k0 + 8 * h, vq);
+        store8(L + W0 + kA + 64 * h, vq);
       }
     }
     if (!is_ssb && !is_am && !is_sam) {   // unknown mode: the reference re-processes stale audio; we emit silence
       const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      store8(L + W0 + k0, z); store8(L + W0 + k0 + 8, z);
+      store8(L + W0 + kA, z); store8(L + W0 + kA + 64, z);
     }
     WAVE_SYNC();
     TL(10);
     TAP_ROW(ASDR_TAP_DEMOD, W0);
 
-    // AGC scalars are requested here, one phase early (latency hides behind the audio-filter pipeline)
-    float agc_gain_in = 0.f, agc_old0 = 0.f, agc_carrier0 = 0.f;
-    uint32_t agc_hc0 = 0u;
+    // the AGC gain table (row of 132 floats) is requested before the audio-filter pipeline and staged in LDS after it
+    float4 agc_t4[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) agc_t4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ABL_ON(ABL_AGC) && agc_en) {
-      agc_gain_in = S->agc_gain; agc_old0 = S->agc_old_abs; agc_hc0 = S->agc_hang_counter; agc_carrier0 = S->am_carrier;
+      const float *gtab = a.agc_tab + (size_t)agc_tab_idx * ASDR_AGC_TAB_ROW;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) agc_t4[r] = reinterpret_cast<const float4 *>(gtab)[q]; }
     }
     // ---- audio IIR filter, AudioSDR.cpp:149, 280-286: lanes s8 = 0..3 are the four stages ---------------------
     if (ABL_ON(ABL_AF) && __any(af_en)) {
       const int st = s8 & 3;
       const bool on = af_en && (s8 < 4);
       float sv[4];
-      const float4 s4 = *reinterpret_cast<const float4 *>(&S->af_state[4 * st]);
-      sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
-      biquad_pipe(L + W0, on, st, &c_bq_pool[P.audio_table][5 * st], sv);
+      sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
+      biquad_pipe(L + W0, on, st, af_cf, sv);
       if (on) *reinterpret_cast<float4 *>(&S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       WAVE_SYNC();
     }
@@ -979,22 +1052,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ABL_ON(ABL_AGC) && __any(agc_en)) {
       const float *tab = L + AGC_TAB;
       const float gain_in = agc_gain_in;
-      if (agc_en) {   // stage the channel's gain table (row of 132 floats) in LDS, all loads in flight at once
-        const float *gtab = a.agc_tab + (size_t)P.agc_table * ASDR_AGC_TAB_ROW;
-        float4 t4[5];
+      if (agc_en) {   // stage the channel's gain table in LDS
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; t4[r] = (q < 33) ? reinterpret_cast<const float4 *>(gtab)[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = t4[r]; }
+        for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = agc_t4[r]; }
         // |x| clamped to 1.0 (:410-411) for every sample, in parallel; the sequential pass below replaces it in place by the
         // governing envelope value
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
           float au[8], av8[8];
-          load8(L + W0 + k0 + 8 * h, au);
+          load8(L + W0 + kA + 64 * h, au);
 #pragma unroll
           for (int j = 0; j < 8; ++j) { const float ax = fabsf(au[j]); av8[j] = (ax > 1.0f) ? 1.0f : ax; }   // NaN-preserving like the reference
-          store8(L + AGC_GV + k0 + 8 * h, av8);
+          store8(L + AGC_GV + kA + 64 * h, av8);
         }
       }
       WAVE_SYNC();
@@ -1040,7 +1109,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
           float au[8], gvr[8];
-          load8(L + W0 + k0 + 8 * h, au); load8(L + AGC_GV + k0 + 8 * h, gvr);
+          load8(L + W0 + kA + 64 * h, au); load8(L + AGC_GV + kA + 64 * h, gvr);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float gain = (gvr[j] < 0.0f) ? gain_in : agc_compress(tab, gvr[j]);
@@ -1050,7 +1119,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             au[j] = o;
             if ((j & 3) == 3) SCHED_FENCE();
           }
-          store8(L + W0 + k0 + 8 * h, au);
+          store8(L + W0 + kA + 64 * h, au);
         }
       }
       WAVE_SYNC();
@@ -1063,14 +1132,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (ABL_ON(ABL_ALS) && __any(als_en)) {
         const int M = P.als_m, D = P.als_delay;
         const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
-        float *gx = a.als_x + (size_t)ch * ASDR_N + k0, *gw = a.als_w + (size_t)ch * ASDR_N + k0;
+        float *gx = a.als_x + (size_t)ch * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
         if (als_en) {
 #pragma unroll 1
-          for (int h = 0; h < 2; ++h) {
-            float t[8];
-            load8(gx + 8 * h, t); store8(L + ALS_X + k0 + 8 * h, t);            // previous block
-            load8(L + W0 + k0 + 8 * h, t); store8(L + ALS_X + 128 + k0 + 8 * h, t); store8(gx + 8 * h, t);
-            load8(gw + 8 * h, t); store8(L + ALS_W + k0 + 8 * h, t);
+          for (int m = 0; m < 4; ++m) {
+            float t[4];
+            load4(gx + 32 * m, t); store4(L + ALS_X + kF + 32 * m, t);            // previous block
+            load4(L + W0 + kF + 32 * m, t); store4(L + ALS_X + 128 + kF + 32 * m, t); store4(gx + 32 * m, t);
+            load4(gw + 32 * m, t); store4(L + ALS_W + kF + 32 * m, t);
           }
         }
         WAVE_SYNC();
@@ -1121,7 +1190,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         WAVE_SYNC();
         if (als_en) {
 #pragma unroll 1
-          for (int h = 0; h < 2; ++h) { float t[8]; load8(L + ALS_W + k0 + 8 * h, t); store8(gw + 8 * h, t); }
+          for (int m = 0; m < 4; ++m) { float t[4]; load4(L + ALS_W + kF + 32 * m, t); store4(gw + 32 * m, t); }
         }
       }
     }
@@ -1132,7 +1201,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float au[8];
-        load8(L + W0 + k0 + 8 * h, au);
+        load8(L + W0 + kA + 64 * h, au);
         TAP8(ASDR_TAP_ALS, h, au);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1143,7 +1212,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       if (valid) {
         int4 *po = reinterpret_cast<int4 *>(a.out + io_out);
-        po[0] = ro[0].v; po[1] = ro[1].v;
+        po[0] = ro[0].v; po[8] = ro[1].v;
       }
     }
     if (lead) S->status = status;

@@ -707,7 +707,8 @@ int ao_check_sin_interp_f32(void) {
 /* CPU-baseline runner for bench.py                                                            */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
-  int config, ch0, ch1, n_blocks, n_channels_total;
+  int ch0, ch1, n_blocks;
+  asdr_oracle_t **inst;
   const int16_t *I, *Q;
   int16_t *out;
 } bench_job_t;
@@ -728,16 +729,16 @@ static void bench_configure(asdr_oracle_t *o, int config) {
 static void *bench_worker(void *arg) {
   bench_job_t *j = (bench_job_t *)arg;
   for (int c = j->ch0; c < j->ch1; c++) {
-    asdr_oracle_t *o = ao_create();
-    bench_configure(o, j->config);
+    asdr_oracle_t *o = j->inst[c];
     size_t base = (size_t)c * j->n_blocks * N;
     for (int b = 0; b < j->n_blocks; b++)
       ao_update(o, j->I + base + (size_t)b * N, j->Q + base + (size_t)b * N, j->out + base + (size_t)b * N);
-    ao_destroy(o);
   }
   return NULL;
 }
 
+/* Seconds spent in update() only: the instances are created and configured (AGC table build, ...) BEFORE the timed region
+ * and destroyed after it. */
 double ao_bench_run(int config, int n_channels, int n_blocks, const int16_t *I, const int16_t *Q, int16_t *out,
                     int n_threads) {
   if (n_threads < 1) n_threads = 1;
@@ -745,12 +746,39 @@ double ao_bench_run(int config, int n_channels, int n_blocks, const int16_t *I, 
   pthread_t th[256];
   bench_job_t jobs[256];
   struct timespec t0, t1;
+  asdr_oracle_t **inst = (asdr_oracle_t **)malloc((size_t)n_channels * sizeof *inst);
+  for (int c = 0; c < n_channels; c++) { inst[c] = ao_create(); bench_configure(inst[c], config); }
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int t = 0; t < n_threads; t++) {
-    jobs[t] = (bench_job_t){config, (int)((long)n_channels * t / n_threads), (int)((long)n_channels * (t + 1) / n_threads),
-                            n_blocks, n_channels, I, Q, out};
+    jobs[t] = (bench_job_t){(int)((long)n_channels * t / n_threads), (int)((long)n_channels * (t + 1) / n_threads),
+                            n_blocks, inst, I, Q, out};
     pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
   }
+  for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (int c = 0; c < n_channels; c++) ao_destroy(inst[c]);
+  free(inst);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* Host calibration for bench.py: a register-only float loop (no memory traffic, nothing of the oracle) on n_threads threads;
+ * returns seconds.  (n_threads x t(1 thread)) / t(n_threads) = how many threads' worth of arithmetic the box really gives this
+ * process -- sandboxes often expose more logical CPUs than they schedule. */
+static void *spin_worker(void *arg) {
+  long iters = *(long *)arg;
+  volatile float sink;
+  float a = 1.0f, b = 0.5f, c = 0.25f, d = 0.125f;
+  for (long i = 0; i < iters; i++) { a = a * 0.999999f + 1e-7f; b = b * 0.999998f + 2e-7f; c = c * 0.999997f + 3e-7f; d = d * 0.999996f + 4e-7f; }
+  sink = a + b + c + d; (void)sink;
+  return NULL;
+}
+double ao_spin_calibrate(int n_threads, long iters) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, spin_worker, &iters);
   for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
   clock_gettime(CLOCK_MONOTONIC, &t1);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);

@@ -162,4 +162,7 @@ double ao_bench_run(int config, int n_channels, int n_blocks, const int16_t *I, 
 #ifdef __cplusplus
 }
 #endif
+/* bench.py host calibration: seconds for `iters` iterations of a register-only float loop on each of n_threads threads */
+double ao_spin_calibrate(int n_threads, long iters);
+
 #endif /* ASDR_ORACLE_H_ */

@@ -111,6 +111,8 @@ def lib():
     L.ao_check_sin_interp_f32.restype = i32
     L.ao_bench_run.argtypes = [i32, i32, i32, i16p, i16p, i16p, i32]
     L.ao_bench_run.restype = C.c_double
+    L.ao_spin_calibrate.argtypes = [i32, C.c_long]
+    L.ao_spin_calibrate.restype = C.c_double
     # blocks around the hot path (asdr_front_oracle.h)
     L.ao_pre_create.restype = vp; L.ao_pre_destroy.argtypes = [vp]
     L.ao_pre_update.argtypes = [vp, i16p, i16p]
@@ -204,6 +206,13 @@ def bench_run(config, I, Q, n_threads=1):
     out = np.empty_like(I)
     t = lib().ao_bench_run(config, I.shape[0], I.shape[1], _i16p(I), _i16p(Q), _i16p(out), n_threads)
     return t, out
+
+
+def host_parallel_capacity(n_threads, iters=100_000_000):
+    """How many threads' worth of register-only float arithmetic this process really gets on n_threads threads."""
+    t1 = lib().ao_spin_calibrate(1, iters)
+    tn = lib().ao_spin_calibrate(n_threads, iters)
+    return n_threads * t1 / tn
 
 
 # --- numpy views of the data tables (for independent cross-checks) ---
