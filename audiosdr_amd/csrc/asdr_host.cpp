@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/asdr.h"
@@ -56,7 +57,7 @@ struct Chan {
   float agc_slot129 = 100.0f;  // _agc_hangTime, which is also _agc_gainLookup[129] (.h:219-220)
   uint32_t agc_hang_count = 0;
   bool agc_en = true;
-  int agc_table = 0;
+  int agc_table = -1;
   float nb_threshold = 1.2f;
   bool nb_en = true;
 };
@@ -107,12 +108,22 @@ struct asdr_batch {
   hipStream_t stream = nullptr;  // used by the host-pointer entry point and by getters
   std::vector<Chan> ch;          // n + 1 (last = dummy channel used to pad the last wave)
   std::vector<AgcTable> agc_pool;
+  std::unordered_map<uint64_t, std::vector<int>> agc_index;   // hash of (threshold, slope, knee) bits -> rows of agc_pool
+  std::vector<uint32_t> agc_refs;                              // channels using each table
   std::vector<ChanParams> hp;
   std::vector<uint32_t> reset;
   std::vector<SlotInfo> sched;
-  bool params_dirty = true, reset_pending = true, agc_pool_dirty = true;
-  bool any_als = false;          // some channel has the ALS filter enabled -> larger-LDS kernel instantiation
-  bool any_sam = false;          // some channel is in SAM mode -> instantiation with the sine table in LDS
+  // Incremental control plane: a setter marks only the channels it touched.  flush() refills and uploads those rows; the
+  // wave schedule is rebuilt only when a touched channel's schedule key (kernel kind, mode, enables, tables) changed.
+  std::vector<int32_t> dirty;          // channels whose parameter row changed since the last flush (each listed once)
+  std::vector<uint8_t> dirty_flag;
+  bool all_dirty = true;               // first flush, or so many dirty rows that one bulk upload is cheaper
+  bool sched_dirty = true, reset_pending = true, agc_pool_dirty = true;
+  // The sorted schedule is launched as up to three sub-ranges, one per kernel instantiation (plain / SAM / ALS), each padded
+  // to whole waves with the dummy channel: one SAM or ALS channel no longer demotes the whole batch.
+  int kind_first[3] = {0, 0, 0}, kind_slots[3] = {0, 0, 0};
+  // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
+  long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
   // device
   ChanParams *d_params = nullptr;
   ChanSmall *d_small = nullptr;
@@ -133,28 +144,61 @@ struct asdr_batch {
   std::vector<hipEvent_t> tev;   // optional per-launch event pairs (asdr_kernel_timing_begin)
   size_t tev_used = 0;
   hipStream_t last_stream = nullptr;
+  hipEvent_t ev_last = nullptr;  // recorded after every launch: a call on another stream waits for it first
+  bool ev_last_valid = false;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
   ChainConsts k{};
 };
 
 namespace {
 
+uint64_t agc_hash(float thr, float slope, float knee) {
+  uint32_t a, b2, c;
+  memcpy(&a, &thr, 4); memcpy(&b2, &slope, 4); memcpy(&c, &knee, 4);
+  uint64_t h = 1469598103934665603ull;
+  for (uint32_t w : {a, b2, c}) { h ^= w; h *= 1099511628211ull; }
+  return h;
+}
+
 int find_agc_table(asdr_batch *b, float thr, float slope, float knee) {
-  for (size_t i = 0; i < b->agc_pool.size(); i++) {
+  std::vector<int> &bucket = b->agc_index[agc_hash(thr, slope, knee)];
+  for (int i : bucket) {
     const AgcTable &t = b->agc_pool[i];
-    if (memcmp(&t.thr, &thr, 4) == 0 && memcmp(&t.slope, &slope, 4) == 0 && memcmp(&t.knee, &knee, 4) == 0) return (int)i;
+    if (memcmp(&t.thr, &thr, 4) == 0 && memcmp(&t.slope, &slope, 4) == 0 && memcmp(&t.knee, &knee, 4) == 0) return i;
   }
   AgcTable t;
   t.thr = thr; t.slope = slope; t.knee = knee;
   build_agc_table(t);
   b->agc_pool.push_back(t);
+  b->agc_refs.push_back(0);
+  bucket.push_back((int)b->agc_pool.size() - 1);
   b->agc_pool_dirty = true;
   return (int)b->agc_pool.size() - 1;
 }
 
 void rebuild_agc(asdr_batch *b, Chan &c) {  // agc_createLookupTable(): also clobbers _agc_hangTime's storage
+  const int old = c.agc_table;
   c.agc_table = find_agc_table(b, c.agc_threshold, c.agc_slope, c.agc_knee);
+  b->agc_refs[c.agc_table]++;
+  if (old >= 0 && old < (int)b->agc_refs.size() && b->agc_refs[old] > 0) b->agc_refs[old]--;
   c.agc_slot129 = b->agc_pool[c.agc_table].v[129];
+}
+
+// Drop tables no channel uses any more (a UI knob sweep leaves one dead table per step) once they outnumber the live ones.
+void compact_agc_pool(asdr_batch *b) {
+  size_t live = 0;
+  for (uint32_t r : b->agc_refs) live += (r != 0);
+  if (b->agc_pool.size() < 64 || b->agc_pool.size() <= 2 * live) return;
+  std::vector<int> remap(b->agc_pool.size(), -1);
+  std::vector<AgcTable> pool;
+  std::vector<uint32_t> refs;
+  for (size_t i = 0; i < b->agc_pool.size(); i++)
+    if (b->agc_refs[i]) { remap[i] = (int)pool.size(); pool.push_back(b->agc_pool[i]); refs.push_back(b->agc_refs[i]); }
+  b->agc_pool.swap(pool); b->agc_refs.swap(refs);
+  b->agc_index.clear();
+  for (size_t i = 0; i < b->agc_pool.size(); i++) b->agc_index[agc_hash(b->agc_pool[i].thr, b->agc_pool[i].slope, b->agc_pool[i].knee)].push_back((int)i);
+  for (Chan &c : b->ch) c.agc_table = remap[c.agc_table];
+  b->agc_pool_dirty = true; b->all_dirty = true; b->sched_dirty = true;   // every row carries a table index
 }
 
 // setDemodMode, AudioSDR.cpp:187-222

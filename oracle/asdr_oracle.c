@@ -82,6 +82,7 @@ struct asdr_oracle {
   int pll_locked;
   float pll_y_re, pll_y_im, pll_prev_filt, pll_err, pll_filt;
   /* --- test aid */
+  int unknown_mode_silence; /* model the PRODUCT's documented choice for unknown mode values (default 0 = the reference) */
   int taps_on;
   float taps[AO_N_TAPS][N];
 };
@@ -455,7 +456,9 @@ void ao_update(asdr_oracle_t *o, const int16_t *bi, const int16_t *bq, int16_t *
       for (int i = 0; i < N; i++) o->audio[i] = o->Q[i];
     }
     if (o->mode == AO_AM || (o->mode == AO_SAM && !o->pll_locked)) am_envelope(o);
-  } /* any other mode value: _audioOut keeps last block's (already post-processed) samples */
+  } else if (o->unknown_mode_silence) { /* the product's defined difference: silence instead of stale audio */
+    memset(o->audio, 0, sizeof o->audio);
+  } /* any other mode value: _audioOut keeps last block's (already post-processed) samples (.cpp:84,122,149-161) */
   TAP(AO_TAP_MIX_I, o->I); TAP(AO_TAP_MIX_Q, o->Q);
   TAP(AO_TAP_DEMOD, o->audio);
 
@@ -511,6 +514,7 @@ asdr_oracle_t *ao_create(void) {
 
 void ao_destroy(asdr_oracle_t *o) { free(o); }
 void ao_enable_taps(asdr_oracle_t *o, int on) { o->taps_on = on; }
+void ao_set_unknown_mode_silence(asdr_oracle_t *o, int on) { o->unknown_mode_silence = on; }
 const float *ao_tap(const asdr_oracle_t *o, int tap) { return o->taps[tap]; }
 
 void ao_init(asdr_oracle_t *o) { /* .cpp:174-185 */

@@ -162,6 +162,13 @@ double ao_bench_run(int config, int n_channels, int n_blocks, const int16_t *I, 
 #ifdef __cplusplus
 }
 #endif
+/* Unknown demodulation-mode values (anything but 0..6; reachable through setDemodMode, AudioSDR.cpp:188): the reference
+ * leaves _audioOut untouched, so the audio filter / AGC / ALS / output stage re-process the PREVIOUS block's already
+ * processed audio (AudioSDR.cpp:84,122,149-161).  That is the oracle's default.  The HIP product deliberately outputs
+ * the post-processing of a silent block instead (reproducing the stale row would cost a 512-byte store per channel and
+ * block for every channel); on = 1 makes the oracle model that documented choice so the GPU tests can pin it. */
+void ao_set_unknown_mode_silence(asdr_oracle_t *o, int on);
+
 /* bench.py host calibration: seconds for `iters` iterations of a register-only float loop on each of n_threads threads */
 double ao_spin_calibrate(int n_threads, long iters);
 

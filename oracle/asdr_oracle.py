@@ -59,6 +59,7 @@ def lib():
     L.ao_create.restype = vp
     L.ao_destroy.argtypes = [vp]
     L.ao_enable_taps.argtypes = [vp, i32]
+    L.ao_set_unknown_mode_silence.argtypes = [vp, i32]
     L.ao_tap.argtypes = [vp, i32]
     L.ao_tap.restype = fp
     L.ao_update.argtypes = [vp, i16p, i16p, i16p]
@@ -156,6 +157,10 @@ class OracleSDR:
         self._h = self._L.ao_create()
         if taps:
             self._L.ao_enable_taps(self._h, 1)
+
+    def set_unknown_mode_silence(self, on=True):
+        """Model the HIP product's defined difference for unknown mode values (oracle/asdr_oracle.h)."""
+        self._L.ao_set_unknown_mode_silence(self._h, 1 if on else 0)
 
     def __del__(self):
         try:

@@ -1,0 +1,116 @@
+"""BASELINE configs 3, 4 and 5 at their FULL per-GPU sizes through the C ABI (the small cases of tests/cases.py cover the same
+settings block by block with taps).  Inputs are a few thousand distinct channels tiled over the batch on the device; checks:
+sampled channels bit-for-bit against the CPU oracle, the tiled-duplicate property (channel c == channel c mod uniq for the
+whole batch: channels never interact and the wave schedule does not matter), and the domain facts the configs are about
+(SAM lock fraction, capture-sink contents)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+BLOCK = 128
+
+
+def _device_tiles(torch, I, Q, n_ch):
+    """[uniq][n_blk][128] host arrays -> per-block device tensors [n_ch][128] (tiled)."""
+    uniq, n_blk = I.shape[0], I.shape[1]
+    reps = (n_ch + uniq - 1) // uniq
+    dI = [torch.from_numpy(np.ascontiguousarray(I[:, b])).cuda().repeat(reps, 1)[:n_ch].contiguous() for b in range(n_blk)]
+    dQ = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).cuda().repeat(reps, 1)[:n_ch].contiguous() for b in range(n_blk)]
+    return dI, dQ
+
+
+def _assert_tiled(torch, dOut, uniq, what):
+    n_ch = dOut.shape[0]
+    ref = dOut[:uniq]
+    for r0 in range(uniq, n_ch, uniq):
+        part = dOut[r0:r0 + uniq]
+        assert bool(torch.equal(part, ref[:part.shape[0]])), "%s: channels %d.. differ from their duplicates" % (what, r0)
+
+
+def test_full_size_c3_batch(gpu, ao):
+    """C3: SAM + PLL + AGC, 262,144 channels on one GPU.  Lock fraction 1.0 after 12 blocks, sampled channels
+    vs the oracle (all 12 blocks), every channel equal to its duplicate."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, uniq, n_blk = 262144, 3584, 12
+
+    def cfg(s):
+        s.setDemodMode(5); s.setNoiseBlankerThresholdDb(10.0); s.enableAudioFilter(); s.setAudioFilter(0)
+
+    fc = 6890.0 + (np.arange(uniq) % 7 - 3) * 50.0
+    I, Q = make_iq(uniq, n_blk, fc=fc, A=0.3, m=0.5, fm=400.0)
+    dI, dQ = _device_tiles(torch, I, Q, n_ch)
+    batch = gpu.AudioSDRBatch(n_ch)
+    cfg(batch)
+    dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device="cuda")
+    sample = [0, 3, 1234, 3583]
+    got = {c: [] for c in sample}
+    for b in range(n_blk):
+        batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, 0)
+        batch.synchronize()
+        _assert_tiled(torch, dOut, uniq, "C3 block %d" % b)
+        for c in sample:
+            got[c].append(dOut[c + uniq * 70].cpu().numpy().copy())
+    for c in sample:
+        o = ao.OracleSDR(); cfg(o)
+        want = o.update(I[c], Q[c]).reshape(n_blk, BLOCK)
+        assert np.array_equal(np.stack(got[c]), want), "C3 channel %d" % c
+    st = batch.read_status()
+    assert float(st["sam_locked"].mean()) == 1.0
+    batch.close()
+
+
+def test_c4_share(gpu, ao):
+    """C4: one GPU's share (131,072 channels) of the 1M-channel mixed-mode batch: mode = c mod 7, ALS notch on, blanker 10 dB."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, uniq, n_blk = 131072, 3584, 8      # uniq is a multiple of 7: tiling keeps the mode pattern
+    I, Q = make_iq(uniq, n_blk, fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15)
+    dI, dQ = _device_tiles(torch, I, Q, n_ch)
+    batch = gpu.AudioSDRBatch(n_ch)
+    L = gpu.load_library()
+    for c in range(n_ch):
+        L.asdr_setDemodMode(batch._h, c, c % 7)
+    batch.enableALSfilter(); batch.setNoiseBlankerThresholdDb(10.0)
+    dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device="cuda")
+    sample = [0, 1, 2, 3, 4, 5, 6, 3583]
+    got = {c: [] for c in sample}
+    for b in range(n_blk):
+        batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, 0)
+        batch.synchronize()
+        _assert_tiled(torch, dOut, uniq, "C4 block %d" % b)
+        for c in sample:
+            got[c].append(dOut[c + uniq * 30].cpu().numpy().copy())
+    for c in sample:
+        o = ao.OracleSDR()
+        o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
+        want = o.update(I[c], Q[c]).reshape(n_blk, BLOCK)
+        assert np.array_equal(np.stack(got[c]), want), "C4 channel %d (mode %d)" % (c, c % 7)
+    batch.close()
+
+
+def test_c5_share(gpu, ao):
+    """C5: one GPU's share (512 receivers) with the BareBonesWSPR.ino:87-102,129 settings, 2,048 consecutive blocks streamed
+    256 per launch into the capture sink; sampled receivers' whole capture rows vs the oracle."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, T, launches = 512, 256, 8
+
+    def cfg(s):
+        s.enableAGC(); s.setAGCmode(2); s.disableALSfilter(); s.disableNoiseBlanker(); s.setNoiseBlankerThresholdDb(10.0)
+        s.setInputGain(1.0); s.setOutputGain(0.5); s.setIQgainBalance(1.020); s.setAudioFilter(2); s.setDemodMode(6); s.setMute(0)
+
+    I, Q = make_iq(n_ch, T, fc=6890.0, A=0.02, noise=0.05)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    batch = gpu.AudioSDRBatch(n_ch)
+    cfg(batch)
+    batch.capture_open(T * launches)
+    for _ in range(launches):          # the same resident 256-block period is streamed 8 times
+        batch.capture_update_device(dI.data_ptr(), dQ.data_ptr(), T)
+    batch.synchronize()
+    assert batch.capture_position == T * launches
+    for c in (0, 17, 255, 511):
+        o = ao.OracleSDR(); cfg(o)
+        want = o.update(np.tile(I[c], (launches, 1)), np.tile(Q[c], (launches, 1)))
+        assert np.array_equal(batch.capture_read(c).reshape(-1), want.reshape(-1)), "C5 receiver %d" % c
+    batch.close()

@@ -146,6 +146,36 @@ def test_mixer_uniform_and_divergent_phases_in_one_wave(gpu, ao):
         batch.close()
 
 
+@pytest.mark.parametrize("mode", [7, -1, 65535, 9])
+def test_unknown_mode_values(gpu, ao, mode):
+    """setDemodMode with a value outside 0..6 (AudioSDR.cpp:188: only _mode changes).  Defined difference: the
+    reference re-processes the previous block's stale audio (.cpp:84,122,149-161); the product runs the enabled post stages
+    on a SILENT block.  The oracle models that choice with ao_set_unknown_mode_silence; its default (the reference's behaviour)
+    is pinned by tests/test_oracle_known_answers.py.  Everything else -- blanker, IF filter state, the stages after the
+    demodulator, the return to a known mode -- must stay bit-exact."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, n_blk = 11, 12
+    I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.25, impulse_every=700)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")], taps=True)
+    for o in orcs:
+        o.set_unknown_mode_silence()
+    script = {3: [S("setDemodMode", mode, sel=lambda c: c % 2 == 0)], 6: [S("setDemodMode", 4, sel=lambda c: c % 4 == 0)],
+              8: [S("setDemodMode", mode)], 10: [S("setDemodMode", 0)]}
+    for b in range(n_blk):
+        if b in script:
+            apply_setters(batch, orcs, script[b])
+        got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
+        taps = batch.read_taps()
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b], Q[c, b])
+            for t in ("NB_I", "IF_I", "IF_Q", "DEMOD", "AUDIO_FILT", "AGC"):
+                assert np.array_equal(f32_bits(taps[t][c]), f32_bits(orcs[c].tap(t))), "mode %d block %d ch %d tap %s" % (mode, b, c, t)
+            assert np.array_equal(got[c], want), "mode %d block %d ch %d" % (mode, b, c)
+            assert batch.getDemodMode(ch=c) == orcs[c].getDemodMode()
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
 def test_missing_input_guard(gpu, ao):
     """AudioSDR.cpp:48-56: a missing I or Q block -> return without processing; state does not advance."""
     import ctypes as C
