@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #define ASDR_N 128
+#define ASDR_PLL_WRAP_MAX 64  /* turns of 2*pi the SAM PLL's phase wrap may take per sample before the estimate is reset */
 
 /* ChanParams.flags */
 #define ASDR_F_NB_EN        (1u << 0)

@@ -22,7 +22,7 @@
 
 extern "C" int asdr_kernels_upload_tables(void);
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, hipStream_t stream);
-extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int n_rows, hipStream_t stream);
+extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
 
 namespace {
 
@@ -119,6 +119,7 @@ struct asdr_batch {
   std::vector<uint8_t> dirty_flag;
   bool all_dirty = true;               // first flush, or so many dirty rows that one bulk upload is cheaper
   bool sched_dirty = true, reset_pending = true, agc_pool_dirty = true;
+  int reset_lo = 0x7fffffff, reset_hi = -1;   // rows with pending reset bits lie in [reset_lo, reset_hi]
   // The sorted schedule is launched as up to three sub-ranges, one per kernel instantiation (plain / SAM / ALS), each padded
   // to whole waves with the dummy channel: one SAM or ALS channel no longer demotes the whole batch.
   int kind_first[3] = {0, 0, 0}, kind_slots[3] = {0, 0, 0};
@@ -201,6 +202,13 @@ void compact_agc_pool(asdr_batch *b) {
   b->agc_pool_dirty = true; b->all_dirty = true; b->sched_dirty = true;   // every row carries a table index
 }
 
+void mark_reset(asdr_batch *b, int i, uint32_t bits) {
+  b->reset[i] |= bits;
+  b->reset_pending = true;
+  if (i < b->reset_lo) b->reset_lo = i;
+  if (i > b->reset_hi) b->reset_hi = i;
+}
+
 // setDemodMode, AudioSDR.cpp:187-222
 float set_mode(asdr_batch *b, int idx, int new_mode) {
   Chan &c = b->ch[idx];
@@ -212,7 +220,7 @@ float set_mode(asdr_batch *b, int idx, int new_mode) {
   else if (c.mode == ASDR_CW_USBmode) { c.freq_shift = (float)((double)kIFcenter - (double)kBWcw / 2.0); tbl = ASDR_TBL_IF_CW; }
   else if (c.mode == ASDR_CW_LSBmode) { c.freq_shift = (float)((double)kIFcenter + (double)kBWcw / 2.0); tbl = ASDR_TBL_IF_CW; }
   else if (c.mode == ASDR_AMmode || c.mode == ASDR_SAMmode) { c.freq_shift = kIFcenter; tbl = ASDR_TBL_IF_AM; }
-  if (tbl >= 0) { c.if_table = tbl; b->reset[idx] |= ASDR_R_IF; b->reset_pending = true; }
+  if (tbl >= 0) { c.if_table = tbl; mark_reset(b, idx, ASDR_R_IF); }
   return c.freq_shift;
 }
 
@@ -235,11 +243,10 @@ void chan_init(asdr_batch *b, int idx) {
   Chan &c = b->ch[idx];
   c.audio_table = ASDR_TBL_AUDIO_BASE + ASDR_audio2700;
   c.if_table = ASDR_TBL_IF_SSB;
-  b->reset[idx] |= ASDR_R_AF | ASDR_R_IF | ASDR_R_IMG | ASDR_R_NB;
+  mark_reset(b, idx, ASDR_R_AF | ASDR_R_IF | ASDR_R_IMG | ASDR_R_NB);
   agc_init(b, c);
   set_mode(b, idx, ASDR_LSBmode);
   c.muted = false;
-  b->reset_pending = true;
 }
 
 void fill_params(const Chan &c, ChanParams &p) {
@@ -257,20 +264,85 @@ void fill_params(const Chan &c, ChanParams &p) {
   p.als_m = c.als_m; p.als_delay = c.als_delay; p.als_lambda = c.als_lambda;
 }
 
-// Wave scheduling: channels with the same (mode, enables, tables) are grouped so that a wave's 8 channels
-// take the same branches.  Rows of I/Q/out and of every state array are per channel, so the grouping
-// costs nothing in coalescing.
+// Wave scheduling: channels are grouped by kernel instantiation (plain / SAM / ALS) and, inside it, by (mode, enables, tables),
+// so that a wave's 8 channels take the same branches.  Rows of I/Q/out and of every state array are per channel, so the
+// grouping costs nothing in coalescing.
+int kernel_kind(const ChanParams &p) {
+  return (p.flags & ASDR_F_ALS_EN) ? ASDR_KERNEL_ALS : ((p.mode == ASDR_SAMmode) ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN);
+}
 uint64_t sched_key(const ChanParams &p) {
-  return ((uint64_t)(p.mode & 0xFFFF) << 40) | ((uint64_t)(p.flags & 0xFF) << 32) | ((uint64_t)(p.if_table & 0xFF) << 24) |
-         ((uint64_t)(p.audio_table & 0xFF) << 16) | (uint64_t)(p.agc_table & 0xFFFF);
+  return ((uint64_t)kernel_kind(p) << 60) | ((uint64_t)(p.mode & 0xFFFF) << 40) | ((uint64_t)(p.flags & 0xFF) << 32) |
+         ((uint64_t)(p.if_table & 0xFF) << 24) | ((uint64_t)(p.audio_table & 0xFF) << 16) | (uint64_t)(p.agc_table & 0xFFFF);
+}
+
+void mark_dirty(asdr_batch *b, int i) {
+  if (b->all_dirty) return;
+  if (!b->dirty_flag[i]) { b->dirty_flag[i] = 1; b->dirty.push_back(i); }
+  if (b->dirty.size() > (size_t)b->n / 8 + 64) { b->all_dirty = true; }   // a bulk refill is cheaper from here on
+}
+
+// Host half of flush(): refill the parameter rows that changed, decide whether the schedule has to be rebuilt, rebuild it.
+// Returns the sorted list of refilled rows in `rows_out` (empty + all_dirty = every row).  No HIP call in here, so the
+// control-plane tests can time it on a device-less batch.
+void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool &sched_rebuilt) {
+  const int rows = b->n + 1;
+  compact_agc_pool(b);
+  bulk = b->all_dirty;
+  rows_out.clear();
+  b->stat_rows_refilled = 0;
+  if (bulk) {
+    for (int i = 0; i < rows; i++) {
+      const uint64_t old_key = sched_key(b->hp[i]);
+      fill_params(b->ch[i], b->hp[i]);
+      if (i < b->n && sched_key(b->hp[i]) != old_key) b->sched_dirty = true;
+    }
+    b->stat_rows_refilled = rows;
+    b->stat_bulk_uploads++;
+  } else if (!b->dirty.empty()) {
+    std::sort(b->dirty.begin(), b->dirty.end());
+    for (int32_t i : b->dirty) {
+      const uint64_t old_key = sched_key(b->hp[i]);
+      fill_params(b->ch[i], b->hp[i]);
+      if (sched_key(b->hp[i]) != old_key) b->sched_dirty = true;
+      b->dirty_flag[i] = 0;
+    }
+    rows_out = b->dirty;
+    b->stat_rows_refilled = (long)rows_out.size();
+  }
+  b->dirty.clear();
+  if (bulk) std::fill(b->dirty_flag.begin(), b->dirty_flag.end(), 0);
+  b->all_dirty = false;
+  sched_rebuilt = false;
+  if (b->sched_dirty) {
+    std::vector<std::pair<uint64_t, int32_t>> order(b->n);
+    for (int i = 0; i < b->n; i++) order[i] = {sched_key(b->hp[i]), i};
+    std::sort(order.begin(), order.end());   // (key, channel): equal keys stay in channel order
+    int cnt[3] = {0, 0, 0};
+    for (int i = 0; i < b->n; i++) cnt[order[i].first >> 60]++;
+    int pos = 0;
+    for (int k = 0; k < 3; k++) { b->kind_first[k] = pos; b->kind_slots[k] = ((cnt[k] + 7) / 8) * 8; pos += b->kind_slots[k]; }
+    b->sched.assign(pos, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});   // padding = the dummy channel
+    int at[3] = {b->kind_first[0], b->kind_first[1], b->kind_first[2]};
+    for (int i = 0; i < b->n; i++) {
+      const int c = order[i].second, k = (int)(order[i].first >> 60);
+      b->sched[at[k]++] = SlotInfo{c, b->hp[c].mode, b->hp[c].flags, 0u};
+    }
+    b->sched_dirty = false;
+    sched_rebuilt = true;
+    b->stat_sched_rebuilds++;
+  }
 }
 
 int flush(asdr_batch *b, hipStream_t stream) {
   const int rows = b->n + 1;
+  std::vector<int32_t> changed;
+  bool bulk = false, sched_rebuilt = false;
+  flush_host(b, changed, bulk, sched_rebuilt);
+  bool uploaded = false;
   if (b->agc_pool_dirty) {
     const size_t need = b->agc_pool.size() * ASDR_AGC_TAB_ROW;
     if (need > b->agc_tab_cap) {
-      HIPCHK(hipStreamSynchronize(stream));
+      HIPCHK(hipStreamSynchronize(stream));      // ordered behind every earlier launch (update waits for ev_last first)
       if (b->d_agc_tab) HIPCHK(hipFree(b->d_agc_tab));
       b->agc_tab_cap = need * 2;
       HIPCHK(hipMalloc(&b->d_agc_tab, b->agc_tab_cap * sizeof(float)));
@@ -281,22 +353,23 @@ int flush(asdr_batch *b, hipStream_t stream) {
     HIPCHK(hipStreamSynchronize(stream));  // `flat` is a temporary
     b->agc_pool_dirty = false;
   }
-  if (b->params_dirty) {
-    for (int i = 0; i < rows; i++) fill_params(b->ch[i], b->hp[i]);
-    b->any_als = false; b->any_sam = false;
-    for (int i = 0; i < b->n; i++) { b->any_als = b->any_als || b->ch[i].als_en; b->any_sam = b->any_sam || b->ch[i].mode == ASDR_SAMmode; }
-    std::vector<int32_t> order(b->n);
-    for (int i = 0; i < b->n; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t x, int32_t y) { return sched_key(b->hp[x]) < sched_key(b->hp[y]); });
-    const int n_sched = ((b->n + 7) / 8) * 8;
-    b->sched.assign(n_sched, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});
-    for (int i = 0; i < b->n; i++) b->sched[i] = SlotInfo{order[i], b->hp[order[i]].mode, b->hp[order[i]].flags, 0u};
+  if (bulk) {
     HIPCHK(hipMemcpyAsync(b->d_params, b->hp.data(), rows * sizeof(ChanParams), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(b->d_sched, b->sched.data(), n_sched * sizeof(SlotInfo), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));  // host vectors may be rewritten by the next setter
-    b->params_dirty = false;
+    uploaded = true;
+  } else {
+    for (size_t i = 0; i < changed.size();) {   // one copy per run of consecutive rows
+      size_t j = i + 1;
+      while (j < changed.size() && changed[j] == changed[j - 1] + 1) j++;
+      HIPCHK(hipMemcpyAsync(b->d_params + changed[i], &b->hp[changed[i]], (j - i) * sizeof(ChanParams), hipMemcpyHostToDevice, stream));
+      uploaded = true;
+      i = j;
+    }
   }
+  if (sched_rebuilt) {
+    HIPCHK(hipMemcpyAsync(b->d_sched, b->sched.data(), b->sched.size() * sizeof(SlotInfo), hipMemcpyHostToDevice, stream));
+    uploaded = true;
+  }
+  if (uploaded) HIPCHK(hipStreamSynchronize(stream));  // the host rows may be rewritten by the next setter + flush
   return 0;
 }
 
@@ -305,7 +378,7 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
   a.params = b->d_params; a.small = b->d_small;
   a.nb_hist = b->d_nb_hist; a.nb_mask = b->d_nb_mask; a.hil_q = b->d_hil_q; a.hil_i = b->d_hil_i;
   a.als_x = b->d_als_x; a.als_w = b->d_als_w; a.agc_tab = b->d_agc_tab;
-  a.sched = b->d_sched; a.n_sched = ((b->n + 7) / 8) * 8; a.n_channels = b->n;
+  a.sched = b->d_sched; a.n_sched = 0; a.n_channels = b->n;   // the launcher sets the sub-range
   a.taps = b->taps_on ? b->d_taps : nullptr;
   a.nb_phase = b->nb_phase;
   a.k = b->k;
@@ -313,24 +386,26 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
 
 int apply_resets(asdr_batch *b, hipStream_t stream) {
   if (!b->reset_pending) return 0;
-  const int rows = b->n + 1;
-  HIPCHK(hipMemcpyAsync(b->d_reset, b->reset.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  UpdateArgs a;
-  fill_args(b, a);
-  if (asdr_launch_reset(&a, b->d_reset, rows, stream) != 0) return fail("reset kernel launch failed");
-  HIPCHK(hipStreamSynchronize(stream));
-  std::fill(b->reset.begin(), b->reset.end(), 0u);
-  b->reset_pending = false;
+  const int lo = b->reset_lo < 0 ? 0 : b->reset_lo, hi = b->reset_hi > b->n ? b->n : b->reset_hi;
+  if (hi >= lo) {   // only the rows that carry bits travel and get a workgroup
+    const int cnt = hi - lo + 1;
+    HIPCHK(hipMemcpyAsync(b->d_reset + lo, b->reset.data() + lo, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    UpdateArgs a;
+    fill_args(b, a);
+    if (asdr_launch_reset(&a, b->d_reset, lo, cnt, stream) != 0) return fail("reset kernel launch failed");
+    HIPCHK(hipStreamSynchronize(stream));
+    std::fill(b->reset.begin() + lo, b->reset.begin() + hi + 1, 0u);
+  }
+  b->reset_pending = false; b->reset_lo = 0x7fffffff; b->reset_hi = -1;
   return 0;
 }
 
 template <typename F>
 void each(asdr_batch *b, int ch, F f) {
   if (!b) return;
-  if (ch == ASDR_ALL) { for (int i = 0; i < b->n; i++) f(i, b->ch[i]); }
-  else if (ch >= 0 && ch < b->n) f(ch, b->ch[ch]);
+  if (ch == ASDR_ALL) { for (int i = 0; i < b->n; i++) f(i, b->ch[i]); b->all_dirty = true; }
+  else if (ch >= 0 && ch < b->n) { f(ch, b->ch[ch]); mark_dirty(b, ch); }
   else return;
-  b->params_dirty = true;
 }
 const Chan *get(asdr_batch *b, int ch) { return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr; }
 
@@ -376,11 +451,12 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_hil_i, rows * 256 * sizeof(float));
     alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
     alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
-    alloc((void **)&b->d_sched, (rows + 8) * sizeof(SlotInfo));
+    alloc((void **)&b->d_sched, (rows + 32) * sizeof(SlotInfo));   // three sub-ranges, each padded to a whole wave
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
     if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
+    if (ok && hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) ok = false;
     if (ok && asdr_kernels_upload_tables() != 0) ok = false;
     if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
   }
@@ -410,9 +486,12 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
 
   b->ch.assign(rows, Chan());
   b->hp.resize(rows);
+  memset(b->hp.data(), 0, rows * sizeof(ChanParams));
+  b->dirty_flag.assign(rows, 0);
   b->reset.assign(rows, ASDR_R_ALL);
+  b->reset_lo = 0; b->reset_hi = (int)rows - 1;
   for (size_t i = 0; i < rows; i++) chan_init(b, (int)i);  // constructor -> init()
-  b->params_dirty = true; b->reset_pending = true;
+  b->all_dirty = true; b->sched_dirty = true; b->reset_pending = true;
   return b;
 }
 
@@ -427,6 +506,7 @@ void asdr_destroy(asdr_batch_t *b) {
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev_last) hipEventDestroy(b->ev_last);
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -445,6 +525,9 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   if ((((uintptr_t)dI | (uintptr_t)dQ | (uintptr_t)dOut) & 15u) != 0) return fail("I/Q/out device pointers must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
   HIPCHK(hipSetDevice(b->device));
+  // one stream at a time per batch: a call on another stream first waits for the previous call's kernels (state in HBM is
+  // read-modify-written by every launch)
+  if (b->ev_last_valid && stream != b->last_stream) HIPCHK(hipStreamWaitEvent(stream, b->ev_last, 0));
   if (flush(b, stream) != 0) return -1;
   if (apply_resets(b, stream) != 0) return -1;
   UpdateArgs a;
@@ -454,8 +537,14 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = b->ev0, e1 = b->ev1;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   HIPCHK(hipEventRecord(e0, stream));
-  if (asdr_launch_update(&a, b->any_als ? ASDR_KERNEL_ALS : (b->any_sam ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN), stream) != 0) return fail("update kernel launch failed");
+  for (int k = 0; k < 3; k++) {   // up to three sub-ranges of the sorted schedule, one per kernel instantiation
+    if (b->kind_slots[k] == 0) continue;
+    a.sched = b->d_sched + b->kind_first[k]; a.n_sched = b->kind_slots[k];
+    if (asdr_launch_update(&a, k, stream) != 0) return fail("update kernel launch failed");
+  }
   HIPCHK(hipEventRecord(e1, stream));
+  HIPCHK(hipEventRecord(b->ev_last, stream));
+  b->ev_last_valid = true;
   b->ev_valid = (e0 == b->ev0);
   b->last_stream = stream;
   b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
@@ -634,7 +723,7 @@ void asdr_setAudioFilter(asdr_batch_t *b, int ch, int filter) {  // .cpp:298-311
     if (filter == ASDR_audioBypass) c.af_en = false;
     else if (filter >= ASDR_audioAM && filter <= ASDR_audio3300) {
       c.audio_table = ASDR_TBL_AUDIO_BASE + filter;
-      b->reset[i] |= ASDR_R_AF; b->reset_pending = true;
+      mark_reset(b, i, ASDR_R_AF);
     }
     c.current_filter = (int16_t)filter;
   });
@@ -643,7 +732,7 @@ int asdr_getAudioFilter(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); r
 
 // ---- ALS ---------------------------------------------------------------------------------------------------
 void asdr_enableALSfilter(asdr_batch_t *b, int ch) {  // .cpp:384-391
-  each(b, ch, [&](int i, Chan &c) { c.als_en = true; b->reset[i] |= ASDR_R_ALS; b->reset_pending = true; });
+  each(b, ch, [&](int i, Chan &c) { c.als_en = true; mark_reset(b, i, ASDR_R_ALS); });
 }
 void asdr_disableALSfilter(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_en = false; }); }
 void asdr_setALSfilterNotch(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.als_notch = true; }); }
@@ -709,15 +798,15 @@ float asdr_getAGClookup(asdr_batch_t *b, int ch, int i) {
 
 // ---- noise blanker ------------------------------------------------------------------------------------------
 void asdr_enableNoiseBlanker(asdr_batch_t *b, int ch) {
-  each(b, ch, [&](int i, Chan &c) { c.nb_en = true; b->reset[i] |= ASDR_R_NB; b->reset_pending = true; });
+  each(b, ch, [&](int i, Chan &c) { c.nb_en = true; mark_reset(b, i, ASDR_R_NB); });
 }
 void asdr_disableNoiseBlanker(asdr_batch_t *b, int ch) { each(b, ch, [&](int, Chan &c) { c.nb_en = false; }); }
 void asdr_setNoiseBlankerThreshold(asdr_batch_t *b, int ch, float r) {
-  each(b, ch, [&](int i, Chan &c) { c.nb_threshold = r; b->reset[i] |= ASDR_R_NB; b->reset_pending = true; });
+  each(b, ch, [&](int i, Chan &c) { c.nb_threshold = r; mark_reset(b, i, ASDR_R_NB); });
 }
 void asdr_setNoiseBlankerThresholdDb(asdr_batch_t *b, int ch, float db) {  // .cpp:671-674
   const float r = powf(10.0f, (float)((double)db / 20.0));
-  each(b, ch, [&](int i, Chan &c) { c.nb_threshold = r; b->reset[i] |= ASDR_R_NB; b->reset_pending = true; });
+  each(b, ch, [&](int i, Chan &c) { c.nb_threshold = r; mark_reset(b, i, ASDR_R_NB); });
 }
 int asdr_NoiseBlankerisEnabled(asdr_batch_t *b, int ch) { const Chan *c = get(b, ch); return c ? c->nb_en : 0; }
 
@@ -741,6 +830,23 @@ int asdr_read_status(asdr_batch_t *b, int32_t *agc_active, int32_t *nb_detected,
     if (sam_locked) sam_locked[i] = (all[i].status & ASDR_S_PLL_LOCKED) != 0;
     if (sam_frequency) sam_frequency[i] = all[i].pll_freq;
     if (am_carrier) am_carrier[i] = all[i].am_carrier;
+  }
+  return 0;
+}
+
+int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
+  if (!b) return fail("null batch");
+  if (b->device != ASDR_NO_DEVICE) return fail("asdr_control_plane_flush is for control-plane-only batches: a device batch flushes in update()");
+  std::vector<int32_t> changed;
+  bool bulk = false, rebuilt = false;
+  flush_host(b, changed, bulk, rebuilt);
+  b->agc_pool_dirty = false;
+  if (stats) {
+    stats[0] = b->stat_rows_refilled; stats[1] = rebuilt ? 1 : 0;
+    stats[2] = (long long)(b->kind_slots[0] / 8) | ((long long)(b->kind_slots[1] / 8) << 21) | ((long long)(b->kind_slots[2] / 8) << 42);
+    long long live = 0;
+    for (uint32_t r : b->agc_refs) live += (r != 0);
+    stats[3] = live;
   }
   return 0;
 }

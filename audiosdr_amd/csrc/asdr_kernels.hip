@@ -334,11 +334,11 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // =====================================================================================================
 // Pointwise stages work LDS-resident in two 8-sample pieces per lane (`#pragma unroll 1` loops), so no 16-wide
 // register array is carried from one stage to the next.
-template <int STRIDE, bool HAS_ALS, bool SINE_LDS>
+template <int STRIDE, bool HAS_ALS, bool HAS_SAM>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds) {
   const int lane = threadIdx.x, c8 = lane >> 3, s8_ = lane & 7;
-  float *const sine = SINE_LDS ? lds + 8 * STRIDE : nullptr;
-  if (SINE_LDS) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
+  float *const sine = HAS_SAM ? lds + 8 * STRIDE : nullptr;
+  if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   const int4 slot = *reinterpret_cast<const int4 *>(a.sched + blockIdx.x * 8 + c8);   // {channel, mode, flags, -}
   const int ch_ = slot.x;
@@ -351,7 +351,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const uint32_t pflags = (uint32_t)slot.z;
   const bool is_ssb = (mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                       (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode);
-  const bool is_am = (mode == ASDR_AMmode), is_sam = (mode == ASDR_SAMmode);
+  // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
+  const bool is_am = (mode == ASDR_AMmode), is_sam = HAS_SAM && (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
   const bool nb_en = pflags & ASDR_F_NB_EN, af_en = pflags & ASDR_F_AF_EN, agc_en = pflags & ASDR_F_AGC_EN;
   const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
@@ -679,7 +680,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         WAVE_SYNC();
         if (nb_en) {
-          const float trans_dn[7] = {(float)0.933, (float)0.750, (float)0.500, (float)0.250, (float)0.067, 0.0f, 0.0f};
+          // {.933, .750, .500, .250, .067, 0, 0} (:608) read from the code table: as literals the compiler parks them in VGPRs
+          // for the whole kernel
+          float trans_dn[7];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) trans_dn[q] = c_mask_val[2 + q];
+          trans_dn[5] = 0.0f; trans_dn[6] = 0.0f;
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             if (ev[j + 1] == 1.0f && ev[j] == 0.0f) {
@@ -717,8 +723,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float hq_o[16], hq_m[16], idl[16];   // this lane's pieces (samples kF + 32m + j at [4m + j]) of the Hilbert rings
     DEFINE_ALL_PATHS(hq_o, 16); DEFINE_ALL_PATHS(hq_m, 16); DEFINE_ALL_PATHS(idl, 16);
     // Hilbert rings (two previous blocks of mixed Q, the delayed I) are requested before the pipeline: 48 registers that the
-    // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer
-    if (is_ssb) {
+    // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer.  (Not in the SAM-only
+    // instantiation: its only SSB channels are the padding slots, and it has no registers to spare at 3 waves/SIMD.)
+    constexpr bool RING_PREFETCH = !HAS_SAM || HAS_ALS;
+    if (RING_PREFETCH && is_ssb) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         load4(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m);
@@ -746,7 +754,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
     // ---- SAM: quadrature PLL, AudioSDR.cpp:688-749 (sequential per channel) ---------------------------------
     bool pll_locked = false;
-    if (ABL_ON(ABL_SAM) && __any(is_sam)) {
+    if (HAS_SAM && ABL_ON(ABL_SAM) && __any(is_sam)) {
       if (is_sam && lead) {
         float y_re = S->pll_y_re, y_im = S->pll_y_im, prev_filt = S->pll_prev_filt;
         float d0 = S->pll_d0, d1 = S->pll_d1, phase_est = S->pll_phase_est, pfreq = S->pll_freq;
@@ -767,8 +775,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
             phase_est = (float)((double)phase_est + (double)(filt + prev_filt) / 2.0);
             prev_filt = filt;
-            while ((double)phase_est >= PI_D) phase_est -= two_pi;
-            while ((double)phase_est < -PI_D) phase_est += two_pi;
+            // The reference's two unbounded wrap loops (:735-736) never end once |phase_est| is so large that
+            // phase_est -+ twoPI == phase_est (infinity; or a huge step): there they stall one Teensy instance, here they would
+            // hang the wave and with it the batch.  Defined difference: at most ASDR_PLL_WRAP_MAX turns per sample, then the
+            // estimate restarts at 0.  A physical loop-filter step is below pi, i.e. one turn; the oracle mirrors the bound.
+            { int turns = 0;
+              while ((double)phase_est >= PI_D && turns < ASDR_PLL_WRAP_MAX) { phase_est -= two_pi; ++turns; }
+              while ((double)phase_est < -PI_D && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
+              if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f; }
             y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
             y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
             pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
@@ -894,6 +908,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // history sample x[m'] with m' = B + k (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1,
         // 256: this block) is stored at L[XP + m' - 1] (x[0] is never used): natural order shifted by one float, so
         // that every operand pair (x[odd], x[odd+1]) of the FIR is an 8-byte-aligned LDS pair.
+        if (!RING_PREFETCH) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            load4(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m);
+            load4(hq_ring + (hs ^ 1u) * 128 + 32 * m, hq_m + 4 * m);
+          }
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -926,15 +947,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const int p0 = k0 >> 1;
 #pragma unroll 1
         for (int kc = 0; kc < 8; ++kc) {
-          v2f dw[16], uw[16];   // dw[t] = PX[120 + p0 - 8kc + t], uw[t] = PX[p0 + 8kc + t]  (t = 0..14 used)
+          v2f dw[15], uw[15];   // dw[t] = PX[120 + p0 - 8kc + t], uw[t] = PX[p0 + 8kc + t]  (t = 0..14)
           const float4 *dp = reinterpret_cast<const float4 *>(PX + 120 + p0 - 8 * kc);
           const float4 *up = reinterpret_cast<const float4 *>(PX + p0 + 8 * kc);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
+          for (int q = 0; q < 7; ++q) {
             const float4 d4 = dp[q], u4 = up[q];
             dw[2 * q] = (v2f){d4.x, d4.y}; dw[2 * q + 1] = (v2f){d4.z, d4.w};
             uw[2 * q] = (v2f){u4.x, u4.y}; uw[2 * q + 1] = (v2f){u4.z, u4.w};
           }
+          dw[14] = PX[120 + p0 - 8 * kc + 14]; uw[14] = PX[p0 + 8 * kc + 14];
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) {
             const float hk = c_hilbert[8 * kc + kk];
@@ -952,6 +974,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();   // all history reads done: rows W0/W1 may overwrite the start of the history
       TL(9);
+      if (!RING_PREFETCH && is_ssb) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
+      }
       if (is_ssb) {   // the FIR owns 16 contiguous outputs per lane; the combine works on the float-row pieces: hand over through W1
 #pragma unroll
         for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
@@ -1016,7 +1042,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         store8(L + W0 + kA + 64 * h, vq);
       }
     }
-    if (!is_ssb && !is_am && !is_sam) {   // unknown mode: the reference re-processes stale audio; we emit silence
+    if (!is_ssb && !is_am && mode != ASDR_SAMmode) {   // unknown mode: the reference re-processes stale audio; we emit silence
       const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       store8(L + W0 + kA, z); store8(L + W0 + kA + 64, z);
     }
@@ -1240,9 +1266,9 @@ extern "C" __global__ __launch_bounds__(64, 2) void asdr_update_kernel_als(Updat
 }
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
-extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int n_rows) {
-  const int ch = blockIdx.x;
-  if (ch >= n_rows) return;
+extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {
+  if ((int)blockIdx.x >= n_rows) return;
+  const int ch = first_row + blockIdx.x;
   const uint32_t r = reset_bits[ch];
   if (!r) return;
   const int t = threadIdx.x;   // 128 threads
@@ -1280,7 +1306,7 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, hipStream_t 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int n_rows, hipStream_t stream) {
-  hipLaunchKernelGGL(asdr_reset_kernel, dim3(n_rows), dim3(128), 0, stream, *a, d_reset_bits, n_rows);
+extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream) {
+  hipLaunchKernelGGL(asdr_reset_kernel, dim3(n_rows), dim3(128), 0, stream, *a, d_reset_bits, first_row, n_rows);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

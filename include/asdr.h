@@ -179,6 +179,13 @@ float asdr_last_kernel_ms(asdr_batch_t *b);
  * elapsed milliseconds of each launch into ms[0..return-1] and disarms. */
 int asdr_kernel_timing_begin(asdr_batch_t *b, int max_launches);
 int asdr_kernel_timing_end(asdr_batch_t *b, float *ms, int cap);
+/* Control-plane introspection.  A setter only marks the channels it touched; the next update() refills and uploads those
+ * parameter rows and rebuilds the wave schedule only if a touched channel's schedule key (kernel instantiation, mode, enables,
+ * tables) changed.  asdr_control_plane_flush() runs the HOST half of that step on a control-plane-only batch (ASDR_NO_DEVICE;
+ * refused on a device batch, where the next update() does it) and reports what it did:
+ *   stats[0] = parameter rows refilled, stats[1] = 1 if the schedule was rebuilt, stats[2] = waves in the plain / SAM / ALS
+ *   sub-ranges packed as plain | sam << 21 | als << 42, stats[3] = AGC gain tables alive in the pool. */
+int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]);
 /* Library / build identification string (contains "gfx950"). */
 const char *asdr_version(void);
 

@@ -22,6 +22,8 @@
 
 #include "../audiosdr_amd/csrc/asdr_tables.h"
 
+#define AO_PLL_WRAP_MAX 64 /* == ASDR_PLL_WRAP_MAX of the product */
+
 #if defined(FLT_EVAL_METHOD) && FLT_EVAL_METHOD != 0
 #error "oracle requires FLT_EVAL_METHOD == 0 (SSE2 float/double arithmetic)"
 #endif
@@ -313,8 +315,15 @@ static void sam_demod(asdr_oracle_t *o) {
     /* .cpp:732: `phase_est += (a + b)/2.0` : float sum, double halve, double add, float store */
     o->pll_phase_est = (float)((double)o->pll_phase_est + (double)(o->pll_filt + o->pll_prev_filt) / 2.0);
     o->pll_prev_filt = o->pll_filt;
-    while (o->pll_phase_est >= AO_PI) o->pll_phase_est -= two_pi;  /* compare vs double PI */
-    while (o->pll_phase_est < -AO_PI) o->pll_phase_est += two_pi;
+    { /* .cpp:735-736 are two unbounded loops (compare vs double PI) that never end once phase_est -+ twoPI == phase_est
+       * (an infinite estimate): a Teensy instance would stall.  The product bounds them (ASDR_PLL_WRAP_MAX turns per sample, then
+       * phase_est = 0: DESIGN.md 4, defined differences) and the oracle mirrors that bound so the two stay comparable; a
+       * physical loop-filter step is below pi, i.e. at most one turn, so the bound never acts on a finite signal. */
+      int turns = 0;
+      while (o->pll_phase_est >= AO_PI && turns < AO_PLL_WRAP_MAX) { o->pll_phase_est -= two_pi; turns++; }
+      while (o->pll_phase_est < -AO_PI && turns < AO_PLL_WRAP_MAX) { o->pll_phase_est += two_pi; turns++; }
+      if (turns >= AO_PLL_WRAP_MAX) o->pll_phase_est = 0.0f;
+    }
     o->pll_y_re = ao_cos_f32(o->pll_phase_est);
     o->pll_y_im = ao_sin_f32(o->pll_phase_est);
     o->pll_freq = o->alpha_freq * o->pll_freq + o->beta_freq * (o->pll_filt * o->f_conv);

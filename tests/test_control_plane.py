@@ -159,3 +159,58 @@ def test_capture_sink_needs_a_device(A):
         b.update_device_strided(16, 16, 16, 1, 1, 1)
     assert b.capture_position == 0 and b.capture_capacity == 0
     b.close()
+
+
+def test_incremental_control_plane(A):
+    """A setter marks only the channels it touched: the flush before the next launch refills those parameter rows and rebuilds
+    the wave schedule only when a touched channel's schedule key changed (asdr_host.cpp flush_host).  One per-channel
+    setOutputGain on a 1,048,576-channel batch must cost well under 50 us of host time."""
+    import time
+    n = 1 << 20
+    b = A.AudioSDRBatch(n, device=-1)
+    st = b.control_plane_flush()                      # first flush: everything
+    assert st["rows_refilled"] == n + 1 and st["schedule_rebuilt"] and st["waves_plain"] == n // 8 and st["waves_sam"] == 0
+    st = b.control_plane_flush()                      # nothing changed
+    assert st["rows_refilled"] == 0 and not st["schedule_rebuilt"]
+    b.setOutputGain(0.7, ch=17)                       # not part of the schedule key
+    t0 = time.perf_counter()
+    st = b.control_plane_flush()
+    dt = time.perf_counter() - t0
+    assert st["rows_refilled"] == 1 and not st["schedule_rebuilt"]
+    best = dt
+    for i in range(20):
+        b.setOutputGain(0.5 + i * 0.01, ch=17 + i)
+        t0 = time.perf_counter(); b.control_plane_flush(); best = min(best, time.perf_counter() - t0)
+    assert best < 50e-6, "flush after one per-channel setter took %.1f us" % (best * 1e6)
+    b.setInputGain(2.0, ch=5); b.setInputGain(3.0, ch=5); b.setNoiseBlankerThreshold(2.0, ch=9)   # same row twice: listed once
+    st = b.control_plane_flush()
+    assert st["rows_refilled"] == 2 and not st["schedule_rebuilt"]
+    b.setDemodMode(A.SAMmode, ch=123)                 # kernel instantiation of one channel changes: schedule rebuilt
+    st = b.control_plane_flush()
+    assert st["rows_refilled"] == 1 and st["schedule_rebuilt"]
+    assert st["waves_sam"] == 1 and st["waves_plain"] == (n - 1 + 7) // 8 and st["waves_als"] == 0
+    b.enableALSfilter(ch=123); b.enableALSfilter(ch=7)   # ALS wins over SAM for the instantiation
+    st = b.control_plane_flush()
+    assert st["schedule_rebuilt"] and st["waves_sam"] == 0 and st["waves_als"] == 1 and st["waves_plain"] == (n - 2 + 7) // 8
+    b.setMute(1)                                      # broadcast: bulk refill, flags are part of the key
+    st = b.control_plane_flush()
+    assert st["rows_refilled"] == n + 1 and st["schedule_rebuilt"]
+    b.close()
+
+
+def test_agc_table_pool_is_shared_and_compacted(A):
+    """Distinct (threshold, slope, knee) triples share one 130-entry table each (hash lookup, reference counts); tables no
+    channel uses any more are dropped at a flush once they outnumber the live ones (a knob sweep must not leak)."""
+    b = A.AudioSDRBatch(4096, device=-1)
+    assert b.control_plane_flush()["agc_tables_alive"] == 1
+    for i in range(200):                              # a UI knob sweep on all channels
+        b.setAGCthreshold(-60.0 + 0.1 * i)
+    st = b.control_plane_flush()
+    assert st["agc_tables_alive"] == 2                # the swept setting + the padding channel's power-on table
+    for c in range(64):                               # per-channel settings: one table per distinct triple
+        b.setAGCslope(0.1 + 0.01 * (c % 8), ch=c)
+    st = b.control_plane_flush()
+    assert st["agc_tables_alive"] == 9                # 8 slopes (one of them the batch-wide setting) + the padding channel's
+    v = [b.getAGClookup(100, ch=c) for c in range(16)]
+    assert v[0] == v[8] and v[1] == v[9] and v[0] != v[1]
+    b.close()
