@@ -107,7 +107,8 @@ def load_library(path=None):
     L.asdr_getAGClookup.argtypes = [vp, _i, _i]; L.asdr_getAGClookup.restype = _f
     i32p, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
     L.asdr_read_status.argtypes = [vp, i32p, i32p, i32p, fp, fp]; L.asdr_read_status.restype = _i
-    L.asdr_control_plane_flush.argtypes = [vp, C.POINTER(C.c_longlong)]; L.asdr_control_plane_flush.restype = _i
+    if path is None or hasattr(L, "asdr_control_plane_flush"):   # older builds timed by tools/ablate.py lack it
+        L.asdr_control_plane_flush.argtypes = [vp, C.POINTER(C.c_longlong)]; L.asdr_control_plane_flush.restype = _i
     L.asdr_enable_taps.argtypes = [vp, _i]; L.asdr_enable_taps.restype = _i
     L.asdr_read_taps.argtypes = [vp, fp]; L.asdr_read_taps.restype = _i
     L.asdr_kernel_timing_begin.argtypes = [vp, _i]; L.asdr_kernel_timing_begin.restype = _i

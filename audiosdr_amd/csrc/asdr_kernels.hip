@@ -342,13 +342,22 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
   const int4 slot = *reinterpret_cast<const int4 *>(a.sched + blockIdx.x * 8 + c8);   // {channel, mode, flags, -}
   const int ch_ = slot.x;
+#ifdef ASDR_ASSUME_UNIFORM
+  const bool valid = true;
+#else
   const bool valid = ch_ < a.n_channels;
+#endif
   const int loff_ = c8 * STRIDE;
 #define P (*Pp)
   const ChainConsts K = a.k;
 
+#ifdef ASDR_ASSUME_UNIFORM
+  const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane(slot.y);
+  const uint32_t pflags = (uint32_t)__builtin_amdgcn_readfirstlane(slot.z);
+#else
   const uint32_t mode = (uint32_t)slot.y;
   const uint32_t pflags = (uint32_t)slot.z;
+#endif
   const bool is_ssb = (mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                       (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode);
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
@@ -538,21 +547,46 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int u = 0; u < 2; ++u) { const float bmu = L[NB_B + u]; L[NB_B + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
         float bm[8];
         load8(L + NB_B + 2, bm);
+        // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
+        // wrap `t < 0 ? t + twoPI : t` is a sign-mask select (v_ashrrev + v_bfi, no compare -> VCC -> select hazard): the phase
+        // chain is add, shift, select.  (t = -0.0 cannot occur: the phase is never -0.0 and x + y = -0.0 needs both -0.0.)
+        if (__all(minc < 0.0f)) {
 #pragma unroll 1
-        for (int c = 0; c < 16; ++c) {   // both chains in ONE basic block: the scheduler interleaves them
-          float av[8], bn[8], pv[8];
-          load8(L + NB_B + 2 + 8 * (c + 1), bn);   // next chunk, a step ahead
+          for (int c = 0; c < 16; c += 2) {
+            float av[8], bn[8], pv[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u];
-            pv[u] = phase;
-            const float t = phase + minc, tw = t + wrapv;
-            phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+            for (int half = 0; half < 2; ++half) {
+              float *cur = half ? bn : bm, *nxt = half ? bm : bn;   // ping-pong: no register copies
+              load8(L + NB_B + 2 + 8 * (c + half + 1), nxt);      // next chunk, a step ahead
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u];
+                pv[u] = phase;
+                const float t = phase + minc, tw = t + two_pi;
+                const uint32_t tb = __float_as_uint(t), m = (uint32_t)((int32_t)tb >> 31);
+                phase = __uint_as_float((__float_as_uint(tw) & m) | (tb & ~m));
+              }
+              store8(L + PH + 8 * (c + half), pv);
+              store8(L + NB_B + 2 + 8 * (c + half), av);
+            }
           }
-          store8(L + PH + 8 * c, pv);
-          store8(L + NB_B + 2 + 8 * c, av);
+        } else {
+#pragma unroll 1
+          for (int c = 0; c < 16; ++c) {
+            float av[8], bn[8], pv[8];
+            load8(L + NB_B + 2 + 8 * (c + 1), bn);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) bm[u] = bn[u];
+            for (int u = 0; u < 8; ++u) {
+              av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u];
+              pv[u] = phase;
+              const float t = phase + minc, tw = t + wrapv;
+              phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+            }
+            store8(L + PH + 8 * c, pv);
+            store8(L + NB_B + 2 + 8 * c, av);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bm[u] = bn[u];
+          }
         }
 #pragma unroll 1
         for (int c = 16; c < 22; ++c) {
@@ -1102,10 +1136,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const float al_a = P.agc_alpha_att, be_a = P.agc_beta_att, al_r = P.agc_alpha_rel, be_r = P.agc_beta_rel;
         const uint32_t hang = P.agc_hang_count;
         float gv = -1.0f;   // envelope value governing the current gain; -1 = no update yet in this block
+        // Per sample (:412-428): attack if |x| > envelope, else release unless the hang counter runs.  A lone wave issues one
+        // instruction per ~4.5 cycles whatever the dependency depth (tools/ubench/dep_chain.hip), so the loop is written for the
+        // fewest instructions: only the taken branch's alpha / beta are selected, then one mul, mul, add.
+        float x[8];
+        load8(L + AGC_GV, x);
 #pragma unroll 1
         for (int i = 0; i < ASDR_N; i += 8) {
-          float x[8], gvv[8];
-          load8(L + AGC_GV + i, x);
+          float xn[8], gvv[8];
+          load8(L + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);   // next chunk, a step ahead
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const float av = is_am ? am_clamped : x[u];   // AM: twice the carrier level stands in for |x| (:407-409)
@@ -1117,10 +1156,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             const bool upd = att || idle;
             old_abs = upd ? v_new : old_abs;
             gv = upd ? v_new : gv;
-            hc = att ? hang : (idle ? 0u : hc - 1u);
+            hc = att ? hang : __builtin_elementwise_sub_sat(hc, 1u);   // 0 stays 0
             gvv[u] = gv;
           }
           store8(L + AGC_GV + i, gvv);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = xn[u];
         }
         S->agc_old_abs = old_abs;
         S->agc_hang_counter = hc;
