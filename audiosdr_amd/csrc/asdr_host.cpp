@@ -21,7 +21,7 @@
 #include "asdr_tables.h"
 
 extern "C" int asdr_kernels_upload_tables(void);
-extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, hipStream_t stream);
+extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
 
 namespace {
@@ -122,7 +122,9 @@ struct asdr_batch {
   int reset_lo = 0x7fffffff, reset_hi = -1;   // rows with pending reset bits lie in [reset_lo, reset_hi]
   // The sorted schedule is launched as up to three sub-ranges, one per kernel instantiation (plain / SAM / ALS), each padded
   // to whole waves with the dummy channel: one SAM or ALS channel no longer demotes the whole batch.
-  int kind_first[3] = {0, 0, 0}, kind_slots[3] = {0, 0, 0};
+  // Inside a sub-range the whole waves of each key group come first ("uniform" waves: 8 real channels, one key -> the
+  // instantiation with scalar mode/flag tests), then the groups' remainders packed together ("mixed").
+  int kind_first[3] = {0, 0, 0}, kind_slots[3] = {0, 0, 0}, kind_uniform_slots[3] = {0, 0, 0};
   // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
   long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
   // device
@@ -317,15 +319,33 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     std::vector<std::pair<uint64_t, int32_t>> order(b->n);
     for (int i = 0; i < b->n; i++) order[i] = {sched_key(b->hp[i]), i};
     std::sort(order.begin(), order.end());   // (key, channel): equal keys stay in channel order
-    int cnt[3] = {0, 0, 0};
-    for (int i = 0; i < b->n; i++) cnt[order[i].first >> 60]++;
+    // per kernel kind: slots of the whole waves of every key group, and of the groups' remainders
+    int uni[3] = {0, 0, 0}, rem[3] = {0, 0, 0};
+    for (int i = 0; i < b->n;) {
+      int j = i + 1;
+      while (j < b->n && order[j].first == order[i].first) j++;
+      const int k = (int)(order[i].first >> 60), g = j - i;
+      uni[k] += g / 8 * 8; rem[k] += g % 8;
+      i = j;
+    }
     int pos = 0;
-    for (int k = 0; k < 3; k++) { b->kind_first[k] = pos; b->kind_slots[k] = ((cnt[k] + 7) / 8) * 8; pos += b->kind_slots[k]; }
+    for (int k = 0; k < 3; k++) {
+      b->kind_first[k] = pos; b->kind_uniform_slots[k] = uni[k]; b->kind_slots[k] = uni[k] + ((rem[k] + 7) / 8) * 8;
+      pos += b->kind_slots[k];
+    }
     b->sched.assign(pos, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});   // padding = the dummy channel
-    int at[3] = {b->kind_first[0], b->kind_first[1], b->kind_first[2]};
-    for (int i = 0; i < b->n; i++) {
-      const int c = order[i].second, k = (int)(order[i].first >> 60);
-      b->sched[at[k]++] = SlotInfo{c, b->hp[c].mode, b->hp[c].flags, 0u};
+    int at_u[3], at_m[3];
+    for (int k = 0; k < 3; k++) { at_u[k] = b->kind_first[k]; at_m[k] = b->kind_first[k] + uni[k]; }
+    for (int i = 0; i < b->n;) {
+      int j = i + 1;
+      while (j < b->n && order[j].first == order[i].first) j++;
+      const int k = (int)(order[i].first >> 60), g = j - i, whole = g / 8 * 8;
+      for (int t = 0; t < g; t++) {
+        const int c = order[i + t].second;
+        int &at = (t < whole) ? at_u[k] : at_m[k];
+        b->sched[at++] = SlotInfo{c, b->hp[c].mode, b->hp[c].flags, 0u};
+      }
+      i = j;
     }
     b->sched_dirty = false;
     sched_rebuilt = true;
@@ -539,8 +559,15 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   HIPCHK(hipEventRecord(e0, stream));
   for (int k = 0; k < 3; k++) {   // up to three sub-ranges of the sorted schedule, one per kernel instantiation
     if (b->kind_slots[k] == 0) continue;
-    a.sched = b->d_sched + b->kind_first[k]; a.n_sched = b->kind_slots[k];
-    if (asdr_launch_update(&a, k, stream) != 0) return fail("update kernel launch failed");
+    const int nu = b->kind_uniform_slots[k], nm = b->kind_slots[k] - nu;
+    if (nu > 0) {
+      a.sched = b->d_sched + b->kind_first[k]; a.n_sched = nu;
+      if (asdr_launch_update(&a, k, 1, stream) != 0) return fail("update kernel launch failed");
+    }
+    if (nm > 0) {
+      a.sched = b->d_sched + b->kind_first[k] + nu; a.n_sched = nm;
+      if (asdr_launch_update(&a, k, 0, stream) != 0) return fail("update kernel launch failed");
+    }
   }
   HIPCHK(hipEventRecord(e1, stream));
   HIPCHK(hipEventRecord(b->ev_last, stream));

@@ -334,7 +334,9 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // =====================================================================================================
 // Pointwise stages work LDS-resident in two 8-sample pieces per lane (`#pragma unroll 1` loops), so no 16-wide
 // register array is carried from one stage to the next.
-template <int STRIDE, bool HAS_ALS, bool HAS_SAM>
+// UNIFORM: the host guarantees that the wave's 8 slots are real channels with the same schedule key (mode, enable flags, tables):
+// mode and flags become scalars, every `if (nb_en)` / `if (is_ssb)` a scalar branch instead of an EXEC-mask region.
+template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds) {
   const int lane = threadIdx.x, c8 = lane >> 3, s8_ = lane & 7;
   float *const sine = HAS_SAM ? lds + 8 * STRIDE : nullptr;
@@ -342,22 +344,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
   const int4 slot = *reinterpret_cast<const int4 *>(a.sched + blockIdx.x * 8 + c8);   // {channel, mode, flags, -}
   const int ch_ = slot.x;
-#ifdef ASDR_ASSUME_UNIFORM
-  const bool valid = true;
-#else
-  const bool valid = ch_ < a.n_channels;
-#endif
+  const bool valid = UNIFORM || (ch_ < a.n_channels);
   const int loff_ = c8 * STRIDE;
 #define P (*Pp)
   const ChainConsts K = a.k;
 
-#ifdef ASDR_ASSUME_UNIFORM
-  const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane(slot.y);
-  const uint32_t pflags = (uint32_t)__builtin_amdgcn_readfirstlane(slot.z);
-#else
-  const uint32_t mode = (uint32_t)slot.y;
-  const uint32_t pflags = (uint32_t)slot.z;
-#endif
+  const uint32_t mode = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.y) : (uint32_t)slot.y;
+  const uint32_t pflags = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.z) : (uint32_t)slot.z;
   const bool is_ssb = (mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                       (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode);
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
@@ -1289,22 +1282,24 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #undef P
 }
 
-// no channel of the batch has the ALS filter or the SAM PLL enabled: 388 floats of LDS per channel, sine table through L1
-// (12,416 B per wave -> 12 waves/CU at 168 VGPRs)
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
-  asdr_update_body<ASDR_STRIDE, false, false>(a, lds);
-}
-// some channel is in SAM mode: the PLL's per-sample dependent sin/cos lookups read a per-wave LDS copy of the table
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel_sam(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE + 260];
-  asdr_update_body<ASDR_STRIDE, false, true>(a, lds);
-}
-// some channel uses the ALS filter: 516 floats per channel (256-sample ALS history + 128 taps in LDS)
-extern "C" __global__ __launch_bounds__(64, 2) void asdr_update_kernel_als(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * 516 + 260];
-  asdr_update_body<516, true, true>(a, lds);
-}
+// Three instantiations by what a channel needs (the host launches each sub-range of its sorted schedule with its own):
+//   plain  no ALS filter, not SAM: 388 floats of LDS per channel, sine table through L1, no PLL code (12,416 B per wave ->
+//          12 waves/CU at <= 168 VGPRs)
+//   sam    SAM mode: the PLL's per-sample dependent sin/cos lookups read a per-wave LDS copy of the table
+//   als    ALS filter enabled (any mode): 516 floats per channel (256-sample ALS history + 128 taps in LDS)
+// each in a form for waves whose 8 slots share one schedule key (uniform: scalar mode / flag tests) and a general form for the
+// remainders of the key groups and the padding.
+#define ASDR_KERNEL(name, lds_floats, bounds, stride, als, sam, uni)                                            \
+  extern "C" __global__ __launch_bounds__(64, bounds) void name(UpdateArgs a) {                                 \
+    __shared__ __attribute__((aligned(16))) float lds[lds_floats];                                              \
+    asdr_update_body<stride, als, sam, uni>(a, lds);                                                            \
+  }
+ASDR_KERNEL(asdr_update_kernel, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, true)
+ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, false)
+ASDR_KERNEL(asdr_update_kernel_sam, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, true)
+ASDR_KERNEL(asdr_update_kernel_sam_mixed, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, false)
+ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, 2, 516, true, true, true)
+ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, 2, 516, true, true, false)
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
 extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {
@@ -1337,13 +1332,13 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
   }
 }
 
-// `variant`: ASDR_KERNEL_PLAIN / _SAM (a channel runs the PLL: sine table in LDS) / _ALS (a channel runs the ALS filter: larger LDS)
-extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, hipStream_t stream) {
+// `variant`: ASDR_KERNEL_PLAIN / _SAM / _ALS; `uniform`: every wave of the sub-range holds 8 real channels with one schedule key
+extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (variant == ASDR_KERNEL_ALS) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a);
-  else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3(n_waves), dim3(64), 0, stream, *a);
-  else hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  if (variant == ASDR_KERNEL_ALS) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_SAM) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_sam_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
