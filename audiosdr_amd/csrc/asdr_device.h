@@ -89,6 +89,8 @@ typedef struct {
  * in-class initialisers evaluate them (AudioSDR.h:164-168, 238-239, 249-284) */
 typedef struct {
   double inv_two_pi_d;          /* RN(1.0 / (double)two_pi_f): reciprocal for the exact sine-index division */
+  double half_pi_d;             /* PI / 2.0 (Arduino PI, double): cos_f32's phase offset, AudioSDR.h:376 -- a kernel argument so that it
+                                   lives in SGPRs (as a literal the compiler parks it in a VGPR pair for the whole kernel) */
   float if_center;              /* 6890.0f */
   float two_pi_f;               /* (float)(2.0*PI) */
   float half_pi_f;              /* (float)(0.5*PI) */
@@ -102,6 +104,18 @@ typedef struct {
   int32_t ch;
   uint32_t mode, flags, pad_;
 } SlotInfo;
+
+/* Local-oscillator cache: the mixer's phase sequence and its sin/cos pairs depend only on (carried phase, increment).  When all
+ * channels of wave 0 share one pair (receivers configured together), that wave also computes the NEXT block's 128 pairs and
+ * leaves them here; a wave of the next launch whose channels carry exactly that phase and increment (compared bit for bit)
+ * reads the pairs instead of running the 128-step recurrence and the table lookups itself.  Two entries: a launch reads
+ * one and (wave 0) writes the other.  A miss just takes the per-wave path. */
+typedef struct {
+  uint32_t key_phase, key_inc;   /* bit patterns of the phase at the start of the block and of the increment */
+  float phase_end;               /* phase after the block's 128 samples */
+  uint32_t pad_;
+  float c[ASDR_N], s[ASDR_N];    /* cos_f32 / sin_f32 of the block's 128 phases (AudioSDR.h:358-377) */
+} LoEntry;
 
 typedef struct {
   const ChanParams *params;
@@ -118,6 +132,9 @@ typedef struct {
   int16_t *out;
   int32_t n_blocks;       /* blocks per channel processed by this call */
   uint32_t nb_phase;      /* blocks processed by the batch so far, mod 3: oldest slot of every channel's blanker ring */
+  LoEntry *lo_cache;      /* [2] */
+  uint32_t lo_parity;     /* entry this launch reads; wave 0 of the launch with lo_write set fills the other one */
+  uint32_t lo_write;
   int32_t in_stride;      /* row stride of I and Q in blocks (>= n_blocks; == n_blocks for the packed layout) */
   int32_t out_stride;     /* row stride of out in blocks (a capture row holds many calls' worth) */
   float *taps;            /* NULL or [ASDR_N_TAPS][n_channels][128] */

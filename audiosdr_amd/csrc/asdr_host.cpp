@@ -149,6 +149,8 @@ struct asdr_batch {
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_last = nullptr;  // recorded after every launch: a call on another stream waits for it first
   bool ev_last_valid = false;
+  LoEntry *d_lo = nullptr;       // local-oscillator cache, 2 entries (asdr_device.h)
+  uint32_t lo_parity = 0;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
   ChainConsts k{};
 };
@@ -401,6 +403,7 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
   a.sched = b->d_sched; a.n_sched = 0; a.n_channels = b->n;   // the launcher sets the sub-range
   a.taps = b->taps_on ? b->d_taps : nullptr;
   a.nb_phase = b->nb_phase;
+  a.lo_cache = b->d_lo; a.lo_parity = b->lo_parity; a.lo_write = 0;
   a.k = b->k;
 }
 
@@ -473,6 +476,8 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
     alloc((void **)&b->d_sched, (rows + 32) * sizeof(SlotInfo));   // three sub-ranges, each padded to a whole wave
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
+    alloc((void **)&b->d_lo, 2 * sizeof(LoEntry));
+    if (ok && hipMemset(b->d_lo, 0xFF, 2 * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
     if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
@@ -487,6 +492,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   k.two_pi_f = (float)(2.0 * kPI);
   k.half_pi_f = (float)(0.5 * kPI);
   k.inv_two_pi_d = 1.0 / (double)k.two_pi_f;
+  k.half_pi_d = kPI / 2.0;
   k.phase_inc_unit = k.two_pi_f / kFs;
   k.nb_alpha = 0.995f;
   k.nb_beta = (float)(1.0 - (double)k.nb_alpha);
@@ -521,7 +527,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipSetDevice(b->device);
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
-                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture};
+                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture};
   for (void *p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -557,15 +563,18 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = b->ev0, e1 = b->ev1;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   HIPCHK(hipEventRecord(e0, stream));
+  bool first_launch = true;
   for (int k = 0; k < 3; k++) {   // up to three sub-ranges of the sorted schedule, one per kernel instantiation
     if (b->kind_slots[k] == 0) continue;
     const int nu = b->kind_uniform_slots[k], nm = b->kind_slots[k] - nu;
     if (nu > 0) {
       a.sched = b->d_sched + b->kind_first[k]; a.n_sched = nu;
+      a.lo_write = first_launch ? 1u : 0u; first_launch = false;   // wave 0 of the first launch fills the other cache entry
       if (asdr_launch_update(&a, k, 1, stream) != 0) return fail("update kernel launch failed");
     }
     if (nm > 0) {
       a.sched = b->d_sched + b->kind_first[k] + nu; a.n_sched = nm;
+      a.lo_write = first_launch ? 1u : 0u; first_launch = false;
       if (asdr_launch_update(&a, k, 0, stream) != 0) return fail("update kernel launch failed");
     }
   }
@@ -575,6 +584,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   b->ev_valid = (e0 == b->ev0);
   b->last_stream = stream;
   b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
+  b->lo_parity ^= 1u;
   return 0;
 }
 

@@ -135,8 +135,8 @@ __device__ __forceinline__ float sin_f32(const float *sine, float phase, float t
   return sin_lut(sine, sin_index(phase, two_pi, inv_two_pi));
 }
 // AudioSDR.h:375-377
-__device__ __forceinline__ float cos_f32(const float *sine, float phase, float two_pi, double inv_two_pi) {
-  return sin_f32(sine, (float)((double)phase + PI_D / 2.0), two_pi, inv_two_pi);
+__device__ __forceinline__ float cos_f32(const float *sine, float phase, float two_pi, double inv_two_pi, double half_pi_d) {
+  return sin_f32(sine, (float)((double)phase + half_pi_d), two_pi, inv_two_pi);
 }
 // AudioSDR.h:384-408
 __device__ __forceinline__ float approx_atan(float z) {
@@ -369,6 +369,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int s8 = s8_; asm volatile("" : "+v"(s8));
     int loff = loff_; asm volatile("" : "+v"(loff));
     int ch = ch_; asm volatile("" : "+v"(ch));
+    int lane_i = lane; asm volatile("" : "+v"(lane_i));   // for the rarely taken paths: their addresses must not be hoisted (and spilled)
     const ChanParams *Pp = row_ptr(a.params, (uint32_t)ch * (uint32_t)sizeof(ChanParams));
     ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
     float *L = lds + loff;
@@ -437,13 +438,23 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     // mixer phase and increment (AudioSDR.h:508-512) of the modes whose mixer does not depend on this block's data
     const bool mix_early = is_ssb || is_am;
-    float mphase = 0.0f, minc = 0.0f;
+    float mphase = 0.0f, minc = 0.0f, mphase_end = 0.0f;   // mphase_end: valid on the lead lanes once the sequence has been computed
     if (mix_early) {
       mphase = is_ssb ? S->phase_ssb : S->phase_am;
       const float fs = is_ssb ? -P.freq_shift : -K.if_center;
       minc = fs * K.phase_inc_unit;
     }
     bool ph_ready = false;   // this channel's phase sequence is in its PH row
+    // local-oscillator cache (asdr_device.h LoEntry): hit = every channel of the wave starts this block with exactly the cached
+    // phase and increment -> no recurrence, no table lookups, the pairs are read from the entry
+    const LoEntry *lo_rd = a.lo_cache + (a.lo_parity & 1u);
+    bool lo_hit = false;
+    if (blk == 0) {
+      const uint32_t kp = lo_rd->key_phase, ki = lo_rd->key_inc;
+      lo_hit = __all(mix_early && __float_as_uint(mphase) == kp && __float_as_uint(minc) == ki);
+    }
+    const float lo_end = lo_rd->phase_end;
+    if (lo_hit && lead) { if (is_ssb) S->phase_ssb = lo_end; else S->phase_am = lo_end; }
 
     // ---- input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
     // With a blanker in the wave, the blanker's delay line is kept as RAW int16 samples plus the gains that were in
@@ -540,6 +551,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int u = 0; u < 2; ++u) { const float bmu = L[NB_B + u]; L[NB_B + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
         float bm[8];
         load8(L + NB_B + 2, bm);
+        int c_tail = 0;   // first chunk of the average-only loop below
+        if (!lo_hit) {
+        c_tail = 16;
         // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
         // wrap `t < 0 ? t + twoPI : t` is a sign-mask select (v_ashrrev + v_bfi, no compare -> VCC -> select hazard): the phase
         // chain is add, shift, select.  (t = -0.0 cannot occur: the phase is never -0.0 and x + y = -0.0 needs both -0.0.)
@@ -581,8 +595,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             for (int u = 0; u < 8; ++u) bm[u] = bn[u];
           }
         }
+        }   // !lo_hit
 #pragma unroll 1
-        for (int c = 16; c < 22; ++c) {
+        for (int c = c_tail; c < 22; ++c) {
           float av[8], bn[8];
           load8(L + NB_B + 2 + 8 * ((c < 21) ? c + 1 : c), bn);
 #pragma unroll
@@ -592,9 +607,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           for (int u = 0; u < 8; ++u) bm[u] = bn[u];
         }
         if (nb_en) S->nb_avg = avg;
-        if (mix_early) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
+        if (mix_early && !lo_hit) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
+        mphase_end = phase;
       }
-      ph_ready = mix_early;
+      ph_ready = mix_early && !lo_hit;
       WAVE_SYNC();
       // parallel: threshold test mag[t] > avg[t]*threshold (:628) on the lanes that hold the envelopes
       uint32_t fm = 0u, ft = 0u;   // detection flags: bit 8h + j <-> this lane's sample kA + 64h + j of the middle block / bit j <-> 64 + kA + j of the oldest
@@ -647,8 +663,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           };
           const uint32_t cnt_t = (uint32_t)__builtin_popcount(ft), cnt_a = (uint32_t)__builtin_popcount(fm & 0xFFu), cnt_b = (uint32_t)__builtin_popcount(fm >> 8);
           const uint32_t inc_t = scan8(cnt_t), inc_a = scan8(cnt_a), inc_b = scan8(cnt_b);
-          const int last = (lane & ~7) | 7;
-          const uint32_t tot_t = (uint32_t)__shfl((int)inc_t, last), tot_a = (uint32_t)__shfl((int)inc_a, last), tot_m = tot_a + (uint32_t)__shfl((int)inc_b, last);
+          const int last = (lane_i & ~7) | 7;
+          const uint32_t tot_t = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)inc_t), tot_a = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)inc_a),
+                         tot_m = tot_a + (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)inc_b);   // the totals sit on the channel's last lane
           uint8_t *cbw = reinterpret_cast<uint8_t *>(Li + NB_CB);
           uint32_t run = inc_t - cnt_t;
           if (own_tail) {
@@ -749,7 +766,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float *hq_ring = row_ptr(a.hil_q, (uint32_t)ch * 1024u + 4u * (uint32_t)kF);
     float hq_o[16], hq_m[16], idl[16];   // this lane's pieces (samples kF + 32m + j at [4m + j]) of the Hilbert rings
     DEFINE_ALL_PATHS(hq_o, 16); DEFINE_ALL_PATHS(hq_m, 16); DEFINE_ALL_PATHS(idl, 16);
-    // Hilbert rings (two previous blocks of mixed Q, the delayed I) are requested before the pipeline: 48 registers that the
+    // Hilbert ring (two previous blocks of mixed Q) is requested before the pipeline: 32 registers that the
     // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer.  (Not in the SAM-only
     // instantiation: its only SSB channels are the padding slots, and it has no registers to spare at 3 waves/SIMD.)
     constexpr bool RING_PREFETCH = !HAS_SAM || HAS_ALS;
@@ -758,7 +775,6 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       for (int m = 0; m < 4; ++m) {
         load4(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m);
         load4(hq_ring + (hs ^ 1u) * 128 + 32 * m, hq_m + 4 * m);
-        load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);   // delayed I = previous block's mixed I (:111)
       }
     }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
@@ -810,7 +826,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               while ((double)phase_est >= PI_D && turns < ASDR_PLL_WRAP_MAX) { phase_est -= two_pi; ++turns; }
               while ((double)phase_est < -PI_D && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
               if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f; }
-            y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
+            y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);
             y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
             pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
             locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
@@ -838,7 +854,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // channels that fall back to the envelope detector (their mixer runs only if the PLL ends the block unlocked, :132), when
     // no channel of the wave runs the blanker, and after the blanker's general path (whose scratch overlays the PH row).
     if (do_mix && !mix_early) { mphase = S->phase_am; minc = -K.if_center * K.phase_inc_unit; }
-    const bool ph_seq = do_mix && !ph_ready;
+    const bool ph_seq = do_mix && !ph_ready && !lo_hit;
     if (__any(ph_seq)) {
       if (ph_seq && lead) {
         float phase = mphase;
@@ -857,6 +873,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           store8(L + PH + i, pv);
         }
         if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
+        mphase_end = phase;
       }
       WAVE_SYNC();
     }
@@ -868,10 +885,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const uint32_t inc_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(minc));
     const bool mix_uni = __all(do_mix && __float_as_uint(mphase) == ph_first && __float_as_uint(minc) == inc_first);
     TL(6);
-    if (ABL_ON(ABL_MIX) && mix_uni) {   // sin/cos of the wave's 128 phases, two per lane
+    if (ABL_ON(ABL_MIX) && mix_uni && !lo_hit) {   // sin/cos of the wave's 128 phases, two per lane
       const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane);
-      const float c0 = cos_f32(sine, p2.x, two_pi, K.inv_two_pi_d), s0 = sin_f32(sine, p2.x, two_pi, K.inv_two_pi_d);
-      const float c1 = cos_f32(sine, p2.y, two_pi, K.inv_two_pi_d), s1 = sin_f32(sine, p2.y, two_pi, K.inv_two_pi_d);
+      const float c0 = cos_f32(sine, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d), s0 = sin_f32(sine, p2.x, two_pi, K.inv_two_pi_d);
+      const float c1 = cos_f32(sine, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d), s1 = sin_f32(sine, p2.y, two_pi, K.inv_two_pi_d);
       *reinterpret_cast<float2 *>(lds + STRIDE + PH + 2 * lane) = make_float2(c0, c1);
       *reinterpret_cast<float2 *>(lds + 2 * STRIDE + PH + 2 * lane) = make_float2(s0, s1);
       WAVE_SYNC();
@@ -883,14 +900,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       for (int m = 0; m < 4; ++m) {
         float cc[4], sn[4], vi[4], vq[4], mi[4], mq[4];
         load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
-        if (mix_uni) {
+        if (lo_hit) {
+          load4(lo_rd->c + kF + 32 * m, cc); load4(lo_rd->s + kF + 32 * m, sn);
+        } else if (mix_uni) {
           load4(lds + STRIDE + PH + kF + 32 * m, cc); load4(lds + 2 * STRIDE + PH + kF + 32 * m, sn);
         } else {
           float ph[4];
           load4(L + PH + kF + 32 * m, ph);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            cc[j] = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
+            cc[j] = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d, K.half_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
             if ((j & 1) == 1) SCHED_FENCE();
           }
         }
@@ -1001,7 +1020,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();   // all history reads done: rows W0/W1 may overwrite the start of the history
       TL(9);
-      if (!RING_PREFETCH && is_ssb) {
+      if (is_ssb) {   // delayed I = previous block's mixed I (:111); requested here: the FIR has no registers to spare for it
 #pragma unroll
         for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
       }
@@ -1277,6 +1296,37 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     if (lead) S->status = status;
     WAVE_SYNC();
+    // Wave 0 of the designated launch leaves the NEXT block's local-oscillator pairs in the other cache entry (LoEntry).
+    if (a.lo_write && blockIdx.x == 0 && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
+      LoEntry *lo_wr = a.lo_cache + ((a.lo_parity & 1u) ^ 1u);
+      const float start = lo_hit ? lo_end : __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mphase_end)));
+      const float inc = __uint_as_float(inc_first);
+      if (lane == 0) {
+        float phase = start;
+        const bool up = !(inc < 0.0f);
+        const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
+        const uint32_t flip = up ? 0u : 0x80000000u;
+#pragma unroll 1
+        for (int i = 0; i < ASDR_N; i += 8) {
+          float pv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            pv[u] = phase;
+            const float t = phase + inc, tw = t + wrapv;
+            phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+          }
+          store8(lds + PH + i, pv);
+        }
+        lo_wr->key_phase = __float_as_uint(start); lo_wr->key_inc = __float_as_uint(inc); lo_wr->phase_end = phase;
+      }
+      WAVE_SYNC();
+      const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane_i);
+      const float c0 = cos_f32(sine, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d), s0 = sin_f32(sine, p2.x, two_pi, K.inv_two_pi_d);
+      const float c1 = cos_f32(sine, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d), s1 = sin_f32(sine, p2.y, two_pi, K.inv_two_pi_d);
+      *reinterpret_cast<float2 *>(lo_wr->c + 2 * lane_i) = make_float2(c0, c1);
+      *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s0, s1);
+      WAVE_SYNC();
+    }
     TL(15);
   }
 #undef P
