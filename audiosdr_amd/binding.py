@@ -53,7 +53,7 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 # every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
-            "asdr_read_status", "asdr_control_plane_flush", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
+            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
             "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_update_device_strided", "asdr_capture_open",
             "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read"] +
@@ -107,6 +107,8 @@ def load_library(path=None):
     L.asdr_getAGClookup.argtypes = [vp, _i, _i]; L.asdr_getAGClookup.restype = _f
     i32p, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
     L.asdr_read_status.argtypes = [vp, i32p, i32p, i32p, fp, fp]; L.asdr_read_status.restype = _i
+    if path is None or hasattr(L, "asdr_get_chain_constants"):
+        L.asdr_get_chain_constants.argtypes = [vp, _i, C.POINTER(C.c_float)]; L.asdr_get_chain_constants.restype = C.c_uint
     if path is None or hasattr(L, "asdr_control_plane_flush"):   # older builds timed by tools/ablate.py lack it
         L.asdr_control_plane_flush.argtypes = [vp, C.POINTER(C.c_longlong)]; L.asdr_control_plane_flush.restype = _i
     L.asdr_enable_taps.argtypes = [vp, _i]; L.asdr_enable_taps.restype = _i
@@ -201,6 +203,12 @@ class AudioSDRBatch:
         out = np.empty(int(n_blocks) * BLOCK, dtype=np.int16)
         self._chk(self._L.asdr_capture_read(self._h, int(ch), int(first_block), int(n_blocks), out.ctypes.data_as(C.POINTER(C.c_int16))))
         return out
+
+    def chain_constants(self, ch=0):
+        """(hang count of `ch`, the 12 derived float constants of include/asdr.h asdr_get_chain_constants)."""
+        out = (C.c_float * 12)()
+        hang = int(self._L.asdr_get_chain_constants(self._h, int(ch), out))
+        return hang, np.array(list(out), dtype=np.float32)
 
     def control_plane_flush(self):
         """Host half of the pre-launch flush on a control-plane-only batch: what the next update() would refill / rebuild."""

@@ -871,6 +871,18 @@ int asdr_read_status(asdr_batch_t *b, int32_t *agc_active, int32_t *nb_detected,
   return 0;
 }
 
+unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]) {
+  if (!b) return 0;
+  const ChainConsts &k = b->k;
+  if (out) {
+    const float v[12] = {k.pll_b0, k.pll_b1, k.pll_a1, k.pll_alpha_freq, k.pll_beta_freq, k.pll_f_conv, k.pll_lock_lo, k.pll_lock_hi,
+                         k.two_pi_f, k.half_pi_f, k.phase_inc_unit, k.nb_beta};
+    memcpy(out, v, sizeof v);
+  }
+  const Chan *c = get(b, ch);
+  return c ? c->agc_hang_count : 0u;
+}
+
 int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
   if (!b) return fail("null batch");
   if (b->device != ASDR_NO_DEVICE) return fail("asdr_control_plane_flush is for control-plane-only batches: a device batch flushes in update()");

@@ -769,7 +769,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Hilbert ring (two previous blocks of mixed Q) is requested before the pipeline: 32 registers that the
     // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer.  (Not in the SAM-only
     // instantiation: its only SSB channels are the padding slots, and it has no registers to spare at 3 waves/SIMD.)
-    constexpr bool RING_PREFETCH = !HAS_SAM || HAS_ALS;
+    constexpr bool RING_PREFETCH = !HAS_SAM;
     if (RING_PREFETCH && is_ssb) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -1348,8 +1348,8 @@ ASDR_KERNEL(asdr_update_kernel, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE,
 ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, false)
 ASDR_KERNEL(asdr_update_kernel_sam, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, true)
 ASDR_KERNEL(asdr_update_kernel_sam_mixed, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, false)
-ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, 2, 516, true, true, true)
-ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, 2, 516, true, true, false)
+ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_WAVES_PER_EU, 516, true, true, true)      /* LDS allows 9 waves/CU: needs 3 on one SIMD */
+ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_WAVES_PER_EU, 516, true, true, false)
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
 extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {

@@ -186,6 +186,12 @@ int asdr_kernel_timing_end(asdr_batch_t *b, float *ms, int cap);
  *   stats[0] = parameter rows refilled, stats[1] = 1 if the schedule was rebuilt, stats[2] = waves in the plain / SAM / ALS
  *   sub-ranges packed as plain | sam << 21 | als << 42, stats[3] = AGC gain tables alive in the pool. */
 int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]);
+/* The derived constants the hot path runs with, as the host evaluated them from the reference's in-class initialisers and
+ * setters (AudioSDR.h:238-239, 249-284; AudioSDR.cpp:447, 563-566) -- exposed so that an independent restatement of that
+ * arithmetic can pin them bit for bit (tests/test_control_plane_independent.py).  out[12] = pll_b0, pll_b1, pll_a1, alpha_freq,
+ * beta_freq, f_conv, lock_freq_low, lock_freq_high, twoPI, halfPI, twoPI/AUDIO_SAMPLE_RATE_EXACT, 1 - nb alpha; returns the
+ * AGC hang count (samples) of channel `ch` (0 for a bad channel). */
+unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]);
 /* Library / build identification string (contains "gfx950"). */
 const char *asdr_version(void);
 

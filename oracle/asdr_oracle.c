@@ -658,6 +658,11 @@ float ao_getAGCbetaRelease(const asdr_oracle_t *o) { return o->agc_beta_rel; }
 float ao_getAGClookup(const asdr_oracle_t *o, int i) { return (i >= 0 && i < 130) ? o->agc_table[i] : 0.0f; }
 float ao_getAGCstaticGain(const asdr_oracle_t *o) { return o->agc_static_gain; }
 uint32_t ao_getAGChangCount(const asdr_oracle_t *o) { return o->agc_hang_count; }
+void ao_get_chain_constants(const asdr_oracle_t *o, float out[12]) {
+  const float v[12] = {o->pll_b0, o->pll_b1, o->pll_a1, o->alpha_freq, o->beta_freq, o->f_conv, o->lock_lo, o->lock_hi,
+                       o->two_pi_f, o->half_pi_f, o->two_pi_f / AO_FS, o->nb_beta};
+  memcpy(out, v, sizeof v);
+}
 
 void ao_enableNoiseBlanker(asdr_oracle_t *o) { o->nb_enabled = 1; nb_reset(o); }
 void ao_disableNoiseBlanker(asdr_oracle_t *o) { o->nb_enabled = 0; }

@@ -169,6 +169,8 @@ double ao_bench_run(int config, int n_channels, int n_blocks, const int16_t *I, 
  * block for every channel); on = 1 makes the oracle model that documented choice so the GPU tests can pin it. */
 void ao_set_unknown_mode_silence(asdr_oracle_t *o, int on);
 
+/* same 12 derived constants as the product's asdr_get_chain_constants (include/asdr.h) */
+void ao_get_chain_constants(const asdr_oracle_t *o, float out[12]);
 /* bench.py host calibration: seconds for `iters` iterations of a register-only float loop on each of n_threads threads */
 double ao_spin_calibrate(int n_threads, long iters);
 

@@ -60,6 +60,7 @@ def lib():
     L.ao_destroy.argtypes = [vp]
     L.ao_enable_taps.argtypes = [vp, i32]
     L.ao_set_unknown_mode_silence.argtypes = [vp, i32]
+    L.ao_get_chain_constants.argtypes = [vp, fp]
     L.ao_tap.argtypes = [vp, i32]
     L.ao_tap.restype = fp
     L.ao_update.argtypes = [vp, i16p, i16p, i16p]
@@ -157,6 +158,11 @@ class OracleSDR:
         self._h = self._L.ao_create()
         if taps:
             self._L.ao_enable_taps(self._h, 1)
+
+    def chain_constants(self):
+        out = np.zeros(12, dtype=np.float32)
+        self._L.ao_get_chain_constants(self._h, _fp(out))
+        return int(self._L.ao_getAGChangCount(self._h)), out
 
     def set_unknown_mode_silence(self, on=True):
         """Model the HIP product's defined difference for unknown mode values (oracle/asdr_oracle.h)."""
