@@ -148,6 +148,8 @@ struct asdr_batch {
   size_t tev_used = 0;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_last = nullptr;  // recorded after every launch: a call on another stream waits for it first
+  hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // helper streams for concurrent sub-range launches
+  hipEvent_t ev_fork = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_last_valid = false;
   LoEntry *d_lo = nullptr;       // local-oscillator cache, 2 entries (asdr_device.h)
   uint32_t lo_parity = 0;
@@ -482,6 +484,11 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) ok = false;
+    if (ok && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
+    for (int i = 0; i < 5 && ok; i++) {
+      if (hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking) != hipSuccess) ok = false;
+      if (ok && hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess) ok = false;
+    }
     if (ok && asdr_kernels_upload_tables() != 0) ok = false;
     if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
   }
@@ -533,6 +540,8 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev_last) hipEventDestroy(b->ev_last);
+  if (b->ev_fork) hipEventDestroy(b->ev_fork);
+  for (int i = 0; i < 5; i++) { if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]); if (b->aux[i]) hipStreamDestroy(b->aux[i]); }
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -563,20 +572,26 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = b->ev0, e1 = b->ev1;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   HIPCHK(hipEventRecord(e0, stream));
-  bool first_launch = true;
-  for (int k = 0; k < 3; k++) {   // up to three sub-ranges of the sorted schedule, one per kernel instantiation
+  // Up to six sub-ranges of the sorted schedule (3 kernel instantiations x {uniform, mixed waves}).  They touch disjoint channels,
+  // so they run CONCURRENTLY: the first on the caller's stream, the others on the batch's helper streams, forked behind an
+  // event and joined before the call's end marker -- launched back to back on one stream the short ones (a handful of waves of
+  // the slowest instantiation) would each add a whole wave lifetime to the step.  Heaviest instantiation first.
+  struct Sub { int kind, uniform, first, slots; };
+  Sub subs[6]; int n_sub = 0;
+  for (int k = 2; k >= 0; k--) {
     if (b->kind_slots[k] == 0) continue;
     const int nu = b->kind_uniform_slots[k], nm = b->kind_slots[k] - nu;
-    if (nu > 0) {
-      a.sched = b->d_sched + b->kind_first[k]; a.n_sched = nu;
-      a.lo_write = first_launch ? 1u : 0u; first_launch = false;   // wave 0 of the first launch fills the other cache entry
-      if (asdr_launch_update(&a, k, 1, stream) != 0) return fail("update kernel launch failed");
-    }
-    if (nm > 0) {
-      a.sched = b->d_sched + b->kind_first[k] + nu; a.n_sched = nm;
-      a.lo_write = first_launch ? 1u : 0u; first_launch = false;
-      if (asdr_launch_update(&a, k, 0, stream) != 0) return fail("update kernel launch failed");
-    }
+    if (nu > 0) subs[n_sub++] = Sub{k, 1, b->kind_first[k], nu};
+    if (nm > 0) subs[n_sub++] = Sub{k, 0, b->kind_first[k] + nu, nm};
+  }
+  if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
+  for (int i = 0; i < n_sub; i++) {
+    hipStream_t s = (i == 0) ? stream : b->aux[i - 1];
+    if (i > 0) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
+    a.sched = b->d_sched + subs[i].first; a.n_sched = subs[i].slots;
+    a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
+    if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
+    if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }
   }
   HIPCHK(hipEventRecord(e1, stream));
   HIPCHK(hipEventRecord(b->ev_last, stream));

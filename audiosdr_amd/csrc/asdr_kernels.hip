@@ -1213,12 +1213,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
         float *gx = a.als_x + (size_t)ch * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
         if (als_en) {
-#pragma unroll 1
+          float tx[16], tw[16], tn[16];   // all eight row loads in flight together
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { load4(gx + 32 * m, tx + 4 * m); load4(gw + 32 * m, tw + 4 * m); load4(L + W0 + kF + 32 * m, tn + 4 * m); }
+#pragma unroll
           for (int m = 0; m < 4; ++m) {
-            float t[4];
-            load4(gx + 32 * m, t); store4(L + ALS_X + kF + 32 * m, t);            // previous block
-            load4(L + W0 + kF + 32 * m, t); store4(L + ALS_X + 128 + kF + 32 * m, t); store4(gx + 32 * m, t);
-            load4(gw + 32 * m, t); store4(L + ALS_W + kF + 32 * m, t);
+            store4(L + ALS_X + kF + 32 * m, tx + 4 * m);            // previous block
+            store4(L + ALS_X + 128 + kF + 32 * m, tn + 4 * m); store4(gx + 32 * m, tn + 4 * m);
+            store4(L + ALS_W + kF + 32 * m, tw + 4 * m);
           }
         }
         WAVE_SYNC();
@@ -1348,8 +1350,11 @@ ASDR_KERNEL(asdr_update_kernel, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE,
 ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, false)
 ASDR_KERNEL(asdr_update_kernel_sam, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, true)
 ASDR_KERNEL(asdr_update_kernel_sam_mixed, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, false)
-ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_WAVES_PER_EU, 516, true, true, true)      /* LDS allows 9 waves/CU: needs 3 on one SIMD */
-ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_WAVES_PER_EU, 516, true, true, false)
+#ifndef ASDR_ALS_WAVES_PER_EU
+#define ASDR_ALS_WAVES_PER_EU 3   /* LDS allows 9 waves/CU: needs 3 on one SIMD */
+#endif
+ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true)
+ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false)
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
 extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {

@@ -61,8 +61,30 @@ def run(rounds=5, n_ch=65536):
             continue
         L = A.binding.load_library(p)
         h = L.asdr_create(n_ch, 0)
-        L.asdr_setDemodMode(h, -1, 1)
-        L.asdr_enableAudioFilter(h, -1)
+        cfg = os.environ.get("ABLATE_CFG", "c2")
+        if cfg == "c3":      # SAM + PLL (BASELINE config 3 settings)
+            L.asdr_setDemodMode(h, -1, 5); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0); L.asdr_enableAudioFilter(h, -1); L.asdr_setAudioFilter(h, -1, 0)
+        elif cfg == "c4":    # mixed modes + ALS (BASELINE config 4 settings)
+            for c in range(n_ch):
+                L.asdr_setDemodMode(h, c, c % 7)
+            L.asdr_enableALSfilter(h, -1); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
+        elif cfg == "c4blk":   # the C4 mix with the seven modes in contiguous channel ranges instead of c mod 7
+            for c in range(n_ch):
+                L.asdr_setDemodMode(h, c, min(6, c * 7 // n_ch))
+            L.asdr_enableALSfilter(h, -1); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
+        elif cfg == "c4noals":
+            for c in range(n_ch):
+                L.asdr_setDemodMode(h, c, c % 7)
+            L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
+        elif cfg.startswith("als_mode"):   # one mode + ALS: where a C4 regression comes from
+            L.asdr_setDemodMode(h, -1, int(cfg[8:])); L.asdr_enableALSfilter(h, -1); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
+        elif cfg.startswith("mode"):       # one mode, C4 blanker setting, no ALS
+            L.asdr_setDemodMode(h, -1, int(cfg[4:])); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
+        elif cfg == "c5":    # WSPR receiver settings, blanker and audio filter off
+            L.asdr_disableNoiseBlanker(h, -1); L.asdr_setAGCmode(h, -1, 2); L.asdr_setDemodMode(h, -1, 6)
+        else:
+            L.asdr_setDemodMode(h, -1, 1)
+            L.asdr_enableAudioFilter(h, -1)
         libs[name] = (L, h)
     times = {k: [] for k in libs}
     VARS = libs
