@@ -145,5 +145,8 @@ typedef struct {
 #define ASDR_KERNEL_PLAIN 0
 #define ASDR_KERNEL_SAM 1
 #define ASDR_KERNEL_ALS 2
+#ifndef ASDR_SAM_WAVES
+#define ASDR_SAM_WAVES 4
+#endif   /* waves (x 8 channels) per workgroup of the SAM instantiation: one of them runs every channel's PLL */
 
 #endif /* ASDR_DEVICE_H_ */

@@ -329,7 +329,8 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
       const int k = (int)(order[i].first >> 60), g = j - i;
-      uni[k] += g / 8 * 8; rem[k] += g % 8;
+      if (k == ASDR_KERNEL_SAM) rem[k] += g;   // the SAM instantiation has only the general form (4-wave workgroups)
+      else { uni[k] += g / 8 * 8; rem[k] += g % 8; }
       i = j;
     }
     int pos = 0;
@@ -343,7 +344,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
-      const int k = (int)(order[i].first >> 60), g = j - i, whole = g / 8 * 8;
+      const int k = (int)(order[i].first >> 60), g = j - i, whole = (k == ASDR_KERNEL_SAM) ? 0 : g / 8 * 8;
       for (int t = 0; t < g; t++) {
         const int c = order[i + t].second;
         int &at = (t < whole) ? at_u[k] : at_m[k];

@@ -329,20 +329,32 @@ template <typename T>
 __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
   return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
-#define WAVE_SYNC() __syncthreads() /* workgroup == one wave: lowers to a wave barrier + LDS/VMEM waits */
+// Hand-off between the lanes of ONE wave through LDS / HBM: outstanding memory operations drained and no code motion across it.
+// (A wave's LDS operations execute in order, so no s_barrier is needed; the multi-wave SAM instantiation uses a real
+// __syncthreads() only around its shared PLL phase.)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
 // =====================================================================================================
 // Pointwise stages work LDS-resident in two 8-sample pieces per lane (`#pragma unroll 1` loops), so no 16-wide
 // register array is carried from one stage to the next.
 // UNIFORM: the host guarantees that the wave's 8 slots are real channels with the same schedule key (mode, enable flags, tables):
 // mode and flags become scalars, every `if (nb_en)` / `if (is_ssb)` a scalar branch instead of an EXEC-mask region.
-template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM>
-__device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds) {
-  const int lane = threadIdx.x, c8 = lane >> 3, s8_ = lane & 7;
-  float *const sine = HAS_SAM ? lds + 8 * STRIDE : nullptr;
+// WAVES: waves per workgroup.  1 everywhere except the SAM instantiation (4): there the per-sample PLL recurrence -- by far the
+// longest dependent chain of the whole path, one lane per channel -- is run for all 32 channels of the workgroup by ONE wave
+// (32 lanes busy instead of 8 in each of 4 waves) while the sibling waves wait at a workgroup barrier.
+template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES>
+__device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds_wg) {
+  const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
+  const int wave_g = (int)blockIdx.x * WAVES + wave;        // this wave's index in the launched schedule sub-range
+  float *const lds = lds_wg + wave * 8 * STRIDE;            // this wave's 8 channel rows
+  const int lane = threadIdx.x & 63, c8 = lane >> 3, s8_ = lane & 7;
+  float *const sine = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : nullptr;
   if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
-  const int4 slot = *reinterpret_cast<const int4 *>(a.sched + blockIdx.x * 8 + c8);   // {channel, mode, flags, -}
+  int4 slot = make_int4(a.n_channels, 0, 0, 0);
+  if (WAVES == 1 || wave_g * 8 < a.n_sched) slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
+  else { const ChanParams *pd = a.params + a.n_channels; slot.y = (int)pd->mode; slot.z = (int)pd->flags; }   // padding wave of a multi-wave workgroup: dummy channel
   const int ch_ = slot.x;
   const bool valid = UNIFORM || (ch_ < a.n_channels);
   const int loff_ = c8 * STRIDE;
@@ -384,7 +396,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const bool lead = (s8 == 0);
 #ifdef ASDR_TIMELINE
     // profiling build (tools/timeline.py): lane 0 of a few waves timestamps the phase boundaries into the taps buffer
-    const int tl_slot = (blockIdx.x == 0) ? 0 : ((blockIdx.x == 2731) ? 1 : ((blockIdx.x == 5461) ? 2 : ((blockIdx.x == 8191) ? 3 : -1)));
+    const int tl_slot = (wave_g == 0) ? 0 : ((wave_g == 2731) ? 1 : ((wave_g == 5461) ? 2 : ((wave_g == 8191) ? 3 : -1)));
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(a.taps) + 32 * (tl_slot < 0 ? 0 : tl_slot);
 #define TL(i) do { if (a.taps != nullptr && tl_slot >= 0 && lane == 0) tl[i] = clock64(); } while (0)
     const bool tap_on = false;
@@ -529,7 +541,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       TL(2);
-      if (ABL_ON(ABL_IF)) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
+      if (ABL_ON(ABL_IF) && WAVES == 1) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
+                                            // (not in the multi-wave SAM instantiation: no registers to spare)
         if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
         const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
 #pragma unroll
@@ -797,50 +810,81 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
     // ---- SAM: quadrature PLL, AudioSDR.cpp:688-749 (sequential per channel) ---------------------------------
     bool pll_locked = false;
-    if (HAS_SAM && ABL_ON(ABL_SAM) && __any(is_sam)) {
-      if (is_sam && lead) {
-        float y_re = S->pll_y_re, y_im = S->pll_y_im, prev_filt = S->pll_prev_filt;
-        float d0 = S->pll_d0, d1 = S->pll_d1, phase_est = S->pll_phase_est, pfreq = S->pll_freq;
-        bool locked = false;
+    // One channel's 128 PLL steps on ONE lane: Lc = the channel's LDS rows, Sc = its state row.  Returns the lock flag.
+    auto pll_run = [&](float *Lc, ChanSmall *Sc) -> bool {
+      float y_re = Sc->pll_y_re, y_im = Sc->pll_y_im, prev_filt = Sc->pll_prev_filt;
+      float d0 = Sc->pll_d0, d1 = Sc->pll_d1, phase_est = Sc->pll_phase_est, pfreq = Sc->pll_freq;
+      bool locked = false;
 #pragma unroll 1
-        for (int i = 0; i < ASDR_N; i += 4) {
-          float xr[4], xi[4];
-          { const float4 r4 = *reinterpret_cast<const float4 *>(L + W0 + i), i4 = *reinterpret_cast<const float4 *>(L + W1 + i);
-            xr[0] = r4.x; xr[1] = r4.y; xr[2] = r4.z; xr[3] = r4.w; xi[0] = i4.x; xi[1] = i4.y; xi[2] = i4.z; xi[3] = i4.w; }
+      for (int i = 0; i < ASDR_N; i += 4) {
+        float xr[4], xi[4];
+        { const float4 r4 = *reinterpret_cast<const float4 *>(Lc + W0 + i), i4 = *reinterpret_cast<const float4 *>(Lc + W1 + i);
+          xr[0] = r4.x; xr[1] = r4.y; xr[2] = r4.z; xr[3] = r4.w; xi[0] = i4.x; xi[1] = i4.y; xi[2] = i4.z; xi[3] = i4.w; }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float x_re = xr[u], x_im = xi[u];
-            const float d_re = x_re * y_re + x_im * y_im;
-            const float d_im = x_im * y_re - x_re * y_im;
-            const float err = approx_atan2(d_im, d_re, K.half_pi_f);
-            d1 = d0;
-            d0 = err - K.pll_a1 * d1;
-            const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
-            phase_est = (float)((double)phase_est + (double)(filt + prev_filt) / 2.0);
-            prev_filt = filt;
-            // The reference's two unbounded wrap loops (:735-736) never end once |phase_est| is so large that
-            // phase_est -+ twoPI == phase_est (infinity; or a huge step): there they stall one Teensy instance, here they would
-            // hang the wave and with it the batch.  Defined difference: at most ASDR_PLL_WRAP_MAX turns per sample, then the
-            // estimate restarts at 0.  A physical loop-filter step is below pi, i.e. one turn; the oracle mirrors the bound.
-            { int turns = 0;
-              while ((double)phase_est >= PI_D && turns < ASDR_PLL_WRAP_MAX) { phase_est -= two_pi; ++turns; }
-              while ((double)phase_est < -PI_D && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
-              if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f; }
-            y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);
-            y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
-            pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
-            locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
-            const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
-            xr[u] = locked ? o_re : x_re;      // rotated sample while locked (:720-723), else the sample stays
-            xi[u] = locked ? o_im : x_im;
-          }
-          *reinterpret_cast<float4 *>(L + W0 + i) = make_float4(xr[0], xr[1], xr[2], xr[3]);
-          *reinterpret_cast<float4 *>(L + W1 + i) = make_float4(xi[0], xi[1], xi[2], xi[3]);
+        for (int u = 0; u < 4; ++u) {
+          const float x_re = xr[u], x_im = xi[u];
+          const float d_re = x_re * y_re + x_im * y_im;
+          const float d_im = x_im * y_re - x_re * y_im;
+          const float err = approx_atan2(d_im, d_re, K.half_pi_f);
+          d1 = d0;
+          d0 = err - K.pll_a1 * d1;
+          const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
+          phase_est = (float)((double)phase_est + (double)(filt + prev_filt) / 2.0);
+          prev_filt = filt;
+          // The reference's two unbounded wrap loops (:735-736) never end once |phase_est| is so large that
+          // phase_est -+ twoPI == phase_est (infinity; or a huge step): there they stall one Teensy instance, here they would
+          // hang the wave and with it the batch.  Defined difference: at most ASDR_PLL_WRAP_MAX turns per sample, then the
+          // estimate restarts at 0.  A physical loop-filter step is below pi, i.e. one turn; the oracle mirrors the bound.
+          // Comparisons against the double PI are comparisons against the float just above it: no float lies between them
+          // (pe >= PI_D <=> pe >= pi_up; pe < -PI_D <=> pe <= -pi_up).  The first turn is a select; further turns (never for a
+          // finite loop-filter step) run in a loop that a wave enters only if one of its lanes still needs it.
+          { const float pi_up = 3.14159274101257324f;   // RN_float(PI) > PI_D
+            const float dn = phase_est - two_pi, up = phase_est + two_pi;
+            phase_est = (phase_est >= pi_up) ? dn : ((phase_est <= -pi_up) ? up : phase_est);
+            if (__any(phase_est >= pi_up || phase_est <= -pi_up)) {
+              int turns = 1;
+              while (phase_est >= pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est -= two_pi; ++turns; }
+              while (phase_est <= -pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
+              if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f;
+            } }
+          y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);
+          y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
+          pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
+          locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
+          const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
+          xr[u] = locked ? o_re : x_re;      // rotated sample while locked (:720-723), else the sample stays
+          xi[u] = locked ? o_im : x_im;
         }
-        S->pll_y_re = y_re; S->pll_y_im = y_im; S->pll_prev_filt = prev_filt;
-        S->pll_d0 = d0; S->pll_d1 = d1; S->pll_phase_est = phase_est; S->pll_freq = pfreq;
-        status = (status & ~ASDR_S_PLL_LOCKED) | (locked ? ASDR_S_PLL_LOCKED : 0u);
-        Li[SCR0] = locked ? 1 : 0;
+        *reinterpret_cast<float4 *>(Lc + W0 + i) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+        *reinterpret_cast<float4 *>(Lc + W1 + i) = make_float4(xi[0], xi[1], xi[2], xi[3]);
+      }
+      Sc->pll_y_re = y_re; Sc->pll_y_im = y_im; Sc->pll_prev_filt = prev_filt;
+      Sc->pll_d0 = d0; Sc->pll_d1 = d1; Sc->pll_phase_est = phase_est; Sc->pll_freq = pfreq;
+      return locked;
+    };
+    if constexpr (HAS_SAM && WAVES > 1) {
+      // Every wave of the workgroup has its IF output in LDS; wave 0 runs the PLL of all 8 * WAVES channels, one per lane.
+      __syncthreads();
+      if (ABL_ON(ABL_SAM) && wave == 0 && lane_i < 8 * WAVES) {
+        const int sj = (int)blockIdx.x * WAVES * 8 + lane_i;       // schedule slot of workgroup channel lane_i
+        int chj = a.n_channels; uint32_t modej = a.params[a.n_channels].mode;
+        if (sj < a.n_sched) { const int4 sl = *reinterpret_cast<const int4 *>(a.sched + sj); chj = sl.x; modej = (uint32_t)sl.y; }
+        if (modej == ASDR_SAMmode) {
+          float *Lc = lds_wg + lane_i * STRIDE;
+          const bool lk = pll_run(Lc, row_ptr(a.small, (uint32_t)chj * (uint32_t)sizeof(ChanSmall)));
+          reinterpret_cast<int *>(Lc)[SCR0] = lk ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (is_sam) {
+        pll_locked = Li[SCR0] != 0;
+        if (lead) status = (status & ~ASDR_S_PLL_LOCKED) | (pll_locked ? ASDR_S_PLL_LOCKED : 0u);
+      }
+    } else if (HAS_SAM && ABL_ON(ABL_SAM) && __any(is_sam)) {
+      if (is_sam && lead) {
+        const bool lk = pll_run(L, S);
+        status = (status & ~ASDR_S_PLL_LOCKED) | (lk ? ASDR_S_PLL_LOCKED : 0u);
+        Li[SCR0] = lk ? 1 : 0;
       }
       WAVE_SYNC();
       if (is_sam) pll_locked = Li[SCR0] != 0;
@@ -1299,7 +1343,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (lead) S->status = status;
     WAVE_SYNC();
     // Wave 0 of the designated launch leaves the NEXT block's local-oscillator pairs in the other cache entry (LoEntry).
-    if (a.lo_write && blockIdx.x == 0 && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
+    if (a.lo_write && wave_g == 0 && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
       LoEntry *lo_wr = a.lo_cache + ((a.lo_parity & 1u) ^ 1u);
       const float start = lo_hit ? lo_end : __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mphase_end)));
       const float inc = __uint_as_float(inc_first);
@@ -1341,20 +1385,20 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 //   als    ALS filter enabled (any mode): 516 floats per channel (256-sample ALS history + 128 taps in LDS)
 // each in a form for waves whose 8 slots share one schedule key (uniform: scalar mode / flag tests) and a general form for the
 // remainders of the key groups and the padding.
-#define ASDR_KERNEL(name, lds_floats, bounds, stride, als, sam, uni)                                            \
-  extern "C" __global__ __launch_bounds__(64, bounds) void name(UpdateArgs a) {                                 \
+#define ASDR_KERNEL(name, lds_floats, bounds, stride, als, sam, uni, waves)                                     \
+  extern "C" __global__ __launch_bounds__(64 * waves, bounds) void name(UpdateArgs a) {                         \
     __shared__ __attribute__((aligned(16))) float lds[lds_floats];                                              \
-    asdr_update_body<stride, als, sam, uni>(a, lds);                                                            \
+    asdr_update_body<stride, als, sam, uni, waves>(a, lds);                                                     \
   }
-ASDR_KERNEL(asdr_update_kernel, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, true)
-ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, false)
-ASDR_KERNEL(asdr_update_kernel_sam, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, true)
-ASDR_KERNEL(asdr_update_kernel_sam_mixed, 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, false)
+ASDR_KERNEL(asdr_update_kernel, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, true, 1)
+ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, false, 1)
+// SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
+ASDR_KERNEL(asdr_update_kernel_sam, ASDR_SAM_WAVES * 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, false, ASDR_SAM_WAVES)
 #ifndef ASDR_ALS_WAVES_PER_EU
 #define ASDR_ALS_WAVES_PER_EU 3   /* LDS allows 9 waves/CU: needs 3 on one SIMD */
 #endif
-ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true)
-ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false)
+ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true, 1)
+ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
 extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {
@@ -1392,7 +1436,7 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
   if (variant == ASDR_KERNEL_ALS) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
-  else if (variant == ASDR_KERNEL_SAM) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_sam_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
