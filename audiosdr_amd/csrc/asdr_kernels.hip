@@ -790,6 +790,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         load4(hq_ring + (hs ^ 1u) * 128 + 32 * m, hq_m + 4 * m);
       }
     }
+    // the cached sin/cos pairs of this lane's pieces likewise (local-oscillator cache hit: they come from L2)
+    float lo_c[16], lo_s[16];
+    DEFINE_ALL_PATHS(lo_c, 16); DEFINE_ALL_PATHS(lo_s, 16);
+    if (RING_PREFETCH && lo_hit) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { load4(lo_rd->c + kF + 32 * m, lo_c + 4 * m); load4(lo_rd->s + kF + 32 * m, lo_s + 4 * m); }
+    }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
     if (ABL_ON(ABL_IF)) {
       const int iq = s8 >> 2, st = s8 & 3;
@@ -940,12 +947,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
     // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
     if (ABL_ON(ABL_MIX) && do_mix) {
-#pragma unroll 1
+#pragma unroll
       for (int m = 0; m < 4; ++m) {
         float cc[4], sn[4], vi[4], vq[4], mi[4], mq[4];
         load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
         if (lo_hit) {
-          load4(lo_rd->c + kF + 32 * m, cc); load4(lo_rd->s + kF + 32 * m, sn);
+          if (RING_PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cc[j] = lo_c[4 * m + j]; sn[j] = lo_s[4 * m + j]; }
+          } else { load4(lo_rd->c + kF + 32 * m, cc); load4(lo_rd->s + kF + 32 * m, sn); }
         } else if (mix_uni) {
           load4(lds + STRIDE + PH + kF + 32 * m, cc); load4(lds + 2 * STRIDE + PH + kF + 32 * m, sn);
         } else {
@@ -1201,19 +1211,33 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int i = 0; i < ASDR_N; i += 8) {
           float xn[8], gvv[8];
           load8(L + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);   // next chunk, a step ahead
+          // Hanging chunk: no sample of the chunk attacks (none exceeds the envelope, which therefore does not move) and the hang
+          // counter cannot run out inside it -> envelope, gain and governing value stay, the counter drops by 8.  With a steady
+          // signal most chunks between two envelope peaks are like this.  (v_max ignores a NaN operand, as `NaN > old` is false.)
+          float mx = is_am ? am_clamped : x[0];
+          if (!is_am) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float av = is_am ? am_clamped : x[u];   // AM: twice the carrier level stands in for |x| (:407-409)
-            const bool att = av > old_abs;                 // attack
-            const bool idle = (hc == 0u);                  // not hanging: release when not attacking
-            const float al = att ? al_a : al_r, be = att ? be_a : be_r;   // only the branch that is taken is evaluated (:418 / :424)
-            const float pa = al * old_abs, pb = be * av;
-            const float v_new = pa + pb;
-            const bool upd = att || idle;
-            old_abs = upd ? v_new : old_abs;
-            gv = upd ? v_new : gv;
-            hc = att ? hang : __builtin_elementwise_sub_sat(hc, 1u);   // 0 stays 0
-            gvv[u] = gv;
+            for (int u = 1; u < 8; ++u) mx = fmaxf(mx, x[u]);
+          }
+          if (__all(!(mx > old_abs) && hc >= 8u)) {   // EXEC = the lead lanes: wave-uniform over the wave's channels
+            hc -= 8u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gvv[u] = gv;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float av = is_am ? am_clamped : x[u];   // AM: twice the carrier level stands in for |x| (:407-409)
+              const bool att = av > old_abs;                 // attack
+              const bool idle = (hc == 0u);                  // not hanging: release when not attacking
+              const float al = att ? al_a : al_r, be = att ? be_a : be_r;   // only the branch that is taken is evaluated (:418 / :424)
+              const float pa = al * old_abs, pb = be * av;
+              const float v_new = pa + pb;
+              const bool upd = att || idle;
+              old_abs = upd ? v_new : old_abs;
+              gv = upd ? v_new : gv;
+              hc = att ? hang : __builtin_elementwise_sub_sat(hc, 1u);   // 0 stays 0
+              gvv[u] = gv;
+            }
           }
           store8(L + AGC_GV + i, gvv);
 #pragma unroll
