@@ -135,6 +135,10 @@ typedef struct {
   LoEntry *lo_cache;      /* [2] */
   uint32_t lo_parity;     /* entry this launch reads; wave 0 of the launch with lo_write set fills the other one */
   uint32_t lo_write;
+  int32_t direct_ch0;     /* >= 0: the launched sub-range is ONE key group of consecutive channels direct_ch0, direct_ch0 + 1, ...:
+                             slot i is channel direct_ch0 + i with direct_mode / direct_flags, and no wave has to load its
+                             schedule entry first (one HBM round trip less at the start of every wave); -1: read a.sched */
+  uint32_t direct_mode, direct_flags;
   int32_t in_stride;      /* row stride of I and Q in blocks (>= n_blocks; == n_blocks for the packed layout) */
   int32_t out_stride;     /* row stride of out in blocks (a capture row holds many calls' worth) */
   float *taps;            /* NULL or [ASDR_N_TAPS][n_channels][128] */

@@ -125,6 +125,7 @@ struct asdr_batch {
   // Inside a sub-range the whole waves of each key group come first ("uniform" waves: 8 real channels, one key -> the
   // instantiation with scalar mode/flag tests), then the groups' remainders packed together ("mixed").
   int kind_first[3] = {0, 0, 0}, kind_slots[3] = {0, 0, 0}, kind_uniform_slots[3] = {0, 0, 0};
+  bool kind_direct[3] = {false, false, false};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
   // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
   long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
   // device
@@ -352,6 +353,13 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       }
       i = j;
     }
+    for (int k = 0; k < 3; k++) {
+      const SlotInfo *sl = b->sched.data() + b->kind_first[k];
+      bool direct = b->kind_uniform_slots[k] > 0;
+      for (int j = 1; j < b->kind_uniform_slots[k] && direct; j++)
+        direct = (sl[j].ch == sl[0].ch + j) && sl[j].mode == sl[0].mode && sl[j].flags == sl[0].flags;
+      b->kind_direct[k] = direct;
+    }
     b->sched_dirty = false;
     sched_rebuilt = true;
     b->stat_sched_rebuilds++;
@@ -572,7 +580,6 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   a.in_stride = (int32_t)in_stride_blocks; a.out_stride = (int32_t)out_stride_blocks;
   hipEvent_t e0 = b->ev0, e1 = b->ev1;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
-  HIPCHK(hipEventRecord(e0, stream));
   // Up to six sub-ranges of the sorted schedule (3 kernel instantiations x {uniform, mixed waves}).  They touch disjoint channels,
   // so they run CONCURRENTLY: the first on the caller's stream, the others on the batch's helper streams, forked behind an
   // event and joined before the call's end marker -- launched back to back on one stream the short ones (a handful of waves of
@@ -585,11 +592,17 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (nu > 0) subs[n_sub++] = Sub{k, 1, b->kind_first[k], nu};
     if (nm > 0) subs[n_sub++] = Sub{k, 0, b->kind_first[k] + nu, nm};
   }
+  HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
   if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
   for (int i = 0; i < n_sub; i++) {
     hipStream_t s = (i == 0) ? stream : b->aux[i - 1];
     if (i > 0) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
     a.sched = b->d_sched + subs[i].first; a.n_sched = subs[i].slots;
+    a.direct_ch0 = -1;
+    if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
+      const SlotInfo &s0 = b->sched[subs[i].first];
+      a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags;
+    }
     a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
     if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
     if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }

@@ -353,7 +353,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   int4 slot = make_int4(a.n_channels, 0, 0, 0);
-  if (WAVES == 1 || wave_g * 8 < a.n_sched) slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
+  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, 0);
+  else if (WAVES == 1 || wave_g * 8 < a.n_sched) slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
   else { const ChanParams *pd = a.params + a.n_channels; slot.y = (int)pd->mode; slot.z = (int)pd->flags; }   // padding wave of a multi-wave workgroup: dummy channel
   const int ch_ = slot.x;
   const bool valid = UNIFORM || (ch_ < a.n_channels);
