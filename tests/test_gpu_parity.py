@@ -176,6 +176,91 @@ def test_unknown_mode_values(gpu, ao, mode):
     batch.close()
 
 
+def test_local_oscillator_cache_hits_misses_and_multi_block_calls(gpu, ao):
+    """The mixer's sin/cos pairs of the next block are left in HBM by wave 0 and read by every wave whose channels start that
+    block with exactly the cached (phase, increment) (asdr_device.h LoEntry).  Sequence: uniform USB batch (misses once, then
+    hits), a multi-block call (only its first block can hit), all channels to LSB (new increment: miss, then hits), half of the
+    channels to CW (two key groups with different increments: wave 0's group hits, the other computes its own), back to one
+    group.  Every block of every channel against the oracle."""
+    from audiosdr_amd.synth import make_iq
+    n_ch = 40                                       # 5 waves
+    plan = [1, 1, 1, 3, 1, 1, 2, 1, 1, 1, 1, 4, 1]  # blocks per update() call
+    script = {4: [S("setDemodMode", 0)], 7: [S("setDemodMode", 3, sel=lambda c: c >= 16)], 10: [S("setDemodMode", 1)]}
+    I, Q = make_iq(n_ch, sum(plan), fc=6290.0, A=0.25, impulse_every=900)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")])
+    b0 = 0
+    for call, nb in enumerate(plan):
+        if call in script:
+            apply_setters(batch, orcs, script[call])
+        got = batch.update(I[:, b0:b0 + nb], Q[:, b0:b0 + nb])
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b0:b0 + nb], Q[c, b0:b0 + nb]).reshape(nb, 128)
+            assert np.array_equal(got[c], want), "call %d (blocks %d..%d) ch %d" % (call, b0, b0 + nb - 1, c)
+        b0 += nb
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
+def test_agc_hanging_chunks_and_attacks(gpu, ao):
+    """The AGC recurrence skips 8-sample chunks in which no sample attacks and the hang counter cannot run out (envelope, gain
+    and counter arithmetic unchanged).  Amplitude steps up and down with fast / medium / slow AGC settings exercise chunks with
+    attacks, pure hang chunks, the hang counter running out inside a chunk and release chunks; AGC tap + int16 vs the oracle."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, n_blk = 10, 40
+    I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.3, noise=0.002)
+    env = np.ones(n_blk * 128)
+    env[128 * 6:128 * 12] = 0.05; env[128 * 12:128 * 13] = 1.0; env[128 * 13:128 * 30] = 0.02; env[128 * 30:] = 0.6
+    I = (I.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
+    Q = (Q.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
+    setters = [S("setDemodMode", 1), S("disableNoiseBlanker"),
+               S("setAGCmode", 1, sel=lambda c: c % 3 == 0), S("setAGCmode", 3, sel=lambda c: c % 3 == 1),
+               S("setAGChangTime", 7.0, sel=lambda c: c % 3 == 2)]       # 7 ms = 308 samples: runs out inside chunks
+    batch, orcs = _mk(gpu, ao, n_ch, setters, taps=True)
+    for b in range(n_blk):
+        got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
+        taps = batch.read_taps()
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b], Q[c, b])
+            assert np.array_equal(f32_bits(taps["AGC"][c]), f32_bits(orcs[c].tap("AGC"))), "block %d ch %d AGC tap" % (b, c)
+            assert np.array_equal(got[c], want), "block %d ch %d" % (b, c)
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
+def test_calls_alternating_between_two_streams(gpu, ao):
+    """asdr_update_device on a different stream than the previous call waits (event) for that call's kernels: every launch
+    read-modify-writes the same per-channel state.  Two caller-owned streams used alternately, no host synchronisation in
+    between; a batch with three kernel instantiations (plain / SAM / ALS) so the internal helper streams are in play too."""
+    from audiosdr_amd.synth import make_iq
+    import ctypes as C
+    from helpers import Hip
+    hip = Hip()
+    n_ch, n_blk = 27, 12
+    I, Q = make_iq(n_ch, n_blk, fc=6890.0, A=0.3, m=0.5)
+    setters = [S("setNoiseBlankerThresholdDb", 10.0)] + [S("setDemodMode", m, sel=(lambda c, m=m: c % 7 == m)) for m in range(7)] + \
+              [S("enableALSfilter", sel=lambda c: c % 5 == 0)]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    s = [C.c_void_p(), C.c_void_p()]
+    for x in s:
+        assert hip.h.hipStreamCreate(C.byref(x)) == 0
+    dI = [hip.upload(I[:, b].copy()) for b in range(n_blk)]
+    dQ = [hip.upload(Q[:, b].copy()) for b in range(n_blk)]
+    dO = [hip.malloc(n_ch * 256) for _ in range(n_blk)]
+    L = gpu.load_library()
+    for b in range(n_blk):
+        assert L.asdr_update_device(batch._h, C.c_void_p(dI[b]), C.c_void_p(dQ[b]), C.c_void_p(dO[b]), 1, s[b & 1]) == 0
+    for x in s:
+        hip.h.hipStreamSynchronize(x)
+    for b in range(n_blk):
+        got = np.zeros((n_ch, 128), np.int16)
+        assert hip.h.hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(dO[b]), got.nbytes, 2) == 0
+        for c in range(n_ch):
+            assert np.array_equal(got[c], orcs[c].update(I[c, b], Q[c, b])), "block %d ch %d" % (b, c)
+    for x in s:
+        hip.h.hipStreamDestroy(x)
+    batch.close()
+
+
 def test_missing_input_guard(gpu, ao):
     """AudioSDR.cpp:48-56: a missing I or Q block -> return without processing; state does not advance."""
     import ctypes as C
