@@ -263,11 +263,22 @@ __device__ __forceinline__ void store8(float *p, const float *v) {
   q[0] = make_float4(v[0], v[1], v[2], v[3]); q[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// RN(x / 32767.0) in binary64 for an int16 x with ONE multiply and ONE fma.  1/(2^15 - 1) is the bit pattern 2^-15 repeated
+// every 15 bits, so its binary64 rounding r = 0x1.0002000400080p-15 leaves the tail 1/32767 - r = r * 2^-60 * (1 + 2^-60 + ..);
+// x*r + RN(x * r*2^-60) differs from x/32767 by < 2^-118 |x|, and for none of the 65,536 inputs does that move the rounding
+// (checked exhaustively against true division by the CPU test-suite: oracle ao_check_scale_division).
+__device__ __forceinline__ double div_i16_by_32767(double x) {
+  return __builtin_fma(x, 0x1.0002000400080p-15, x * 0x1.0002000400080p-75);
+}
 // AudioSDR.cpp:68-69 for 8 raw samples: ((float)s / 32767.0) * gain in binary64, rounded to float by the store
 __device__ __forceinline__ void scale8(const int16_t *s, double g, float *out) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
+#ifdef ASDR_OLD_SCALE
     out[j] = (float)(div_by_const((double)s[j], 32767.0, 1.0 / 32767.0) * g);
+#else
+    out[j] = (float)(div_i16_by_32767((double)s[j]) * g);
+#endif
     if ((j & 1) == 1) SCHED_FENCE();
   }
 }
@@ -281,6 +292,13 @@ __device__ __forceinline__ float mask_decode(uint32_t c) { return c_mask_val[c &
 __device__ __forceinline__ uint32_t mask_encode(float v) {
   const uint32_t code = c_mask_code[(__float_as_uint(v) >> 20) & 0x3Fu];
   return (c_mask_val[code] == v) ? code : 1u;   // exact match only (any other non-zero value is code 1)
+}
+// four entries -> one code word.  The codes are made opaque before they are shifted: otherwise `(match ? code : 1) << 8k` becomes a
+// select against the literals 0x100 / 0x10000 / 0x1000000, which the compiler parks in three VGPRs for the whole kernel.
+__device__ __forceinline__ uint32_t mask_encode4(float4 mv) {
+  uint32_t c0 = mask_encode(mv.x), c1 = mask_encode(mv.y), c2 = mask_encode(mv.z), c3 = mask_encode(mv.w);
+  asm volatile("" : "+v"(c1), "+v"(c2), "+v"(c3));
+  return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
 }
 
 // ALS FIR (AudioSDR.cpp:331-335): y = sum_{q < M} w[q] * x[top - q], q ascending, every product and sum separately rounded.
@@ -318,6 +336,7 @@ __device__ __forceinline__ float als_dot(const float *w, const float *x, int top
 // path of the block-loop iteration: otherwise its value "from the previous iteration" is formally live around the whole loop
 // body and pins its registers everywhere (tools/isa_liveness.py found 32 such VGPRs).
 #define DEFINE_ALL_PATHS(arr, n) do { _Pragma("unroll") for (int z_ = 0; z_ < (n); ++z_) (arr)[z_] = 0.0f; } while (0)
+// (Also kept in the uniform-key instantiations, where the conditions are scalar branches: without it they spill 216 VGPRs.)
 // Per-channel rows addressed as (uniform base) + (32-bit byte offset): the offset stays in ONE VGPR and the access uses
 // the scalar-base addressing mode, instead of a 64-bit pointer in two VGPRs per array.  Valid because every state array is
 // smaller than 4 GiB (1,048,577 rows of at most 1.5 KiB).
@@ -611,14 +630,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         }   // !lo_hit
 #pragma unroll 1
-        for (int c = c_tail; c < 22; ++c) {
+        for (int c = c_tail; c < 22; c += 2) {   // c_tail is even; two chunks per trip, ping-pong like above
           float av[8], bn[8];
-          load8(L + NB_B + 2 + 8 * ((c < 21) ? c + 1 : c), bn);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u]; }
-          store8(L + NB_B + 2 + 8 * c, av);
+          for (int half = 0; half < 2; ++half) {
+            float *cur = half ? bn : bm, *nxt = half ? bm : bn;
+            load8(L + NB_B + 2 + 8 * ((c + half < 21) ? c + half + 1 : 21), nxt);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) bm[u] = bn[u];
+            for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; }
+            store8(L + NB_B + 2 + 8 * (c + half), av);
+          }
         }
         if (nb_en) S->nb_avg = avg;
         if (mix_early && !lo_hit) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
@@ -627,7 +648,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       ph_ready = mix_early && !lo_hit;
       WAVE_SYNC();
       // parallel: threshold test mag[t] > avg[t]*threshold (:628) on the lanes that hold the envelopes
-      uint32_t fm = 0u, ft = 0u;   // detection flags: bit 8h + j <-> this lane's sample kA + 64h + j of the middle block / bit j <-> 64 + kA + j of the oldest
+      // detection flags, shifted in one sample at a time (x + x + flag: no `1 << k` literals, which the compiler would park in nine
+      // VGPRs for the whole kernel): bit 15 - (8h + j) <-> this lane's sample kA + 64h + j of the middle block / bit 7 - j <-> 64 + kA + j of the oldest
+      uint32_t fm = 0u, ft = 0u;
       if (nb_en) {
         const float thr = P.nb_threshold;
 #pragma unroll
@@ -635,14 +658,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           float av[8];
           load8(L + NB_B + 50 + kA + 64 * h, av);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) fm |= (mgm[8 * h + j] > av[j] * thr) ? (1u << (8 * h + j)) : 0u;
+          for (int j = 0; j < 8; ++j) fm = fm + fm + ((mgm[8 * h + j] > av[j] * thr) ? 1u : 0u);
         }
         if (own_tail) {
           float av[8];
           if (s8 >= 2) load8(L + kA - 12, av);
           else { const float4 t4 = *reinterpret_cast<const float4 *>(L); av[0] = av[1] = av[2] = av[3] = 0.0f; av[4] = t4.x; av[5] = t4.y; av[6] = t4.z; av[7] = t4.w; }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ft |= ((64 + kA + j >= 78) && (mgt[j] > av[j] * thr)) ? (1u << j) : 0u;
+          for (int j = 0; j < 8; ++j) ft = ft + ft + (((64 + kA + j >= 78) && (mgt[j] > av[j] * thr)) ? 1u : 0u);
         }
       }
       TL(3);
@@ -675,7 +698,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             { const uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); v += (s8 >= 4) ? t4 : 0u; }
             return v;
           };
-          const uint32_t cnt_t = (uint32_t)__builtin_popcount(ft), cnt_a = (uint32_t)__builtin_popcount(fm & 0xFFu), cnt_b = (uint32_t)__builtin_popcount(fm >> 8);
+          const uint32_t cnt_t = (uint32_t)__builtin_popcount(ft), cnt_a = (uint32_t)__builtin_popcount(fm >> 8), cnt_b = (uint32_t)__builtin_popcount(fm & 0xFFu);
           const uint32_t inc_t = scan8(cnt_t), inc_a = scan8(cnt_a), inc_b = scan8(cnt_b);
           const int last = (lane_i & ~7) | 7;
           const uint32_t tot_t = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)inc_t), tot_a = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)inc_a),
@@ -684,14 +707,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           uint32_t run = inc_t - cnt_t;
           if (own_tail) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { run += (ft >> j) & 1u; if (64 + kA + j >= 78) cbw[24 + 64 + kA + j - 78] = (uint8_t)run; }
+            for (int j = 0; j < 8; ++j) { run += (ft >> (7 - j)) & 1u; if (64 + kA + j >= 78) cbw[24 + 64 + kA + j - 78] = (uint8_t)run; }
           }
           run = tot_t + inc_a - cnt_a;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { run += (fm >> j) & 1u; cbw[24 + 50 + kA + j] = (uint8_t)run; }
+          for (int j = 0; j < 8; ++j) { run += (fm >> (15 - j)) & 1u; cbw[24 + 50 + kA + j] = (uint8_t)run; }
           run = tot_t + tot_a + inc_b - cnt_b;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { run += (fm >> (8 + j)) & 1u; cbw[24 + 50 + 64 + kA + j] = (uint8_t)run; }
+          for (int j = 0; j < 8; ++j) { run += (fm >> (7 - j)) & 1u; cbw[24 + 50 + 64 + kA + j] = (uint8_t)run; }
           if (lead) {
             const uint32_t fin = ((tot_t + tot_m) & 0xFFu) * 0x01010101u;
 #pragma unroll
@@ -710,8 +733,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               *reinterpret_cast<float4 *>(L + NB_MSK + e) = make_float4(mask_decode(mkc[r] & 0xFFu), mask_decode((mkc[r] >> 8) & 0xFFu),
                                                                          mask_decode((mkc[r] >> 16) & 0xFFu), mask_decode(mkc[r] >> 24));
           }
+          float one = 1.0f; asm volatile("" : "+v"(one));   // materialised here, not parked in a VGPR at kernel entry
 #pragma unroll
-          for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = 1.0f;   /* any partition of 138..265 */
+          for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = one;   /* any partition of 138..265 */
         }
         WAVE_SYNC();
         if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are 0.0, so order-free:
@@ -761,7 +785,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             for (int r = 0; r < 5; ++r) {
               const int e = 32 * r + 4 * s8;   // entries >= 138 are padding: store code 1
               const float4 mv = (e < ASDR_NB_MASK_USED + 2) ? *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-              mrow[8 * r] = mask_encode(mv.x) | (mask_encode(mv.y) << 8) | (mask_encode(mv.z) << 16) | (mask_encode(mv.w) << 24);
+              mrow[8 * r] = mask_encode4(mv);
             }
           }
         }
@@ -1085,12 +1109,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       if (is_ssb) {   // sideband combine (:115-118) with the delayed I
+        // x - y == x + (-y) exactly: the sideband is a sign bit, not a select between two forms (a wave-uniform
+        // `sub_q ? a - b : a + b` per sample compiles to a scalar branch cascade per sample in the uniform-key instantiations)
+        const uint32_t sgn = sub_q ? 0x80000000u : 0u;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           float qh[4], au[4];
           load4(L + W1 + kF + 32 * m, qh);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) au[j] = sub_q ? (idl[4 * m + j] - qh[j]) : (idl[4 * m + j] + qh[j]);
+          for (int j = 0; j < 4; ++j) au[j] = idl[4 * m + j] + __uint_as_float(__float_as_uint(qh[j]) ^ sgn);
           store4(L + W0 + kF + 32 * m, au);
           TAP4(ASDR_TAP_MIX_I, m, idl + 4 * m); TAP4(ASDR_TAP_MIX_Q, m, qh);
         }
@@ -1206,11 +1233,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // Per sample (:412-428): attack if |x| > envelope, else release unless the hang counter runs.  A lone wave issues one
         // instruction per ~4.5 cycles whatever the dependency depth (tools/ubench/dep_chain.hip), so the loop is written for the
         // fewest instructions: only the taken branch's alpha / beta are selected, then one mul, mul, add.
-        float x[8];
-        load8(L + AGC_GV, x);
+        float x_[8];
+        load8(L + AGC_GV, x_);
 #pragma unroll 1
-        for (int i = 0; i < ASDR_N; i += 8) {
-          float xn[8], gvv[8];
+        for (int i2 = 0; i2 < ASDR_N; i2 += 16) {   // two chunks per trip: the prefetched chunk ping-pongs between x and xn (no copies)
+          float xn_[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int i = i2 + 8 * half;
+          float *x = half ? xn_ : x_, *xn = half ? x_ : xn_;
+          float gvv[8];
           load8(L + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);   // next chunk, a step ahead
           // Hanging chunk: no sample of the chunk attacks (none exceeds the envelope, which therefore does not move) and the hang
           // counter cannot run out inside it -> envelope, gain and governing value stay, the counter drops by 8.  With a steady
@@ -1241,8 +1273,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             }
           }
           store8(L + AGC_GV + i, gvv);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = xn[u];
+        }
         }
         S->agc_old_abs = old_abs;
         S->agc_hang_counter = hc;

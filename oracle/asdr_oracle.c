@@ -703,8 +703,12 @@ uint64_t ao_check_sin_index_division(uint32_t bits_lo, uint32_t bits_hi) {
 /* all int16: s/32767.0 (AudioSDR.cpp:68) */
 int ao_check_scale_division(void) {
   int bad = 0;
-  for (int s = -32768; s < 32768; s++)
+  if (1.0 / 32767.0 != 0x1.0002000400080p-15) bad++;
+  for (int s = -32768; s < 32768; s++) {
     if (div_by_const_fma((double)s, 32767.0, 1.0 / 32767.0) != (double)s / 32767.0) bad++;
+    /* the kernels' two-operation form (asdr_kernels.hip div_i16_by_32767): fma(x, r, x * r * 2^-60) */
+    if (fma((double)s, 0x1.0002000400080p-15, (double)s * 0x1.0002000400080p-75) != (double)s / 32767.0) bad++;
+  }
   return bad;
 }
 
