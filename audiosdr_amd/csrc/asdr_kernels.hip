@@ -1233,6 +1233,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // Per sample (:412-428): attack if |x| > envelope, else release unless the hang counter runs.  A lone wave issues one
         // instruction per ~4.5 cycles whatever the dependency depth (tools/ubench/dep_chain.hip), so the loop is written for the
         // fewest instructions: only the taken branch's alpha / beta are selected, then one mul, mul, add.
+        // AM: twice the carrier level stands in for |x| of every sample (:407-409): the lead lane overwrites its channel's row
+        // with that constant once, so that the recurrence below needs no per-sample select
+        if (is_am) {
+#pragma unroll 1
+          for (int i = 0; i < ASDR_N; i += 4) *reinterpret_cast<float4 *>(L + AGC_GV + i) = make_float4(am_clamped, am_clamped, am_clamped, am_clamped);
+        }
         float x_[8];
         load8(L + AGC_GV, x_);
 #pragma unroll 1
@@ -1247,19 +1253,38 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           // Hanging chunk: no sample of the chunk attacks (none exceeds the envelope, which therefore does not move) and the hang
           // counter cannot run out inside it -> envelope, gain and governing value stay, the counter drops by 8.  With a steady
           // signal most chunks between two envelope peaks are like this.  (v_max ignores a NaN operand, as `NaN > old` is false.)
-          float mx = is_am ? am_clamped : x[0];
-          if (!is_am) {
+          float mx = x[0];
 #pragma unroll
-            for (int u = 1; u < 8; ++u) mx = fmaxf(mx, x[u]);
-          }
-          if (__all(!(mx > old_abs) && hc >= 8u)) {   // EXEC = the lead lanes: wave-uniform over the wave's channels
+          for (int u = 1; u < 8; ++u) mx = fmaxf(mx, x[u]);
+          // While the hang counter cannot run out inside the chunk (counter >= 8 now, and an attack re-arms it with >= 8), nothing
+          // releases: only attacks change the envelope.  The counter is then kept as a base value: an attack at sample u sets it to
+          // hang + (u + 1), so that base - 8 is the counter after the chunk.  All tests are wave-uniform (EXEC = the lead lanes).
+          const bool no_release = __all(hc >= 8u && hang >= 8u);
+          if (no_release && __all(!(mx > old_abs))) {
             hc -= 8u;
 #pragma unroll
             for (int u = 0; u < 8; ++u) gvv[u] = gv;
+          } else if (no_release) {
+            uint32_t hcb = hc;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float av = x[u];
+              const bool att = av > old_abs;
+              if (__any(att)) {   // rare: a sample above the envelope in some channel of the wave
+                asm volatile("");   // keeps this a branch (the compiler would otherwise flatten it into selects for every sample)
+                const float pa = al_a * old_abs, pb = be_a * av;   // (:418)
+                const float v_new = pa + pb;
+                old_abs = att ? v_new : old_abs;
+                gv = att ? v_new : gv;
+                hcb = att ? hang + (uint32_t)(u + 1) : hcb;
+              }
+              gvv[u] = gv;
+            }
+            hc = hcb - 8u;
           } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              const float av = is_am ? am_clamped : x[u];   // AM: twice the carrier level stands in for |x| (:407-409)
+              const float av = x[u];
               const bool att = av > old_abs;                 // attack
               const bool idle = (hc == 0u);                  // not hanging: release when not attacking
               const float al = att ? al_a : al_r, be = att ? be_a : be_r;   // only the branch that is taken is evaluated (:418 / :424)

@@ -202,19 +202,26 @@ def test_local_oscillator_cache_hits_misses_and_multi_block_calls(gpu, ao):
 
 
 def test_agc_hanging_chunks_and_attacks(gpu, ao):
-    """The AGC recurrence skips 8-sample chunks in which no sample attacks and the hang counter cannot run out (envelope, gain
-    and counter arithmetic unchanged).  Amplitude steps up and down with fast / medium / slow AGC settings exercise chunks with
-    attacks, pure hang chunks, the hang counter running out inside a chunk and release chunks; AGC tap + int16 vs the oracle."""
+    """The AGC recurrence has three wave-uniform forms per 8-sample chunk: (a) no sample attacks and the hang counter cannot run
+    out -> only the counter moves; (b) the counter cannot run out (counter >= 8, hang >= 8) -> only attacking samples are
+    evaluated; (c) the general per-sample form (release possible).  Waves 0 / 1 / 2 are homogeneous so that (a) and (b) are
+    taken (long hang: USB; tiny or zero hang: always (c); AM, whose |x| is the constant carrier level), wave 3 mixes all of
+    them.  Amplitude steps up and down drive attacks, pure hang, the counter running out and release; AGC tap + int16 output."""
     from audiosdr_amd.synth import make_iq
-    n_ch, n_blk = 10, 40
+    n_ch, n_blk = 32, 40
     I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.3, noise=0.002)
     env = np.ones(n_blk * 128)
     env[128 * 6:128 * 12] = 0.05; env[128 * 12:128 * 13] = 1.0; env[128 * 13:128 * 30] = 0.02; env[128 * 30:] = 0.6
     I = (I.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
     Q = (Q.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
+    grp = lambda c: (c // 8) if c < 24 else (c % 3)
     setters = [S("setDemodMode", 1), S("disableNoiseBlanker"),
-               S("setAGCmode", 1, sel=lambda c: c % 3 == 0), S("setAGCmode", 3, sel=lambda c: c % 3 == 1),
-               S("setAGChangTime", 7.0, sel=lambda c: c % 3 == 2)]       # 7 ms = 308 samples: runs out inside chunks
+               S("setAGChangTime", 7.0, sel=lambda c: grp(c) == 0 and c % 2 == 0),      # 308 samples: runs out inside chunks
+               S("setAGCmode", 3, sel=lambda c: grp(c) == 0 and c % 4 == 1),
+               S("setAGChangTime", 0.1, sel=lambda c: grp(c) == 1 and c % 2 == 0),      # 4 samples: below the chunk length
+               S("setAGChangTime", 0.0, sel=lambda c: grp(c) == 1 and c % 2 == 1),
+               S("setDemodMode", 4, sel=lambda c: grp(c) == 2),
+               S("setAGCmode", 1, sel=lambda c: grp(c) == 2 and c % 2 == 1)]
     batch, orcs = _mk(gpu, ao, n_ch, setters, taps=True)
     for b in range(n_blk):
         got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
