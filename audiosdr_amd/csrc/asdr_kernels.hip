@@ -146,14 +146,27 @@ __device__ __forceinline__ float approx_atan(float z) {
 // The reference's branch tree (quadrant by quadrant, one division per branch) evaluated branch-free with ONE division:
 // every lane performs exactly the operations of the branch it would have taken (the operands of the division are
 // selected first; -a - half_pi == -a + (-half_pi) and a - PI == a + (-PI) exactly), the other results are discarded.
+template <bool TWO_SUMS>
 __device__ __forceinline__ float approx_atan2(float y, float x, float half_pi) {
   const bool xnz = (x != 0.0f);
   const bool big = fabsf(x) > fabsf(y);
   const float num = big ? y : x, den = big ? x : y;
   const float z = num / den;
   const float a = approx_atan(z);
-  const double pis = (y >= 0.0f) ? PI_D : -PI_D;
-  const float a_pi = (float)((double)a + pis);
+  // a + PI for y >= 0, a - PI otherwise (a - PI == a + (-PI) exactly).  The select between the two binary64 constants parks
+  // their three distinct words in VGPRs for the whole kernel: the SAM instantiation affords them (this is its longest dependent
+  // chain: two instructions fewer per sample), the ALS instantiations (TWO_SUMS) form both sums and select the result.
+  float a_pi;
+  if (TWO_SUMS) {
+    const double ad = (double)a;
+    const float a_pp = (float)(ad + PI_D);
+    float a_pm = (float)(ad - PI_D);
+    asm volatile("" : "+v"(a_pm));   // (keeps the compiler from folding the two sums back into that select)
+    a_pi = (y >= 0.0f) ? a_pp : a_pm;
+  } else {
+    const double pis = (y >= 0.0f) ? PI_D : -PI_D;
+    a_pi = (float)((double)a + pis);
+  }
   const float r_big = (x > 0.0f) ? a : a_pi;                               // |x| > |y|
   const float r_small = -a + ((y > 0.0f) ? half_pi : -half_pi);            // |x| <= |y|, x != 0
   const float r_x0 = (y > 0.0f) ? half_pi : ((y < 0.0f) ? -half_pi : 0.0f);   // x == 0
@@ -433,6 +446,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                                   store8(tap_base + (size_t)(id) * tap_stride + 64 * h_, tv_); } } } while (0)
 
     uint32_t status = S->status;
+    // Small operands first (memory waits count loads in order: what is requested first can be waited for alone): the carried
+    // mixer phase of the modes whose mixer does not depend on this block's data, the frequency shift, the oscillator cache's key.
+    const bool mix_early = is_ssb || is_am;
+    float mphase = 0.0f, minc = 0.0f, mphase_end = 0.0f;   // mphase_end: valid on the lead lanes once the sequence has been computed
+    float fsh_raw = 0.0f;
+    if (mix_early) { mphase = is_ssb ? S->phase_ssb : S->phase_am; fsh_raw = P.freq_shift; }
+    const LoEntry *lo_rd = a.lo_cache + (a.lo_parity & 1u);
+    const uint32_t lo_kp = lo_rd->key_phase, lo_ki = lo_rd->key_inc;
+    const float lo_end = lo_rd->phase_end;
     // Ring positions.  The blanker ring advances once per processed block for EVERY channel (a batch-wide block counter):
     // enabling the blanker or changing its threshold resets all three slots (AudioSDR.cpp:653-682), so a channel whose
     // blanker was off meanwhile never sees a stale position -- and no load has to wait for a per-channel slot word.
@@ -468,24 +490,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
       nb_avg0 = S->nb_avg;
     }
-    // mixer phase and increment (AudioSDR.h:508-512) of the modes whose mixer does not depend on this block's data
-    const bool mix_early = is_ssb || is_am;
-    float mphase = 0.0f, minc = 0.0f, mphase_end = 0.0f;   // mphase_end: valid on the lead lanes once the sequence has been computed
-    if (mix_early) {
-      mphase = is_ssb ? S->phase_ssb : S->phase_am;
-      const float fs = is_ssb ? -P.freq_shift : -K.if_center;
-      minc = fs * K.phase_inc_unit;
-    }
+    // mixer increment (AudioSDR.h:508-512) and the local-oscillator cache test (asdr_device.h LoEntry): hit = every channel of the
+    // wave starts this block with exactly the cached phase and increment -> no recurrence, no table lookups, the pairs are read
+    // from the entry.  (The operands were requested before the input rows: the test does not wait for those.)
+    if (mix_early) minc = (is_ssb ? -fsh_raw : -K.if_center) * K.phase_inc_unit;
     bool ph_ready = false;   // this channel's phase sequence is in its PH row
-    // local-oscillator cache (asdr_device.h LoEntry): hit = every channel of the wave starts this block with exactly the cached
-    // phase and increment -> no recurrence, no table lookups, the pairs are read from the entry
-    const LoEntry *lo_rd = a.lo_cache + (a.lo_parity & 1u);
     bool lo_hit = false;
-    if (blk == 0) {
-      const uint32_t kp = lo_rd->key_phase, ki = lo_rd->key_inc;
-      lo_hit = __all(mix_early && __float_as_uint(mphase) == kp && __float_as_uint(minc) == ki);
-    }
-    const float lo_end = lo_rd->phase_end;
+    if (blk == 0) lo_hit = __all(mix_early && __float_as_uint(mphase) == lo_kp && __float_as_uint(minc) == lo_ki);
     if (lo_hit && lead) { if (is_ssb) S->phase_ssb = lo_end; else S->phase_am = lo_end; }
 
     // ---- input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
@@ -800,6 +811,19 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     TL(4);
     TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1);
 
+    // The IF pipeline's state and coefficients must be IN registers before the ring prefetches below are issued: memory waits
+    // count loads in order, and a wait for these values placed after the (conditional) prefetches would be a wait for everything
+    // -- the first pipeline step would sit out the prefetches' HBM latency (it did: vmcnt(0) inside the pipeline loop).
+    auto load_if_rows = [&]() {
+      if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
+      const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
+#pragma unroll
+      for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
+    };
+    if (ABL_ON(ABL_IF) && !HAS_ALS) {   // (the ALS instantiations keep the old order: they spill with this one)
+      if (!if_pre) load_if_rows();
+      asm volatile("" : "+v"(if_s4.x), "+v"(if_s4.y), "+v"(if_s4.z), "+v"(if_s4.w), "+v"(if_cf[0]), "+v"(if_cf[1]), "+v"(if_cf[2]), "+v"(if_cf[3]), "+v"(if_cf[4]));
+    }
     float *hi_ring = row_ptr(a.hil_i, (uint32_t)ch * 1024u + 4u * (uint32_t)kF);   // float rows: pieces kF + 32m
     float *hq_ring = row_ptr(a.hil_q, (uint32_t)ch * 1024u + 4u * (uint32_t)kF);
     float hq_o[16], hq_m[16], idl[16];   // this lane's pieces (samples kF + 32m + j at [4m + j]) of the Hilbert rings
@@ -826,12 +850,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ABL_ON(ABL_IF)) {
       const int iq = s8 >> 2, st = s8 & 3;
       float sv[4];
-      if (!if_pre) {
-        if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[iq][4 * st]);
-        const float *cf = &c_bq_pool[P.if_table][5 * st];
-#pragma unroll
-        for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
-      }
+      if (HAS_ALS && !if_pre) load_if_rows();
       sv[0] = if_s4.x; sv[1] = if_s4.y; sv[2] = if_s4.z; sv[3] = if_s4.w;
       biquad_pipe(L + (iq ? W1 : W0), true, st, if_cf, sv);
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
@@ -857,7 +876,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           const float x_re = xr[u], x_im = xi[u];
           const float d_re = x_re * y_re + x_im * y_im;
           const float d_im = x_im * y_re - x_re * y_im;
-          const float err = approx_atan2(d_im, d_re, K.half_pi_f);
+          const float err = approx_atan2<HAS_ALS>(d_im, d_re, K.half_pi_f);
           d1 = d0;
           d0 = err - K.pll_a1 * d1;
           const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
