@@ -219,12 +219,33 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
 #pragma unroll
   for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
   const bool s0 = (st == 0);
+  const unsigned long long s0m = __ballot(s0);   // EXEC is full here
 #pragma unroll 1
   for (int c = 0; c < NSTEP; ++c) {
     const int cn = c - st;
     float x[C], p[C], y[C];
+#if defined(ASDR_PIPE_PLAIN_SELECT) || ASDR_PIPE_CHUNK != 8
 #pragma unroll
     for (int j = 0; j < C; ++j) { const float d = dpp_row_shr1(yo[j]); x[j] = s0 ? xn[j] : d; }
+#else
+    // x[j] = stage 0 ? the LDS chunk : the previous lane's output, as ONE instruction per sample: v_cndmask_b32 with the DPP
+    // shift on its first source (VOP2 form: the condition must be VCC).  The compiler keeps the stage-0 mask in an SGPR pair and
+    // emits v_mov_b32_dpp + v_cndmask_b32_e64 (16 instead of 8 per step), hence the assembly.
+    asm("s_mov_b64 vcc, %[m]\n\ts_nop 1\n\t"
+        "v_cndmask_b32_dpp %[x0], %[y0], %[n0], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x1], %[y1], %[n1], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x2], %[y2], %[n2], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x3], %[y3], %[n3], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x4], %[y4], %[n4], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x5], %[y5], %[n5], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x6], %[y6], %[n6], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_dpp %[x7], %[y7], %[n7], vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]), [x4] "=&v"(x[4]), [x5] "=&v"(x[5]), [x6] "=&v"(x[6]), [x7] "=&v"(x[7])
+        : [y0] "v"(yo[0]), [y1] "v"(yo[1]), [y2] "v"(yo[2]), [y3] "v"(yo[3]), [y4] "v"(yo[4]), [y5] "v"(yo[5]), [y6] "v"(yo[6]), [y7] "v"(yo[7]),
+          [n0] "v"(xn[0]), [n1] "v"(xn[1]), [n2] "v"(xn[2]), [n3] "v"(xn[3]), [n4] "v"(xn[4]), [n5] "v"(xn[5]), [n6] "v"(xn[6]), [n7] "v"(xn[7]),
+          [m] "s"(s0m)
+        : "vcc");
+#endif
     {   // prefetch the next chunk for stage 0
       const int nc = (c + 1 < ASDR_N / C) ? c + 1 : ASDR_N / C - 1;
 #pragma unroll
