@@ -473,6 +473,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float mphase = 0.0f, minc = 0.0f, mphase_end = 0.0f;   // mphase_end: valid on the lead lanes once the sequence has been computed
     float fsh_raw = 0.0f;
     if (mix_early) { mphase = is_ssb ? S->phase_ssb : S->phase_am; fsh_raw = P.freq_shift; }
+    const float nb_thr = P.nb_threshold;   // used after the blanker's sequential pass: requested here, not there
     const LoEntry *lo_rd = a.lo_cache + (a.lo_parity & 1u);
     const uint32_t lo_kp = lo_rd->key_phase, lo_ki = lo_rd->key_inc;
     const float lo_end = lo_rd->phase_end;
@@ -622,7 +623,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
         // wrap `t < 0 ? t + twoPI : t` is a sign-mask select (v_ashrrev + v_bfi, no compare -> VCC -> select hazard): the phase
         // chain is add, shift, select.  (t = -0.0 cannot occur: the phase is never -0.0 and x + y = -0.0 needs both -0.0.)
-        if (__all(minc < 0.0f)) {
+        if (!HAS_ALS && __all(minc < 0.0f)) {   // (the ALS instantiations take the compact loop below: this one costs them spills)
 #pragma unroll 1
           for (int c = 0; c < 16; c += 2) {
             float av[8], bn[8], pv[8];
@@ -684,7 +685,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // VGPRs for the whole kernel): bit 15 - (8h + j) <-> this lane's sample kA + 64h + j of the middle block / bit 7 - j <-> 64 + kA + j of the oldest
       uint32_t fm = 0u, ft = 0u;
       if (nb_en) {
-        const float thr = P.nb_threshold;
+        const float thr = nb_thr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float av[8];
@@ -1222,7 +1223,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float4 agc_t4[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) agc_t4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float agc_al_a = 0.f, agc_be_a = 0.f, agc_al_r = 0.f, agc_be_r = 0.f, agc_sg = 0.f;   // likewise the channel's AGC parameters
+    uint32_t agc_hang = 0u;
     if (ABL_ON(ABL_AGC) && agc_en) {
+      agc_al_a = P.agc_alpha_att; agc_be_a = P.agc_beta_att; agc_al_r = P.agc_alpha_rel; agc_be_r = P.agc_beta_rel;
+      agc_sg = P.agc_static_gain; agc_hang = P.agc_hang_count;
       const float *gtab = a.agc_tab + (size_t)agc_tab_idx * ASDR_AGC_TAB_ROW;
 #pragma unroll
       for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) agc_t4[r] = reinterpret_cast<const float4 *>(gtab)[q]; }
@@ -1267,8 +1272,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         uint32_t hc = agc_hc0;
         const float am_level = (float)(2.0 * (double)(carrier_fresh ? carrier_now : agc_carrier0));
         const float am_clamped = (am_level > 1.0f) ? 1.0f : am_level;
-        const float al_a = P.agc_alpha_att, be_a = P.agc_beta_att, al_r = P.agc_alpha_rel, be_r = P.agc_beta_rel;
-        const uint32_t hang = P.agc_hang_count;
+        const float al_a = agc_al_a, be_a = agc_be_a, al_r = agc_al_r, be_r = agc_be_r;
+        const uint32_t hang = agc_hang;
         float gv = -1.0f;   // envelope value governing the current gain; -1 = no update yet in this block
         // Per sample (:412-428): attack if |x| > envelope, else release unless the hang counter runs.  A lone wave issues one
         // instruction per ~4.5 cycles whatever the dependency depth (tools/ubench/dep_chain.hip), so the loop is written for the
@@ -1349,7 +1354,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       WAVE_SYNC();
       TL(13);
       if (agc_en) {
-        const float sg = P.agc_static_gain;
+        const float sg = agc_sg;
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
           float au[8], gvr[8];
