@@ -59,7 +59,9 @@ int asdr_n_channels(const asdr_batch_t *b);
  *  asdr_update        : host pointers; copies in, runs, copies out, synchronises.
  *  asdr_update_device : device pointers (already resident in HBM); asynchronous on `stream`
  *                       (a hipStream_t; NULL = the null stream).  Buffers must stay valid until
- *                       the stream reaches this point.
+ *                       the stream reaches this point.  Calls may come on different streams: a call on
+ *                       another stream than the previous one first waits (event) for that call's kernels,
+ *                       so the previous stream must still exist when the next call is made.
  * A NULL I or Q mirrors the reference's missing-input guard (AudioSDR.cpp:48-56): nothing is
  * processed, no state advances, out is untouched, return 0. */
 int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks);
@@ -171,9 +173,19 @@ enum { ASDR_TAP_SCALED_I = 0, ASDR_TAP_SCALED_Q, ASDR_TAP_NB_I, ASDR_TAP_NB_Q, A
        ASDR_N_TAPS };
 int asdr_enable_taps(asdr_batch_t *b, int on);
 int asdr_read_taps(asdr_batch_t *b, float *dst /* [ASDR_N_TAPS][n_channels][128] */);
-/* Kernel-only timing of the most recent asdr_update_device() in milliseconds (HIP events recorded on the
- * launch stream around the kernel launches of that call); synchronises on the stop event. */
+/* Timing (none of it in the reference).  By default a call enqueues its kernels and nothing else: every HIP event record is
+ * one more packet between two kernels (a C2 call costs 0.134 ms back to back with an event pair around it, 0.127 ms without).
+ *   asdr_set_launch_timing(b, 1)   from now on every call records an event pair around its launches;
+ *   asdr_last_kernel_ms            elapsed milliseconds of the most recent such call (synchronises on the stop event;
+ *                                  -1 when launch timing is off);
+ *   asdr_region_timing_begin/_end  ONE event pair on `stream` around any number of calls: _end records the stop event on the
+ *                                  same stream, synchronises, and returns the elapsed milliseconds and the number of update
+ *                                  calls in between -- the average time per back-to-back call, gaps included, with no packet
+ *                                  added between the kernels (what bench.py reports as kernel_ms). */
+int asdr_set_launch_timing(asdr_batch_t *b, int on);
 float asdr_last_kernel_ms(asdr_batch_t *b);
+int asdr_region_timing_begin(asdr_batch_t *b, void *stream);
+int asdr_region_timing_end(asdr_batch_t *b, float *ms_total, long *n_calls);
 /* Per-launch kernel timing across a region: _begin() arms up to `max_launches` HIP-event pairs; every following
  * asdr_update_device() records one pair on ITS launch stream around the kernel; _end() synchronises, writes the
  * elapsed milliseconds of each launch into ms[0..return-1] and disarms. */

@@ -338,13 +338,25 @@ def test_device_pointer_entry_point_and_stream(gpu, ao):
     assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dO, nbytes, D2H) == 0
     want = np.stack([orcs[c].update(I[c], Q[c]).reshape(n_blk, 128) for c in range(n_ch)])
     assert np.array_equal(got, want)
+    # timing is opt-in (no event packets around the kernels by default)
+    assert batch.last_kernel_ms() < 0
+    batch.set_launch_timing(True)
+    batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
     assert batch.last_kernel_ms() > 0
-    # per-launch timing API used by bench.py
+    batch.set_launch_timing(False)
+    assert batch.last_kernel_ms() < 0
+    # per-launch pairs
     batch.kernel_timing_begin(3)
     for _ in range(3):
         batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
     ms = batch.kernel_timing_end(3)
     assert len(ms) == 3 and (ms > 0).all()
+    # one pair around a region of calls (bench.py's kernel_ms): not less than the kernels inside it
+    batch.region_timing_begin(stream.value)
+    for _ in range(4):
+        batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
+    total, calls = batch.region_timing_end()
+    assert calls == 4 and total > 0.8 * 4 * float(ms.min())
     for p_ in (dI, dQ, dO):
         hip.hipFree(p_)
     batch.close()

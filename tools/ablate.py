@@ -61,6 +61,8 @@ def run(rounds=5, n_ch=65536):
             continue
         L = A.binding.load_library(p)
         h = L.asdr_create(n_ch, 0)
+        if hasattr(L, "asdr_set_launch_timing"):
+            L.asdr_set_launch_timing(h, 1)   # an event pair per call (older variant builds always record it)
         cfg = os.environ.get("ABLATE_CFG", "c2")
         if cfg == "c3":      # SAM + PLL (BASELINE config 3 settings)
             L.asdr_setDemodMode(h, -1, 5); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0); L.asdr_enableAudioFilter(h, -1); L.asdr_setAudioFilter(h, -1, 0)

@@ -75,7 +75,7 @@ def main():
         I, Q = make_iq(1, 2048, fc=6890.0, A=0.3, m=0.5, fm=400.0)
         t, _ = ao.bench_run(1, I, Q, 1)
         o = ao.OracleSDR(); o.setDemodMode(ao.AMmode)
-        b = A.AudioSDRBatch(1); b.setDemodMode(A.AMmode)
+        b = A.AudioSDRBatch(1); b.set_launch_timing(True); b.setDemodMode(A.AMmode)
         got = b.update(I[:, :16], Q[:, :16])
         ok = np.array_equal(got[0].reshape(-1), o.update(I[0, :16], Q[0, :16]))
         ms = []
@@ -91,13 +91,13 @@ def main():
         n_ch = 65536
         if "c2" in which:
             I, Q = tiled(n_ch, 12, 2048, fc=6290.0, A=0.25)
-            b = A.AudioSDRBatch(n_ch); cfg(b)
+            b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True); cfg(b)
             ms, got = run_launches(b, I, Q, 1, 4, 8)
             report("C2 USB 64k x 1 block/launch", n_ch, 1, ms, {"parity": check(cfg, I, Q, got, [0, 777, 2047, 65535])})
             b.close()
         if "c2" in which:   # same chain with an impulse every 1000 samples in every channel: the blanker's general path
             I, Q = tiled(n_ch, 28, 2048, fc=6290.0, A=0.25, impulse_every=97)   # an impulse in (almost) every block
-            b = A.AudioSDRBatch(n_ch); cfg(b)
+            b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True); cfg(b)
             ms, got = run_launches(b, I, Q, 1, 20, 8)                             # the blanker's average has settled by block 20
             st = b.read_status()
             report("C2 USB 64k x 1 block/launch, impulsive input (blanker detecting in every channel)", n_ch, 1, ms,
@@ -105,7 +105,7 @@ def main():
             b.close()
         if "c2s" in which:
             I, Q = tiled(n_ch, 64 * 3, 512, fc=6290.0, A=0.25)
-            b = A.AudioSDRBatch(n_ch); cfg(b)
+            b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True); cfg(b)
             ms, got = run_launches(b, I, Q, 64, 1, 2)
             report("C2 streaming USB 64k x 64 blocks/launch", n_ch, 64, ms, {"parity": check(cfg, I, Q, got, [0, 511, 40000])})
             b.close()
@@ -115,7 +115,7 @@ def main():
         n_ch, uniq = 262144, 3584
         fc = 6890.0 + (np.arange(uniq) % 7 - 3) * 50.0
         I, Q = tiled(n_ch, 16, uniq, fc=fc, A=0.3, m=0.5, fm=400.0)
-        b = A.AudioSDRBatch(n_ch); cfg(b)
+        b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True); cfg(b)
         ms, got = run_launches(b, I, Q, 1, 10, 6)
         st = b.read_status()
         report("C3 SAM 256k x 1 block/launch", n_ch, 1, ms, {"lock_fraction": float(st["sam_locked"].mean()),
@@ -126,7 +126,7 @@ def main():
             s.setDemodMode(c % 7); s.enableALSfilter(); s.setNoiseBlankerThresholdDb(10.0)
         n_ch, uniq = 131072, 3584
         I, Q = tiled(n_ch, 12, uniq, fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15)
-        b = A.AudioSDRBatch(n_ch)
+        b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True)
         for m in range(7):
             pass
         # per-channel modes: c mod 7 (uniq is a multiple of 7, so tiling keeps the pattern)
@@ -144,7 +144,7 @@ def main():
             s.setInputGain(1.0); s.setOutputGain(0.5); s.setIQgainBalance(1.020); s.setAudioFilter(2); s.setDemodMode(6); s.setMute(0)
         n_ch, T, total = 512, 646, 41344     # 41344 = 64 x 646 blocks = one 2-minute WSPR slot at 44.1 kHz
         I, Q = make_iq(n_ch, T, fc=6890.0, A=0.02, noise=0.05)
-        b = A.AudioSDRBatch(n_ch); cfg(b)
+        b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True); cfg(b)
         dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
         b.capture_open(total)              # the whole slot stays in HBM: [512][41344*128] int16 = 5.4 GB
         b.kernel_timing_begin(total // T)

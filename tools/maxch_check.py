@@ -8,7 +8,7 @@ from audiosdr_amd.synth import make_iq
 from oracle import asdr_oracle as ao
 n = 1 << 20
 t0 = time.time()
-b = A.AudioSDRBatch(n)
+b = A.AudioSDRBatch(n); b.set_launch_timing(True)
 b.setDemodMode(A.USBmode); b.enableAudioFilter()
 b.setDemodMode(A.AMmode, ch=n - 1); b.setDemodMode(A.SAMmode, ch=12345)
 uniq = 4096

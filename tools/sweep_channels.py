@@ -13,7 +13,7 @@ for waves_per_cu in [1, 2, 4, 6, 8, 10, 11, 12, 13, 14, 16, 18, 20, 22, 24, 25, 
     dI = torch.from_numpy(np.ascontiguousarray(np.tile(I, (reps, 1, 1))[:n_ch, 0])).cuda()
     dQ = torch.from_numpy(np.ascontiguousarray(np.tile(Q, (reps, 1, 1))[:n_ch, 0])).cuda()
     dO = torch.empty((n_ch, 128), dtype=torch.int16, device="cuda")
-    b = A.AudioSDRBatch(n_ch)
+    b = A.AudioSDRBatch(n_ch); b.set_launch_timing(True)
     b.setDemodMode(1); b.enableAudioFilter()
     ts = []
     for i in range(12):
