@@ -88,7 +88,7 @@ def cpu_baseline(seconds_budget=14.0):
     tp, _ = ao.bench_run(0, Ip, Qp, threads)
     rate_p = Ip.size / tp
     target_s = max(2.0, seconds_budget / 3.0)
-    n_ch = int(min(32768, max(threads, rate_p * target_s / (n_blk * BLOCK))))
+    n_ch = int(min(65536, max(threads, rate_p * target_s / (n_blk * BLOCK))))   # <= 1 GiB of int16 per input array
     n_ch -= n_ch % threads
     n_ch = max(n_ch, threads)
     base = make_iq(min(n_ch, 2048), n_blk, fc=6290.0, A=0.25)
