@@ -20,6 +20,10 @@
 #include "asdr_device.h"
 #include "asdr_tables.h"
 
+// batches of at least this many waves issue a multi-block call as one launch per block (asdr_update_device_strided)
+#ifndef ASDR_PER_BLOCK_LAUNCH_WAVES
+#define ASDR_PER_BLOCK_LAUNCH_WAVES 1024
+#endif
 extern "C" int asdr_kernels_upload_tables(void);
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
@@ -608,20 +612,37 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (nu > 0) subs[n_sub++] = Sub{k, 1, b->kind_first[k], nu};
     if (nm > 0) subs[n_sub++] = Sub{k, 0, b->kind_first[k] + nu, nm};
   }
+  // A multi-block call on a LARGE batch is issued as one launch per block: only the first block of a launch can read the
+  // local-oscillator cache (wave 0 leaves the next LAUNCH's pairs), launches of >= 1024 waves follow each other without a gap
+  // (tools/launch_gap.py), and C2 x 64 blocks ran at 0.157 ms per block inside one launch against 0.129 ms as 64 launches.  Small
+  // batches (C5: 64 waves, 646 blocks) keep the in-kernel block loop: there a launch per 19-us block would be all overhead.
+  int total_slots = 0;
+  for (int i = 0; i < n_sub; i++) total_slots += subs[i].slots;
+  const bool per_block = n_blocks > 1 && total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES;
+  const int n_launch = per_block ? n_blocks : 1;
+  float *const taps = a.taps;
   if (e0) HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
-  if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
-  for (int i = 0; i < n_sub; i++) {
-    hipStream_t s = (i == 0) ? stream : b->aux[i - 1];
-    if (i > 0) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
-    a.sched = b->d_sched + subs[i].first; a.n_sched = subs[i].slots;
-    a.direct_ch0 = -1;
-    if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
-      const SlotInfo &s0 = b->sched[subs[i].first];
-      a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags;
+  for (int lb = 0; lb < n_launch; lb++) {
+    if (per_block) {
+      a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
+      a.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
+      a.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
+      a.taps = (lb == n_launch - 1) ? taps : nullptr;   // the taps are those of the call's last block
     }
-    a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
-    if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
-    if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }
+    if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
+    for (int i = 0; i < n_sub; i++) {
+      hipStream_t s = (i == 0) ? stream : b->aux[i - 1];
+      if (i > 0) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
+      a.sched = b->d_sched + subs[i].first; a.n_sched = subs[i].slots;
+      a.direct_ch0 = -1;
+      if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
+        const SlotInfo &s0 = b->sched[subs[i].first];
+        a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags;
+      }
+      a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
+      if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
+      if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }
+    }
   }
   if (e1) HIPCHK(hipEventRecord(e1, stream));
   b->ev_last_valid = true;
@@ -629,7 +650,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   if (b->region_calls >= 0) b->region_calls++;
   b->last_stream = stream;
   b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
-  b->lo_parity ^= 1u;
+  b->lo_parity ^= (uint32_t)(n_launch & 1);
   return 0;
 }
 

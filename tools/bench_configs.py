@@ -48,7 +48,24 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
         outs.append(dO.cpu().numpy().copy())
         if len(ms) >= timed_launches:
             break
+    # Steady state: the launches above are each preceded by an upload and followed by a download (the parity check needs the
+    # outputs), so they start from an idle GPU -- ~15 % slower than back-to-back launches on resident buffers.  The same launch
+    # repeated on the last resident input for >= 0.2 s, then timed with ONE event pair around the run (as bench.py does).
+    global STEADY_MS
+    one = max(1e-3, float(np.median(ms)))
+    n_rep = int(min(4000, max(20, 250.0 / one)))
+    for _ in range(n_rep):
+        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
+    torch.cuda.synchronize()
+    batch.region_timing_begin(0)
+    for _ in range(n_rep):
+        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
+    total, calls = batch.region_timing_end()
+    STEADY_MS = total / max(1, calls)
     return ms, np.concatenate(outs, axis=1)
+
+
+STEADY_MS = None
 
 
 def check(configure, I, Q, got, channels):
@@ -65,6 +82,9 @@ def report(name, n_ch, T, ms, extra):
     k = float(np.median(ms))
     out = {"config": name, "channels": n_ch, "blocks_per_launch": T, "kernel_ms_median": round(k, 5),
            "Msamples_per_s": round(n_ch * T * BLOCK / k / 1e3, 1), "launches_timed": len(ms)}
+    if STEADY_MS is not None:   # back-to-back launches on resident buffers (see run_launches)
+        out["steady_ms_per_launch"] = round(STEADY_MS, 5)
+        out["steady_Msamples_per_s"] = round(n_ch * T * BLOCK / STEADY_MS / 1e3, 1)
     out.update(extra)
     print(json.dumps(out), flush=True)
 
