@@ -115,8 +115,11 @@ __device__ __forceinline__ double div_by_const(double x, double c, double r) {
   return __builtin_fma(rem, r, q0);
 }
 // sin_f32's phase -> uint16 table phase (AudioSDR.h:362-364): index logic, evaluated in binary64.
+// BELOW_TWO_PI: the caller guarantees phase < twoPI (the PLL: |phase_est| < pi after its wrap, so phase_est and
+// phase_est + pi/2 are below 4.72), which makes the first test dead -- three instructions less on the PLL's dependent chain.
+template <bool BELOW_TWO_PI = false>
 __device__ __forceinline__ uint32_t sin_index(float phase, float two_pi, double inv_two_pi) {
-  if (phase >= two_pi) phase -= two_pi;
+  if (!BELOW_TWO_PI && phase >= two_pi) phase -= two_pi;
   if (phase < 0.0f) phase += two_pi;
   const double q = div_by_const((double)phase * 65535.0, (double)two_pi, inv_two_pi);
   return (uint32_t)(int)q & 0xFFFFu;
@@ -131,12 +134,14 @@ __device__ __forceinline__ float sin_lut(const float *sine, uint32_t ip) {
   const float v1 = sine ? sine[idx] : c_sine[idx], v2 = sine ? sine[idx + 1] : c_sine[idx + 1];
   return v1 + ((v2 - v1) * (float)d) * (1.0f / 256.0f);
 }
+template <bool BELOW_TWO_PI = false>
 __device__ __forceinline__ float sin_f32(const float *sine, float phase, float two_pi, double inv_two_pi) {
-  return sin_lut(sine, sin_index(phase, two_pi, inv_two_pi));
+  return sin_lut(sine, sin_index<BELOW_TWO_PI>(phase, two_pi, inv_two_pi));
 }
 // AudioSDR.h:375-377
+template <bool BELOW_TWO_PI = false>
 __device__ __forceinline__ float cos_f32(const float *sine, float phase, float two_pi, double inv_two_pi, double half_pi_d) {
-  return sin_f32(sine, (float)((double)phase + half_pi_d), two_pi, inv_two_pi);
+  return sin_f32<BELOW_TWO_PI>(sine, (float)((double)phase + half_pi_d), two_pi, inv_two_pi);
 }
 // AudioSDR.h:384-408
 __device__ __forceinline__ float approx_atan(float z) {
@@ -920,8 +925,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               while (phase_est <= -pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
               if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f;
             } }
-          y_re = cos_f32(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);
-          y_im = sin_f32(sine, phase_est, two_pi, K.inv_two_pi_d);
+          y_re = cos_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
+          y_im = sin_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d);
           pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
           locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
           const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
