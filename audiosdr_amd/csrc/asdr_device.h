@@ -142,8 +142,16 @@ typedef struct {
   int32_t in_stride;      /* row stride of I and Q in blocks (>= n_blocks; == n_blocks for the packed layout) */
   int32_t out_stride;     /* row stride of out in blocks (a capture row holds many calls' worth) */
   float *taps;            /* NULL or [ASDR_N_TAPS][n_channels][128] */
+  /* block pipeline of the streaming kernel (asdr_stream_kernel): three role-specialised waves per group of 8 channels
+   * (blanker + IF | mixer + Hilbert | audio filter + AGC + output) work on consecutive blocks of one call at the same time */
+  float *xch_a;           /* [n_channels][ASDR_STREAM_DEPTH][2][128]: IF output I, Q of the blocks in flight (role 1 -> role 2) */
+  float *xch_b;           /* [n_channels][ASDR_STREAM_DEPTH][128]:    demodulated audio (role 2 -> role 3) */
+  uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch; [3 * stream_waves] = error flag */
+  int32_t stream_waves;   /* waves per role = workgroups / 3 */
   ChainConsts k;
 } UpdateArgs;
+#define ASDR_STREAM_DEPTH 4
+#define ASDR_STREAM_SPIN_LIMIT (1u << 18)   /* bounded waits: a broken pipeline ends with the error flag set, never with a hung GPU */
 
 /* instantiations of the update kernel (asdr_launch_update) */
 #define ASDR_KERNEL_PLAIN 0

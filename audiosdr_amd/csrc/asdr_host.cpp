@@ -24,6 +24,16 @@
 #ifndef ASDR_PER_BLOCK_LAUNCH_WAVES
 #define ASDR_PER_BLOCK_LAUNCH_WAVES 1024
 #endif
+// A multi-block call on a SMALL batch of SSB-class channels runs as a block pipeline of three role-specialised waves per channel
+// group (asdr_stream_kernel): all 3 x waves workgroups must be resident at once, hence the cap; shorter calls are not worth the
+// pipeline's fill and drain.
+#ifndef ASDR_STREAM_MAX_WAVES
+#define ASDR_STREAM_MAX_WAVES 512
+#endif
+#ifndef ASDR_STREAM_MIN_BLOCKS
+#define ASDR_STREAM_MIN_BLOCKS 8
+#endif
+extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream);
 extern "C" int asdr_kernels_upload_tables(void);
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
@@ -161,6 +171,13 @@ struct asdr_batch {
   hipEvent_t ev_fork = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_last_valid = false;
   LoEntry *d_lo = nullptr;       // local-oscillator cache, 2 entries (asdr_device.h)
+  // streaming pipeline (asdr_stream_kernel): exchange rings and progress counters, allocated at its first use
+  float *d_xch_a = nullptr, *d_xch_b = nullptr;
+  uint32_t *d_stream_prog = nullptr;
+  bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
+  bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
+  int stream_flag_index = 0;        // 3 * waves of that launch
+  long stat_stream_launches = 0;
   uint32_t lo_parity = 0;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
   ChainConsts k{};
@@ -368,6 +385,15 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
         direct = (sl[j].ch == sl[0].ch + j) && sl[j].mode == sl[0].mode && sl[j].flags == sl[0].flags;
       b->kind_direct[k] = direct;
     }
+    {
+      const SlotInfo *sl = b->sched.data() + b->kind_first[ASDR_KERNEL_PLAIN];
+      bool ssb = b->kind_uniform_slots[ASDR_KERNEL_PLAIN] > 0;
+      for (int j = 0; j < b->kind_uniform_slots[ASDR_KERNEL_PLAIN] && ssb; j += 8) {
+        const uint32_t m = sl[j].mode;
+        ssb = (m == ASDR_USBmode || m == ASDR_LSBmode || m == ASDR_CW_USBmode || m == ASDR_CW_LSBmode || m == ASDR_WSPRmode);
+      }
+      b->plain_uniform_ssb = ssb;
+    }
     b->sched_dirty = false;
     sched_rebuilt = true;
     b->stat_sched_rebuilds++;
@@ -553,7 +579,8 @@ void asdr_destroy(asdr_batch_t *b) {
   hipSetDevice(b->device);
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
-                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture};
+                  b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
+                  b->d_xch_a, b->d_xch_b, b->d_stream_prog};
   for (void *p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -568,6 +595,19 @@ void asdr_destroy(asdr_batch_t *b) {
 }
 
 int asdr_n_channels(const asdr_batch_t *b) { return b ? b->n : 0; }
+
+// Error flag of the last streaming pipeline launch (a wave gave up waiting for its neighbour role: ASDR_STREAM_SPIN_LIMIT).
+static int check_stream_error(asdr_batch *b) {
+  if (!b->stream_launched || !b->d_stream_prog) return 0;
+  HIPCHK(hipStreamSynchronize(b->last_stream));
+  uint32_t flag = 0;
+  const int w_max = (b->n + 7) / 8;
+  (void)w_max;
+  HIPCHK(hipMemcpy(&flag, b->d_stream_prog + b->stream_flag_index, sizeof flag, hipMemcpyDeviceToHost));
+  b->stream_launched = false;
+  if (flag) return fail("streaming pipeline: a wave timed out waiting for its neighbour role (results of that call are invalid)");
+  return 0;
+}
 
 int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
                                long in_stride_blocks, long out_stride_blocks, void *stream_) {
@@ -619,6 +659,35 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   int total_slots = 0;
   for (int i = 0; i < n_sub; i++) total_slots += subs[i].slots;
   const bool per_block = n_blocks > 1 && total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES;
+  // Small batch, many blocks, one sub-range of uniform SSB-class waves, no taps: the block pipeline.
+  static const bool no_stream = getenv("ASDR_NO_STREAM_PIPELINE") != nullptr;   // measurement switch (tools/bench_configs.py)
+  if (!no_stream && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN && subs[0].uniform &&
+      b->plain_uniform_ssb && !b->taps_on && subs[0].slots / 8 <= ASDR_STREAM_MAX_WAVES) {
+    const int w = subs[0].slots / 8;
+    if (!b->d_xch_a) {
+      HIPCHK(hipMalloc(&b->d_xch_a, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * 2 * ASDR_N * sizeof(float)));
+      HIPCHK(hipMalloc(&b->d_xch_b, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)));
+      HIPCHK(hipMalloc(&b->d_stream_prog, (size_t)(3 * ((b->n + 7) / 8) + 1) * sizeof(uint32_t)));
+    }
+    if (b->stream_launched && check_stream_error(b) != 0) return -1;   // (synchronises) the previous pipeline's flag, before it is cleared
+    HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));
+    a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
+    a.direct_ch0 = -1;
+    if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; }
+    a.lo_write = 0u;
+    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_waves = w;
+    if (e0) HIPCHK(hipEventRecord(e0, stream));
+    if (asdr_launch_stream(&a, stream) != 0) return fail("stream kernel launch failed");
+    if (e1) HIPCHK(hipEventRecord(e1, stream));
+    b->stream_launched = true; b->stream_flag_index = 3 * w; b->stat_stream_launches++;
+    b->ev_last_valid = true;
+    b->ev_valid = (e0 != nullptr && e0 == b->ev0);
+    if (b->region_calls >= 0) b->region_calls++;
+    b->last_stream = stream;
+    b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
+    b->lo_parity ^= 1u;
+    return 0;
+  }
   const int n_launch = per_block ? n_blocks : 1;
   float *const taps = a.taps;
   if (e0) HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
@@ -731,7 +800,7 @@ int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *ou
   if (asdr_update_device(b, b->d_io[0], b->d_io[1], b->d_io[2], n_blocks, b->stream) != 0) return -1;
   HIPCHK(hipMemcpyAsync(out, b->d_io[2], count * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  return 0;
+  return check_stream_error(b);
 }
 
 int asdr_synchronize(asdr_batch_t *b) {
@@ -740,7 +809,7 @@ int asdr_synchronize(asdr_batch_t *b) {
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
-  return 0;
+  return check_stream_error(b);
 }
 
 float asdr_last_kernel_ms(asdr_batch_t *b) {
@@ -979,6 +1048,8 @@ unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]) {
   const Chan *c = get(b, ch);
   return c ? c->agc_hang_count : 0u;
 }
+
+long asdr_stream_pipeline_launches(asdr_batch_t *b) { return b ? b->stat_stream_launches : -1; }
 
 int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
   if (!b) return fail("null batch");

@@ -401,10 +401,31 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // WAVES: waves per workgroup.  1 everywhere except the SAM instantiation (4): there the per-sample PLL recurrence -- by far the
 // longest dependent chain of the whole path, one lane per channel -- is run for all 32 channels of the workgroup by ONE wave
 // (32 lanes busy instead of 8 in each of 4 waves) while the sibling waves wait at a workgroup barrier.
-template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES>
+// ROLE: 0 = the whole chain (every launch but the streaming pipeline's).  1 / 2 / 3 = one third of it, for asdr_stream_kernel:
+// 1 = input scale + blanker + IF filter, 2 = mixer + Hilbert + sideband, 3 = audio filter + AGC + output (SSB-class modes,
+// no ALS).  A role skips the other thirds by seeing their enables as off; the rows that cross a boundary (IF output I/Q; the
+// demodulated audio) travel through exchange rings in HBM, ordered by per-wave progress counters (release / acquire, agent scope).
+// Spin-wait until *p >= target (all lanes read the same word); false = gave up (error flag set, see ASDR_STREAM_SPIN_LIMIT).
+__device__ __forceinline__ bool stream_wait(const uint32_t *p, uint32_t target, uint32_t *err) {
+  uint32_t spins = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > ASDR_STREAM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+__device__ __forceinline__ void stream_signal(uint32_t *p, uint32_t value, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every lane's stores of this block are visible before the counter moves
+  if (lane == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds_wg) {
+  constexpr bool DO1 = (ROLE == 0 || ROLE == 1), DO2 = (ROLE == 0 || ROLE == 2), DO3 = (ROLE == 0 || ROLE == 3);
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
-  const int wave_g = (int)blockIdx.x * WAVES + wave;        // this wave's index in the launched schedule sub-range
+  // this wave's index in the launched schedule sub-range (the streaming pipeline launches its three roles one after the other)
+  const int wave_g = (ROLE == 0) ? (int)blockIdx.x * WAVES + wave : (int)blockIdx.x % a.stream_waves;
   float *const lds = lds_wg + wave * 8 * STRIDE;            // this wave's 8 channel rows
   const int lane = threadIdx.x & 63, c8 = lane >> 3, s8_ = lane & 7;
   float *const sine = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : nullptr;
@@ -422,12 +443,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
   const uint32_t mode = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.y) : (uint32_t)slot.y;
   const uint32_t pflags = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.z) : (uint32_t)slot.z;
-  const bool is_ssb = (mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
-                      (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode);
+  const bool is_ssb = DO2 && ((mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
+                              (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode));
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
   const bool is_am = (mode == ASDR_AMmode), is_sam = HAS_SAM && (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
-  const bool nb_en = pflags & ASDR_F_NB_EN, af_en = pflags & ASDR_F_AF_EN, agc_en = pflags & ASDR_F_AGC_EN;
+  const bool nb_en = DO1 && (pflags & ASDR_F_NB_EN), af_en = DO3 && (pflags & ASDR_F_AF_EN), agc_en = DO3 && (pflags & ASDR_F_AGC_EN);
   const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
   const bool muted = pflags & ASDR_F_MUTED;
   const float two_pi = K.two_pi_f;
@@ -441,6 +462,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int loff = loff_; asm volatile("" : "+v"(loff));
     int ch = ch_; asm volatile("" : "+v"(ch));
     int lane_i = lane; asm volatile("" : "+v"(lane_i));   // for the rarely taken paths: their addresses must not be hoisted (and spilled)
+    if (ROLE != 0) {   // streaming pipeline: wait for this block's input rows and for a free slot in the ring this role writes
+      uint32_t *prog = a.stream_prog, *err = a.stream_prog + 3 * a.stream_waves;
+      const uint32_t b1 = (uint32_t)blk + 1u, freed = (blk >= ASDR_STREAM_DEPTH) ? (uint32_t)(blk - ASDR_STREAM_DEPTH + 1) : 0u;
+      if (ROLE == 1) stream_wait(prog + a.stream_waves + wave_g, freed, err);                      // role 2 has left slot blk % DEPTH
+      if (ROLE == 2) { stream_wait(prog + wave_g, b1, err); stream_wait(prog + 2 * a.stream_waves + wave_g, freed, err); }
+      if (ROLE == 3) stream_wait(prog + a.stream_waves + wave_g, b1, err);
+    }
     const ChanParams *Pp = row_ptr(a.params, (uint32_t)ch * (uint32_t)sizeof(ChanParams));
     ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
     float *L = lds + loff;
@@ -501,7 +529,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
     roi[0].v = roi[1].v = roq[0].v = roq[1].v = rmi[0].v = rmi[1].v = rmq[0].v = rmq[1].v = make_int4(0, 0, 0, 0);
     uint32_t mkc[5] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};   // defined on every path
-    if (valid) {
+    if (DO1 && valid) {
       const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
       const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
       ri[0].v = pi[0]; ri[1].v = pi[8]; rq[0].v = pq[0]; rq[1].v = pq[8];   // int4 #8 = 64 samples on
@@ -541,7 +569,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int h = 0; h < 2; ++h) { float xi[8], xq[8]; scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
                                       TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq); }
       }
-    } else {
+    } else if (DO1) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float xi[8], xq[8];
@@ -599,7 +627,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       TL(2);
-      if (ABL_ON(ABL_IF) && WAVES == 1) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
+      if (DO1 && ABL_ON(ABL_IF) && WAVES == 1) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
                                             // (not in the multi-wave SAM instantiation: no registers to spare)
         if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
         const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
@@ -623,7 +651,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float bm[8];
         load8(L + NB_B + 2, bm);
         int c_tail = 0;   // first chunk of the average-only loop below
-        if (!lo_hit) {
+        if (!lo_hit && (DO2 || !UNIFORM)) {
         c_tail = 16;
         // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
         // wrap `t < 0 ? t + twoPI : t` is a sign-mask select (v_ashrrev + v_bfi, no compare -> VCC -> select hazard): the phase
@@ -847,7 +875,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
       for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
     };
-    if (ABL_ON(ABL_IF) && !HAS_ALS) {   // (the ALS instantiations keep the old order: they spill with this one)
+    if (DO1 && ABL_ON(ABL_IF) && !HAS_ALS) {   // (the ALS instantiations keep the old order: they spill with this one)
       if (!if_pre) load_if_rows();
       asm volatile("" : "+v"(if_s4.x), "+v"(if_s4.y), "+v"(if_s4.z), "+v"(if_s4.w), "+v"(if_cf[0]), "+v"(if_cf[1]), "+v"(if_cf[2]), "+v"(if_cf[3]), "+v"(if_cf[4]));
     }
@@ -874,7 +902,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       for (int m = 0; m < 4; ++m) { load4(lo_rd->c + kF + 32 * m, lo_c + 4 * m); load4(lo_rd->s + kF + 32 * m, lo_s + 4 * m); }
     }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
-    if (ABL_ON(ABL_IF)) {
+    if (DO1 && ABL_ON(ABL_IF)) {
       const int iq = s8 >> 2, st = s8 & 3;
       float sv[4];
       if (HAS_ALS && !if_pre) load_if_rows();
@@ -885,6 +913,32 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     WAVE_SYNC();
     TL(5);
     TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1);
+    // A role's own status bits go back with atomics: the three roles of a channel group update one word
+    auto store_status_bits = [&](uint32_t mask) {
+      if (lead) { atomicAnd(&S->status, ~mask); atomicOr(&S->status, status & mask); }
+    };
+    if (ROLE == 1 || ROLE == 2) {   // streaming pipeline, boundary A: the IF output rows I (W0), Q (W1) cross through the exchange ring
+      float *xa = a.xch_a + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH)) * (2 * ASDR_N) + kF;
+      if (ROLE == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float vi[4], vq[4];
+          load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
+          store4(xa + 32 * m, vi); store4(xa + ASDR_N + 32 * m, vq);
+        }
+        store_status_bits(ASDR_S_NB_DETECTED);
+        stream_signal(a.stream_prog + wave_g, (uint32_t)blk + 1u, lane);
+        continue;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float vi[4], vq[4];
+          load4(xa + 32 * m, vi); load4(xa + ASDR_N + 32 * m, vq);
+          store4(L + W0 + kF + 32 * m, vi); store4(L + W1 + kF + 32 * m, vq);
+        }
+        WAVE_SYNC();
+      }
+    }
 
     // ---- SAM: quadrature PLL, AudioSDR.cpp:688-749 (sequential per channel) ---------------------------------
     bool pll_locked = false;
@@ -1216,13 +1270,26 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         store8(L + W0 + kA + 64 * h, vq);
       }
     }
-    if (!is_ssb && !is_am && mode != ASDR_SAMmode) {   // unknown mode: the reference re-processes stale audio; we emit silence
+    if (ROLE == 0 && !is_ssb && !is_am && mode != ASDR_SAMmode) {   // unknown mode: the reference re-processes stale audio; we emit silence
       const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       store8(L + W0 + kA, z); store8(L + W0 + kA + 64, z);
     }
     WAVE_SYNC();
     TL(10);
     TAP_ROW(ASDR_TAP_DEMOD, W0);
+    if (ROLE == 2 || ROLE == 3) {   // streaming pipeline, boundary B: the demodulated audio row (W0)
+      float *xb = a.xch_b + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH)) * ASDR_N + kF;
+      if (ROLE == 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { float v[4]; load4(L + W0 + kF + 32 * m, v); store4(xb + 32 * m, v); }
+        stream_signal(a.stream_prog + a.stream_waves + wave_g, (uint32_t)blk + 1u, lane);
+        continue;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { float v[4]; load4(xb + 32 * m, v); store4(L + W0 + kF + 32 * m, v); }
+        WAVE_SYNC();
+      }
+    }
 
     // the AGC gain table (row of 132 floats) is requested before the audio-filter pipeline and staged in LDS after it
     float4 agc_t4[5];
@@ -1466,12 +1533,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         SCHED_FENCE();
       }
-      if (valid) {
+      if (DO3 && valid) {
         int4 *po = reinterpret_cast<int4 *>(a.out + io_out);
         po[0] = ro[0].v; po[8] = ro[1].v;
       }
     }
-    if (lead) S->status = status;
+    if (ROLE == 0) { if (lead) S->status = status; }
+    else { store_status_bits(ASDR_S_AGC_ACTIVE); stream_signal(a.stream_prog + 2 * a.stream_waves + wave_g, (uint32_t)blk + 1u, lane); }
     WAVE_SYNC();
     // Wave 0 of the designated launch leaves the NEXT block's local-oscillator pairs in the other cache entry (LoEntry).
     if (a.lo_write && wave_g == 0 && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
@@ -1530,6 +1598,21 @@ ASDR_KERNEL(asdr_update_kernel_sam, ASDR_SAM_WAVES * 8 * ASDR_STRIDE + 260, ASDR
 #endif
 ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true, 1)
 ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
+
+// Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves);
+// all 3W workgroups must be resident together (the host launches it only for small batches).  Uniform-key SSB waves only.
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_stream_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  const int role = (int)blockIdx.x / a.stream_waves;   // wave-uniform
+  if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
+  else if (role == 1) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 2>(a, lds);
+  else asdr_update_body<ASDR_STRIDE, false, false, true, 1, 3>(a, lds);
+}
+extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
+  if (a->stream_waves <= 0) return 0;
+  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(64), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
 extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {

@@ -204,6 +204,11 @@ int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]);
  * beta_freq, f_conv, lock_freq_low, lock_freq_high, twoPI, halfPI, twoPI/AUDIO_SAMPLE_RATE_EXACT, 1 - nb alpha; returns the
  * AGC hang count (samples) of channel `ch` (0 for a bad channel). */
 unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]);
+/* How many calls so far ran as the streaming block pipeline (a multi-block call on a small batch of SSB-class channels:
+ * three role-specialised waves per group of 8 channels -- blanker + IF | mixer + Hilbert | audio filter + AGC + output -- work
+ * on consecutive blocks at the same time).  Results are bit-identical to the block-by-block path; the counter
+ * exists so that tests and benchmarks can tell which path ran. */
+long asdr_stream_pipeline_launches(asdr_batch_t *b);
 /* Library / build identification string (contains "gfx950"). */
 const char *asdr_version(void);
 

@@ -100,3 +100,83 @@ def test_capture_long_stream_from_resident_input(gpu, ao):
     for c in (0, 7, 15):
         assert np.array_equal(batch.capture_read(c), orcs[c].update(I[c], Q[c])), "ch %d" % c
     hip.free_all(); batch.close()
+
+
+# ---- block pipeline (asdr_stream_kernel): a multi-block call on a small batch of uniform SSB-class waves ------------------
+def _compare_status(batch, orcs):
+    st = batch.read_status()
+    for c, o in enumerate(orcs):
+        assert int(st["agc_active"][c]) == o.AGCisActive(), "AGCisActive ch %d" % c
+        assert int(st["nb_detected"][c]) == o.NoiseBlankerDetection(), "NoiseBlankerDetection ch %d" % c
+
+
+def test_block_pipeline_parity_and_hand_over(gpu, ao):
+    """64 USB channels (blanker with impulses, audio filter, AGC): calls of 40, 1, 24, 3 and 16 blocks.  The 40-, 24- and 16-block
+    calls run as the three-role block pipeline, the others block by block: every block of every channel equals the oracle, i.e.
+    the per-channel state is handed over correctly in both directions, and the status bits (written by two different roles) match."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 64, (40, 1, 24, 3, 16)
+    total = sum(plan)
+    I, Q = make_iq(n_ch, total, fc=6290.0, A=0.25, noise=0.02, impulse_every=777)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0)])
+    hip = Hip()
+    pos = 0
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call of %d blocks at %d, ch %d" % (T, pos, c)
+        pos += T
+    assert batch.stream_pipeline_launches() == 3
+    _compare_status(batch, orcs)
+    hip.free_all(); batch.close()
+
+
+def test_block_pipeline_key_groups(gpu, ao):
+    """Four key groups of 16 channels (USB / LSB with the blanker off / CW with the audio filter / WSPR as the reference's WSPR
+    receiver configures it), each two uniform waves: one sub-range of uniform waves with different modes and enables per wave."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, T = 64, 33
+    I, Q = make_iq(n_ch, T, fc=6290.0, A=0.2, noise=0.03, impulse_every=500, m=0.3)
+    grp = lambda g: (lambda c: c // 16 == g)
+    setters = [S("setDemodMode", 0, sel=grp(0)), S("setNoiseBlankerThresholdDb", 9.0, sel=grp(0)),
+               S("setDemodMode", 1, sel=grp(1)), S("disableNoiseBlanker", sel=grp(1)), S("setAGCmode", 1, sel=grp(1)),
+               S("setDemodMode", 2, sel=grp(2)), S("enableAudioFilter", sel=grp(2)), S("setAudioFilter", 0, sel=grp(2)),
+               S("setOutputGain", 0.7, sel=grp(2))]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    apply_setters(batch, orcs, [(m, a, (lambda c, s=s: c // 16 == 3 and (s is None or s(c)))) for (m, a, s) in WSPR])
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    dO = hip.malloc(n_ch * T * 256)
+    batch.update_device(dI, dQ, dO, T)
+    batch.synchronize()
+    got = hip.download(dO, (n_ch, T, 128), np.int16)
+    assert batch.stream_pipeline_launches() == 1
+    for c in range(n_ch):
+        want = orcs[c].update(I[c], Q[c]).reshape(T, 128)
+        assert np.array_equal(got[c], want), "ch %d" % c
+    _compare_status(batch, orcs)
+    hip.free_all(); batch.close()
+
+
+def test_block_pipeline_is_not_used_where_it_does_not_apply(gpu, ao):
+    """An AM channel group, stage taps, a ragged channel count or a short call keep the block-by-block path (same results either way)."""
+    from audiosdr_amd.synth import make_iq
+    T = 12
+    for n_ch, setters, taps in ((64, [S("setDemodMode", 4)], False), (64, [S("setDemodMode", 1)], True), (61, [S("setDemodMode", 1)], False)):
+        I, Q = make_iq(n_ch, T, fc=6290.0, A=0.25)
+        batch, orcs = _mk(gpu, ao, n_ch, setters)
+        if taps:
+            batch.enable_taps(True)
+        hip = Hip()
+        dI, dQ = hip.upload(I), hip.upload(Q)
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.update_device(dI, dQ, dO, 4)          # short call (state continues; only the launch count matters here)
+        batch.synchronize()
+        assert batch.stream_pipeline_launches() == 0
+        hip.free_all(); batch.close()
