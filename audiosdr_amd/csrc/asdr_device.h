@@ -146,11 +146,14 @@ typedef struct {
    * (blanker + IF | mixer + Hilbert | audio filter + AGC + output) work on consecutive blocks of one call at the same time */
   float *xch_a;           /* [n_channels][ASDR_STREAM_DEPTH][2][128]: IF output I, Q of the blocks in flight (role 1 -> role 2) */
   float *xch_b;           /* [n_channels][ASDR_STREAM_DEPTH][128]:    demodulated audio (role 2 -> role 3) */
-  uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch; [3 * stream_waves] = error flag */
-  int32_t stream_waves;   /* waves per role = workgroups / 3 */
+  uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch; [3 * stream_waves] = error flag, [+1] = oscillator role's progress */
+  int32_t stream_waves;   /* waves per role = (workgroups - 1) / 3 */
+  LoEntry *lo_ring;       /* [ASDR_LO_RING] the streaming pipeline's oscillator role leaves block b's pairs in entry b % ASDR_LO_RING;
+                             its progress counter is stream_prog[3 * stream_waves + 1] */
   ChainConsts k;
 } UpdateArgs;
 #define ASDR_STREAM_DEPTH 4
+#define ASDR_LO_RING 8
 #define ASDR_STREAM_SPIN_LIMIT (1u << 18)   /* bounded waits: a broken pipeline ends with the error flag set, never with a hung GPU */
 
 /* instantiations of the update kernel (asdr_launch_update) */

@@ -28,7 +28,7 @@
 // group (asdr_stream_kernel): all 3 x waves workgroups must be resident at once, hence the cap; shorter calls are not worth the
 // pipeline's fill and drain.
 #ifndef ASDR_STREAM_MAX_WAVES
-#define ASDR_STREAM_MAX_WAVES 512
+#define ASDR_STREAM_MAX_WAVES 84   /* 3 x 84 + 1 = 253 workgroups: one per CU, the condition the fence-free hand-off is measured for */
 #endif
 #ifndef ASDR_STREAM_MIN_BLOCKS
 #define ASDR_STREAM_MIN_BLOCKS 8
@@ -174,6 +174,7 @@ struct asdr_batch {
   // streaming pipeline (asdr_stream_kernel): exchange rings and progress counters, allocated at its first use
   float *d_xch_a = nullptr, *d_xch_b = nullptr;
   uint32_t *d_stream_prog = nullptr;
+  LoEntry *d_lo_ring = nullptr;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   int stream_flag_index = 0;        // 3 * waves of that launch
@@ -580,7 +581,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
-                  b->d_xch_a, b->d_xch_b, b->d_stream_prog};
+                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring};
   for (void *p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -667,15 +668,16 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (!b->d_xch_a) {
       HIPCHK(hipMalloc(&b->d_xch_a, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * 2 * ASDR_N * sizeof(float)));
       HIPCHK(hipMalloc(&b->d_xch_b, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)));
-      HIPCHK(hipMalloc(&b->d_stream_prog, (size_t)(3 * ((b->n + 7) / 8) + 1) * sizeof(uint32_t)));
+      HIPCHK(hipMalloc(&b->d_stream_prog, (size_t)(3 * ((b->n + 7) / 8) + 2) * sizeof(uint32_t)));
+      HIPCHK(hipMalloc(&b->d_lo_ring, ASDR_LO_RING * sizeof(LoEntry)));
     }
     if (b->stream_launched && check_stream_error(b) != 0) return -1;   // (synchronises) the previous pipeline's flag, before it is cleared
-    HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));
+    HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 2) * sizeof(uint32_t), stream));
     a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
     a.direct_ch0 = -1;
     if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; }
     a.lo_write = 0u;
-    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_waves = w;
+    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_waves = w; a.lo_ring = b->d_lo_ring;
     if (e0) HIPCHK(hipEventRecord(e0, stream));
     if (asdr_launch_stream(&a, stream) != 0) return fail("stream kernel launch failed");
     if (e1) HIPCHK(hipEventRecord(e1, stream));

@@ -54,7 +54,8 @@
 
 #define PI_D 3.1415926535897932384626433832795 /* Arduino.h PI (double) */
 
-typedef float v2f __attribute__((ext_vector_type(2)));   // one aligned VGPR pair: operand of v_pk_mul_f32 / v_pk_add_f32
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // one aligned VGPR quad (operand of the exchange rings' inline-assembly accesses)   // one aligned VGPR pair: operand of v_pk_mul_f32 / v_pk_add_f32
 
 // Build-time ablation mask for profiling builds (DESIGN.md "ablation"); the shipped library uses 0.
 #ifndef ASDR_ABLATE
@@ -405,19 +406,37 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // 1 = input scale + blanker + IF filter, 2 = mixer + Hilbert + sideband, 3 = audio filter + AGC + output (SSB-class modes,
 // no ALS).  A role skips the other thirds by seeing their enables as off; the rows that cross a boundary (IF output I/Q; the
 // demodulated audio) travel through exchange rings in HBM, ordered by per-wave progress counters (release / acquire, agent scope).
+// Hand-off between workgroups without agent-scope fences (which cost 1.7 us per acquire and 1.7-6.5 us per release on this part:
+// MI355X_MICROARCH.md, inter-workgroup visibility): EVERY store of the handed-off rows is an `sc1` (write-through) store, the
+// storing wave drains them (`s_waitcnt vmcnt(0)`) before ONE lane stores the `sc1` counter; the consumer polls the counter with
+// `sc1` loads and then reads EVERY handed-off byte with `sc1` loads to registers (they bypass the CU's vector L1, which another
+// CU's stores never refresh).  One wave per workgroup, one workgroup per CU (the host caps the pipeline at 3 x waves <= 255).
 // Spin-wait until *p >= target (all lanes read the same word); false = gave up (error flag set, see ASDR_STREAM_SPIN_LIMIT).
-__device__ __forceinline__ bool stream_wait(const uint32_t *p, uint32_t target, uint32_t *err) {
-  uint32_t spins = 0;
-  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(8);
-    if (++spins > ASDR_STREAM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+// Returns the counter value it saw (>= target; the caller keeps it: a producer that is several blocks ahead is polled once).
+__device__ __forceinline__ uint32_t stream_wait(const uint32_t *p, uint32_t target, uint32_t *err) {
+  uint32_t spins = 0, v;
+  while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > ASDR_STREAM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = target; break; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return true;
+  asm volatile("" ::: "memory");   // no load of the handed-off rows may be moved in front of the poll
+  return v;
 }
 __device__ __forceinline__ void stream_signal(uint32_t *p, uint32_t value, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every lane's stores of this block are visible before the counter moves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores (all of a channel group's rows are its own) have left
   if (lane == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// four 16-byte pieces (p + 32 m floats, m = 0..3) of an exchange row, `sc1`; the loads are waited for inside
+__device__ __forceinline__ void xch_store4x4(float *p, v4f v0, v4f v1, v4f v2, v4f v3) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:128 sc1\n\t"
+               "global_store_dwordx4 %0, %3, off offset:256 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:384 sc1"
+               :: "v"(p), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
+}
+__device__ __forceinline__ void xch_load4x4(const float *p, v4f &v0, v4f &v1, v4f &v2, v4f &v3) {
+  asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:128 sc1\n\t"
+               "global_load_dwordx4 %2, %4, off offset:256 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:384 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p) : "memory");
 }
 
 template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0>
@@ -453,6 +472,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const bool muted = pflags & ASDR_F_MUTED;
   const float two_pi = K.two_pi_f;
   WAVE_SYNC();
+  // streaming pipeline: the neighbours' progress as last seen, and this role's own progress not yet published (roles 2 and 3
+  // publish block b only after their loads of block b + 1 have returned: that wait drains the stores of block b for free)
+  uint32_t seen_in = 0u, seen_free = 0u, seen_lo = 0u, sig_pending = 0u;
+  // ... and the state role 2 carries from block to block in registers instead of reading back what it has just stored (the
+  // stores still happen: HBM holds the state after the call): mixer phase, frequency shift, Hilbert ring parity
+  float carry_phase = 0.0f, carry_fsh = 0.0f;
+  uint32_t carry_hs = 0u;
+  uint32_t *const my_prog = (ROLE == 0) ? nullptr : a.stream_prog + (ROLE - 1) * a.stream_waves + wave_g;
 
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
@@ -465,9 +492,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ROLE != 0) {   // streaming pipeline: wait for this block's input rows and for a free slot in the ring this role writes
       uint32_t *prog = a.stream_prog, *err = a.stream_prog + 3 * a.stream_waves;
       const uint32_t b1 = (uint32_t)blk + 1u, freed = (blk >= ASDR_STREAM_DEPTH) ? (uint32_t)(blk - ASDR_STREAM_DEPTH + 1) : 0u;
-      if (ROLE == 1) stream_wait(prog + a.stream_waves + wave_g, freed, err);                      // role 2 has left slot blk % DEPTH
-      if (ROLE == 2) { stream_wait(prog + wave_g, b1, err); stream_wait(prog + 2 * a.stream_waves + wave_g, freed, err); }
-      if (ROLE == 3) stream_wait(prog + a.stream_waves + wave_g, b1, err);
+      const bool need_in = (ROLE != 1) && seen_in < b1, need_free = (ROLE != 3) && seen_free < freed;
+      if ((need_in || need_free) && sig_pending) { stream_signal(my_prog, sig_pending, lane); sig_pending = 0u; }   // publish before blocking
+      if (need_in) seen_in = stream_wait(prog + (ROLE - 2) * a.stream_waves + wave_g, b1, err);       // the previous role has stored block blk
+      if (need_free) seen_free = stream_wait(prog + ROLE * a.stream_waves + wave_g, freed, err);      // the next role has left slot blk % DEPTH
     }
     const ChanParams *Pp = row_ptr(a.params, (uint32_t)ch * (uint32_t)sizeof(ChanParams));
     ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
@@ -505,15 +533,29 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const bool mix_early = is_ssb || is_am;
     float mphase = 0.0f, minc = 0.0f, mphase_end = 0.0f;   // mphase_end: valid on the lead lanes once the sequence has been computed
     float fsh_raw = 0.0f;
-    if (mix_early) { mphase = is_ssb ? S->phase_ssb : S->phase_am; fsh_raw = P.freq_shift; }
+    if (mix_early) {
+      if (ROLE == 2 && blk > 0) { mphase = carry_phase; fsh_raw = carry_fsh; }
+      else { mphase = is_ssb ? S->phase_ssb : S->phase_am; fsh_raw = P.freq_shift; }
+    }
     const float nb_thr = P.nb_threshold;   // used after the blanker's sequential pass: requested here, not there
-    const LoEntry *lo_rd = a.lo_cache + (a.lo_parity & 1u);
-    const uint32_t lo_kp = lo_rd->key_phase, lo_ki = lo_rd->key_inc;
-    const float lo_end = lo_rd->phase_end;
+    // Oscillator pairs of this block: the launch-to-launch cache entry, or -- pipeline role 2 -- the entry the pipeline's
+    // oscillator role has left for block blk (EVERY block of the call can hit; read with `sc1` loads, see stream_wait)
+    const LoEntry *lo_rd = (ROLE == 2) ? a.lo_ring + (blk % ASDR_LO_RING) : a.lo_cache + (a.lo_parity & 1u);
+    uint32_t lo_kp, lo_ki;
+    float lo_end;
+    if (ROLE == 2) {
+      if (seen_lo < (uint32_t)blk + 1u) seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves + 1, (uint32_t)blk + 1u, a.stream_prog + 3 * a.stream_waves);
+      v4f key;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(key) : "v"(lo_rd) : "memory");
+      lo_kp = __float_as_uint(key[0]); lo_ki = __float_as_uint(key[1]); lo_end = key[2];
+    } else {
+      lo_kp = lo_rd->key_phase; lo_ki = lo_rd->key_inc; lo_end = lo_rd->phase_end;
+    }
     // Ring positions.  The blanker ring advances once per processed block for EVERY channel (a batch-wide block counter):
     // enabling the blanker or changing its threshold resets all three slots (AudioSDR.cpp:653-682), so a channel whose
     // blanker was off meanwhile never sees a stale position -- and no load has to wait for a per-channel slot word.
-    const uint32_t ns = (a.nb_phase + (uint32_t)blk) % 3u, hs = S->hil_slot & 1u;   // oldest NB ring slot (of 3), Hilbert ring parity
+    const uint32_t ns = (a.nb_phase + (uint32_t)blk) % 3u;                          // oldest NB ring slot (of 3)
+    const uint32_t hs = (ROLE == 2 && blk > 0) ? carry_hs : (S->hil_slot & 1u);     // Hilbert ring parity
     const uint32_t ns_mid = (ns + 1u) % 3u, ns_new = (ns + 2u) % 3u;
     float carrier_now = 0.0f;   // set by the envelope path when it runs in this block
     bool carrier_fresh = false;
@@ -551,7 +593,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (mix_early) minc = (is_ssb ? -fsh_raw : -K.if_center) * K.phase_inc_unit;
     bool ph_ready = false;   // this channel's phase sequence is in its PH row
     bool lo_hit = false;
-    if (blk == 0) lo_hit = __all(mix_early && __float_as_uint(mphase) == lo_kp && __float_as_uint(minc) == lo_ki);
+    if (blk == 0 || ROLE == 2) lo_hit = __all(mix_early && __float_as_uint(mphase) == lo_kp && __float_as_uint(minc) == lo_ki);
     if (lo_hit && lead) { if (is_ssb) S->phase_ssb = lo_end; else S->phase_am = lo_end; }
 
     // ---- input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
@@ -898,8 +940,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float lo_c[16], lo_s[16];
     DEFINE_ALL_PATHS(lo_c, 16); DEFINE_ALL_PATHS(lo_s, 16);
     if (RING_PREFETCH && lo_hit) {
+      if (ROLE == 2) {   // written by another workgroup during this launch: `sc1` loads
+        v4f c4[4], s4[4];
+        xch_load4x4(lo_rd->c + kF, c4[0], c4[1], c4[2], c4[3]); xch_load4x4(lo_rd->s + kF, s4[0], s4[1], s4[2], s4[3]);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { load4(lo_rd->c + kF + 32 * m, lo_c + 4 * m); load4(lo_rd->s + kF + 32 * m, lo_s + 4 * m); }
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { lo_c[4 * m + j] = c4[m][j]; lo_s[4 * m + j] = s4[m][j]; }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { load4(lo_rd->c + kF + 32 * m, lo_c + 4 * m); load4(lo_rd->s + kF + 32 * m, lo_s + 4 * m); }
+      }
     }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
     if (DO1 && ABL_ON(ABL_IF)) {
@@ -920,22 +972,19 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ROLE == 1 || ROLE == 2) {   // streaming pipeline, boundary A: the IF output rows I (W0), Q (W1) cross through the exchange ring
       float *xa = a.xch_a + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH)) * (2 * ASDR_N) + kF;
       if (ROLE == 1) {
+        v4f vi[4], vq[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float vi[4], vq[4];
-          load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
-          store4(xa + 32 * m, vi); store4(xa + ASDR_N + 32 * m, vq);
-        }
+        for (int m = 0; m < 4; ++m) { vi[m] = *reinterpret_cast<const v4f *>(L + W0 + kF + 32 * m); vq[m] = *reinterpret_cast<const v4f *>(L + W1 + kF + 32 * m); }
+        xch_store4x4(xa, vi[0], vi[1], vi[2], vi[3]); xch_store4x4(xa + ASDR_N, vq[0], vq[1], vq[2], vq[3]);
         store_status_bits(ASDR_S_NB_DETECTED);
         stream_signal(a.stream_prog + wave_g, (uint32_t)blk + 1u, lane);
         continue;
       } else {
+        v4f vi[4], vq[4];
+        xch_load4x4(xa, vi[0], vi[1], vi[2], vi[3]); xch_load4x4(xa + ASDR_N, vq[0], vq[1], vq[2], vq[3]);
+        if (sig_pending) { if (lane == 0) __hip_atomic_store(my_prog, sig_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sig_pending = 0u; }   // (vmcnt(0) inside the loads)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float vi[4], vq[4];
-          load4(xa + 32 * m, vi); load4(xa + ASDR_N + 32 * m, vq);
-          store4(L + W0 + kF + 32 * m, vi); store4(L + W1 + kF + 32 * m, vq);
-        }
+        for (int m = 0; m < 4; ++m) { *reinterpret_cast<v4f *>(L + W0 + kF + 32 * m) = vi[m]; *reinterpret_cast<v4f *>(L + W1 + kF + 32 * m) = vq[m]; }
         WAVE_SYNC();
       }
     }
@@ -1053,6 +1102,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
     }
+    if (ROLE == 2) {   // next block's phase = this block's end phase: from the cache entry, or from the channel's lead lane
+      const float endp = __int_as_float(__builtin_amdgcn_ds_bpermute((lane_i & ~7) << 2, __float_as_int(mphase_end)));
+      carry_phase = lo_hit ? lo_end : endp;
+      carry_fsh = fsh_raw;
+    }
     // Wave-uniform mixer: all 8 lanes of a channel hold the channel's carried phase and increment, so the wave can test whether
     // EVERY channel mixes with the same pair -- true for receivers that were configured together, whose phases then stay
     // identical for ever.  Then the 128 sin/cos pairs are evaluated once per wave (2 samples per lane, from channel 0's phase
@@ -1156,9 +1210,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           store4(hq_ring + hs * 128 + 32 * m, qn + 4 * m);   // newest replaces oldest (loaded before the IF pipeline)
         }
         if (lead) S->hil_slot = hs ^ 1u;
+        carry_hs = hs ^ 1u;
       }
       WAVE_SYNC();
       TL(8);
+      constexpr bool IDL_EARLY = (ROLE == 2);   // the pipeline's role 2 has the registers to request the delayed I before the FIR
+      if (IDL_EARLY && is_ssb) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
+      }
       v2f acc2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
@@ -1199,7 +1259,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();   // all history reads done: rows W0/W1 may overwrite the start of the history
       TL(9);
-      if (is_ssb) {   // delayed I = previous block's mixed I (:111); requested here: the FIR has no registers to spare for it
+      if (!IDL_EARLY && is_ssb) {   // delayed I = previous block's mixed I (:111); requested here: the FIR has no registers to spare for it
 #pragma unroll
         for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
       }
@@ -1280,13 +1340,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ROLE == 2 || ROLE == 3) {   // streaming pipeline, boundary B: the demodulated audio row (W0)
       float *xb = a.xch_b + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH)) * ASDR_N + kF;
       if (ROLE == 2) {
+        v4f v[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { float v[4]; load4(L + W0 + kF + 32 * m, v); store4(xb + 32 * m, v); }
-        stream_signal(a.stream_prog + a.stream_waves + wave_g, (uint32_t)blk + 1u, lane);
+        for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const v4f *>(L + W0 + kF + 32 * m);
+        xch_store4x4(xb, v[0], v[1], v[2], v[3]);
+        sig_pending = (uint32_t)blk + 1u;
         continue;
       } else {
+        v4f v[4];
+        xch_load4x4(xb, v[0], v[1], v[2], v[3]);
+        if (sig_pending) { if (lane == 0) __hip_atomic_store(my_prog, sig_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sig_pending = 0u; }   // (vmcnt(0) inside the loads)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { float v[4]; load4(xb + 32 * m, v); store4(L + W0 + kF + 32 * m, v); }
+        for (int m = 0; m < 4; ++m) *reinterpret_cast<v4f *>(L + W0 + kF + 32 * m) = v[m];
         WAVE_SYNC();
       }
     }
@@ -1539,7 +1604,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
     if (ROLE == 0) { if (lead) S->status = status; }
-    else { store_status_bits(ASDR_S_AGC_ACTIVE); stream_signal(a.stream_prog + 2 * a.stream_waves + wave_g, (uint32_t)blk + 1u, lane); }
+    else { store_status_bits(ASDR_S_AGC_ACTIVE); sig_pending = (uint32_t)blk + 1u; }
     WAVE_SYNC();
     // Wave 0 of the designated launch leaves the NEXT block's local-oscillator pairs in the other cache entry (LoEntry).
     if (a.lo_write && wave_g == 0 && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
@@ -1574,6 +1639,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     TL(15);
   }
+  if (ROLE != 0 && sig_pending) stream_signal(my_prog, sig_pending, lane);
 #undef P
 }
 
@@ -1599,18 +1665,81 @@ ASDR_KERNEL(asdr_update_kernel_sam, ASDR_SAM_WAVES * 8 * ASDR_STRIDE + 260, ASDR
 ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true, 1)
 ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
 
-// Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves);
-// all 3W workgroups must be resident together (the host launches it only for small batches).  Uniform-key SSB waves only.
+// Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves),
+// workgroup 3W the oscillator role; all 3W + 1 workgroups must be resident together (the host launches it only for small batches).  Uniform-key SSB waves only.
+// The pipeline's oscillator role (one wave): for every block of the call, the 128 phases that start where the previous block
+// ended -- the recurrence of AudioSDR.h:513-518 from the first channel's carried phase -- and their cos / sin pairs, left in
+// lo_ring[b % ASDR_LO_RING] under the key (start phase, increment).  A role-2 wave whose channels carry exactly that key reads
+// the pairs instead of running the recurrence and the table lookups itself; any other wave computes its own, as ever.
+__device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *lds) {
+  const int lane = threadIdx.x & 63;
+  const ChainConsts K = a.k;
+  const float two_pi = K.two_pi_f;
+  const int ch0 = (a.direct_ch0 >= 0) ? a.direct_ch0 : a.sched[0].ch;
+  float phase = a.small[ch0].phase_ssb;
+  const float inc = (-a.params[ch0].freq_shift) * K.phase_inc_unit;   // as the role-2 waves form it (AudioSDR.h:508-512)
+  uint32_t *const prog = a.stream_prog, *const err = a.stream_prog + 3 * a.stream_waves, *const my = err + 1;
+  const bool up = !(inc < 0.0f);
+  const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
+  const uint32_t flip = up ? 0u : 0x80000000u;
+#pragma unroll 1
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    if (blk >= ASDR_LO_RING) {   // every role-2 wave has left the entry this block overwrites
+      const uint32_t need = (uint32_t)(blk - ASDR_LO_RING + 1);
+      uint32_t spins = 0;
+      while (true) {
+        uint32_t mn = 0xFFFFFFFFu;
+        for (int w = lane; w < a.stream_waves; w += 64) { const uint32_t v = __hip_atomic_load(prog + a.stream_waves + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mn = v < mn ? v : mn; }
+        if (__all(mn >= need)) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > ASDR_STREAM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      asm volatile("" ::: "memory");
+    }
+    LoEntry *e = a.lo_ring + (blk % ASDR_LO_RING);
+    const float start = phase;
+    if (lane == 0) {
+#pragma unroll 1
+      for (int i = 0; i < ASDR_N; i += 8) {
+        float pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          pv[u] = phase;
+          const float t = phase + inc, tw = t + wrapv;
+          phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+        }
+        store8(lds + i, pv);
+      }
+    }
+    phase = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(phase)));   // lane 0's end phase, to all
+    WAVE_SYNC();
+    const float2 p2 = *reinterpret_cast<const float2 *>(lds + 2 * lane);
+    v2f c2, s2;
+    c2[0] = cos_f32(nullptr, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d); s2[0] = sin_f32(nullptr, p2.x, two_pi, K.inv_two_pi_d);
+    c2[1] = cos_f32(nullptr, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d); s2[1] = sin_f32(nullptr, p2.y, two_pi, K.inv_two_pi_d);
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1"
+                 :: "v"(e->c + 2 * lane), "v"(c2), "v"(e->s + 2 * lane), "v"(s2) : "memory");
+    if (lane == 0) {
+      v4f key;
+      key[0] = start; key[1] = inc; key[2] = phase; key[3] = 0.0f;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(e), "v"(key) : "memory");
+    }
+    stream_signal(my, (uint32_t)blk + 1u, lane);
+    WAVE_SYNC();
+  }
+}
+
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_stream_kernel(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   const int role = (int)blockIdx.x / a.stream_waves;   // wave-uniform
-  if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
+  if (role == 3) asdr_stream_lo_role(a, lds);
+  else if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
   else if (role == 1) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 2>(a, lds);
   else asdr_update_body<ASDR_STRIDE, false, false, true, 1, 3>(a, lds);
 }
 extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
   if (a->stream_waves <= 0) return 0;
-  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(64), 0, stream, *a);
+  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves + 1), dim3(64), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
