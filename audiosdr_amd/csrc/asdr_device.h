@@ -146,10 +146,13 @@ typedef struct {
    * (blanker + IF | mixer + Hilbert | audio filter + AGC + output) work on consecutive blocks of one call at the same time */
   float *xch_a;           /* [n_channels][ASDR_STREAM_DEPTH][2][128]: IF output I, Q of the blocks in flight (role 1 -> role 2) */
   float *xch_b;           /* [n_channels][ASDR_STREAM_DEPTH][128]:    demodulated audio (role 2 -> role 3) */
-  uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch; [3 * stream_waves] = error flag, [+1] = oscillator role's progress */
+  uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch (zeroed before it); [3 * stream_waves] =
+                             the oscillator role's progress */
+  uint32_t *stream_err;   /* set to 1 by a wave that gave up waiting (ASDR_STREAM_SPIN_LIMIT); read and cleared by the host at its next
+                             synchronisation point */
   int32_t stream_waves;   /* waves per role = (workgroups - 1) / 3 */
   LoEntry *lo_ring;       /* [ASDR_LO_RING] the streaming pipeline's oscillator role leaves block b's pairs in entry b % ASDR_LO_RING;
-                             its progress counter is stream_prog[3 * stream_waves + 1] */
+                             its progress counter is stream_prog[3 * stream_waves] */
   ChainConsts k;
 } UpdateArgs;
 #define ASDR_STREAM_DEPTH 4

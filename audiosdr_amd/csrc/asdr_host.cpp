@@ -177,7 +177,6 @@ struct asdr_batch {
   LoEntry *d_lo_ring = nullptr;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
-  int stream_flag_index = 0;        // 3 * waves of that launch
   long stat_stream_launches = 0;
   uint32_t lo_parity = 0;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
@@ -478,12 +477,28 @@ void each(asdr_batch *b, int ch, F f) {
 }
 const Chan *get(asdr_batch *b, int ch) { return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr; }
 
+// Error word of the streaming pipeline (a wave gave up waiting for its neighbour role: ASDR_STREAM_SPIN_LIMIT): read, and cleared,
+// at the host's synchronisation points (asdr_synchronize, asdr_update, the status / capture readers).
+int check_stream_error(asdr_batch *b) {
+  if (!b->stream_launched || !b->d_stream_prog) return 0;
+  HIPCHK(hipStreamSynchronize(b->last_stream));
+  uint32_t *word = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1, flag = 0;
+  HIPCHK(hipMemcpy(&flag, word, sizeof flag, hipMemcpyDeviceToHost));
+  b->stream_launched = false;
+  if (flag) {
+    HIPCHK(hipMemset(word, 0, sizeof flag));
+    return fail("streaming pipeline: a wave timed out waiting for its neighbour role (the results of those calls are invalid)");
+  }
+  return 0;
+}
+
 int read_small(asdr_batch *b, int ch, ChanSmall &s) {
   if (!b || ch < 0 || ch >= b->n) return fail("bad channel");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
+  if (check_stream_error(b) != 0) return -1;
   if (apply_resets(b, b->stream) != 0) return -1;
   HIPCHK(hipMemcpy(&s, b->d_small + ch, sizeof s, hipMemcpyDeviceToHost));
   return 0;
@@ -597,19 +612,6 @@ void asdr_destroy(asdr_batch_t *b) {
 
 int asdr_n_channels(const asdr_batch_t *b) { return b ? b->n : 0; }
 
-// Error flag of the last streaming pipeline launch (a wave gave up waiting for its neighbour role: ASDR_STREAM_SPIN_LIMIT).
-static int check_stream_error(asdr_batch *b) {
-  if (!b->stream_launched || !b->d_stream_prog) return 0;
-  HIPCHK(hipStreamSynchronize(b->last_stream));
-  uint32_t flag = 0;
-  const int w_max = (b->n + 7) / 8;
-  (void)w_max;
-  HIPCHK(hipMemcpy(&flag, b->d_stream_prog + b->stream_flag_index, sizeof flag, hipMemcpyDeviceToHost));
-  b->stream_launched = false;
-  if (flag) return fail("streaming pipeline: a wave timed out waiting for its neighbour role (results of that call are invalid)");
-  return 0;
-}
-
 int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
                                long in_stride_blocks, long out_stride_blocks, void *stream_) {
   if (!b) return fail("null batch");
@@ -668,20 +670,21 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (!b->d_xch_a) {
       HIPCHK(hipMalloc(&b->d_xch_a, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * 2 * ASDR_N * sizeof(float)));
       HIPCHK(hipMalloc(&b->d_xch_b, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)));
-      HIPCHK(hipMalloc(&b->d_stream_prog, (size_t)(3 * ((b->n + 7) / 8) + 2) * sizeof(uint32_t)));
+      HIPCHK(hipMalloc(&b->d_stream_prog, (size_t)(3 * ((b->n + 7) / 8) + 2) * sizeof(uint32_t)));   // [+1] = the persistent error word
+      HIPCHK(hipMemsetAsync(b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1, 0, sizeof(uint32_t), stream));
       HIPCHK(hipMalloc(&b->d_lo_ring, ASDR_LO_RING * sizeof(LoEntry)));
     }
-    if (b->stream_launched && check_stream_error(b) != 0) return -1;   // (synchronises) the previous pipeline's flag, before it is cleared
-    HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 2) * sizeof(uint32_t), stream));
+    HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));   // stream-ordered behind the previous launch
     a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
     a.direct_ch0 = -1;
     if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; }
     a.lo_write = 0u;
-    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_waves = w; a.lo_ring = b->d_lo_ring;
+    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_err = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1;
+    a.stream_waves = w; a.lo_ring = b->d_lo_ring;
     if (e0) HIPCHK(hipEventRecord(e0, stream));
     if (asdr_launch_stream(&a, stream) != 0) return fail("stream kernel launch failed");
     if (e1) HIPCHK(hipEventRecord(e1, stream));
-    b->stream_launched = true; b->stream_flag_index = 3 * w; b->stat_stream_launches++;
+    b->stream_launched = true; b->stat_stream_launches++;
     b->ev_last_valid = true;
     b->ev_valid = (e0 != nullptr && e0 == b->ev0);
     if (b->region_calls >= 0) b->region_calls++;

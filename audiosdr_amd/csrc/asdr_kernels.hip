@@ -490,7 +490,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int ch = ch_; asm volatile("" : "+v"(ch));
     int lane_i = lane; asm volatile("" : "+v"(lane_i));   // for the rarely taken paths: their addresses must not be hoisted (and spilled)
     if (ROLE != 0) {   // streaming pipeline: wait for this block's input rows and for a free slot in the ring this role writes
-      uint32_t *prog = a.stream_prog, *err = a.stream_prog + 3 * a.stream_waves;
+      uint32_t *prog = a.stream_prog, *err = a.stream_err;
       const uint32_t b1 = (uint32_t)blk + 1u, freed = (blk >= ASDR_STREAM_DEPTH) ? (uint32_t)(blk - ASDR_STREAM_DEPTH + 1) : 0u;
       const bool need_in = (ROLE != 1) && seen_in < b1, need_free = (ROLE != 3) && seen_free < freed;
       if ((need_in || need_free) && sig_pending) { stream_signal(my_prog, sig_pending, lane); sig_pending = 0u; }   // publish before blocking
@@ -544,7 +544,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     uint32_t lo_kp, lo_ki;
     float lo_end;
     if (ROLE == 2) {
-      if (seen_lo < (uint32_t)blk + 1u) seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves + 1, (uint32_t)blk + 1u, a.stream_prog + 3 * a.stream_waves);
+      if (seen_lo < (uint32_t)blk + 1u) seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves, (uint32_t)blk + 1u, a.stream_err);
       v4f key;
       asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(key) : "v"(lo_rd) : "memory");
       lo_kp = __float_as_uint(key[0]); lo_ki = __float_as_uint(key[1]); lo_end = key[2];
@@ -1678,7 +1678,7 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
   const int ch0 = (a.direct_ch0 >= 0) ? a.direct_ch0 : a.sched[0].ch;
   float phase = a.small[ch0].phase_ssb;
   const float inc = (-a.params[ch0].freq_shift) * K.phase_inc_unit;   // as the role-2 waves form it (AudioSDR.h:508-512)
-  uint32_t *const prog = a.stream_prog, *const err = a.stream_prog + 3 * a.stream_waves, *const my = err + 1;
+  uint32_t *const prog = a.stream_prog, *const err = a.stream_err, *const my = a.stream_prog + 3 * a.stream_waves;
   const bool up = !(inc < 0.0f);
   const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
   const uint32_t flip = up ? 0u : 0x80000000u;
