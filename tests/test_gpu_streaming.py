@@ -180,3 +180,28 @@ def test_block_pipeline_is_not_used_where_it_does_not_apply(gpu, ao):
         batch.synchronize()
         assert batch.stream_pipeline_launches() == 0
         hip.free_all(); batch.close()
+
+
+@pytest.mark.parametrize("n_ch,T,pipelined", [(8, 9, True), (672, 11, True), (680, 9, False)])
+def test_block_pipeline_sizes(gpu, ao, n_ch, T, pipelined):
+    """One channel group (a single wave per role), the largest batch the pipeline takes (84 groups: 3 x 84 + 1 workgroups), and
+    one group more (block-by-block path).  A mode change between two calls resets filter state through the usual path."""
+    from audiosdr_amd.synth import make_iq
+    I, Q = make_iq(n_ch, 2 * T, fc=6290.0, A=0.25, noise=0.02)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")])
+    hip = Hip()
+    sample = sorted(set([0, 1, 7, n_ch // 2, n_ch - 1]))
+    for call in range(2):
+        if call == 1:
+            apply_setters(batch, orcs, [S("setDemodMode", 0)])        # USB -> LSB... (0 = USB): zeroes the IF state (.cpp:191-218)
+        sl = slice(call * T, (call + 1) * T)
+        dI, dQ = hip.upload(I[:, sl]), hip.upload(Q[:, sl])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in sample:
+            want = orcs[c].update(I[c, sl], Q[c, sl]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call %d ch %d" % (call, c)
+    assert batch.stream_pipeline_launches() == (2 if pipelined else 0)
+    hip.free_all(); batch.close()
