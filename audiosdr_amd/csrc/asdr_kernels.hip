@@ -1010,7 +1010,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           d1 = d0;
           d0 = err - K.pll_a1 * d1;
           const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
-          phase_est = (float)((double)phase_est + (double)(filt + prev_filt) / 2.0);
+          // (float)((double)phase_est + (double)(filt + prev_filt) / 2.0) (:732) as ONE binary32 fma: the halving is exact in
+          // binary64 and rounding the binary64 sum of two binary32-precision values to binary32 is innocuous double rounding
+          // (53 >= 2 * 24 + 2), so the single rounding of the exact value agrees for every operand pair (oracle
+          // ao_check_pll_phase_update).  Four binary64-rate operations less on the loop's dependent chain.
+          phase_est = __builtin_fmaf(filt + prev_filt, 0.5f, phase_est);
           prev_filt = filt;
           // The reference's two unbounded wrap loops (:735-736) never end once |phase_est| is so large that
           // phase_est -+ twoPI == phase_est (infinity; or a huge step): there they stall one Teensy instance, here they would

@@ -712,6 +712,27 @@ int ao_check_scale_division(void) {
   return bad;
 }
 
+/* The kernels' PLL phase update fmaf(filt + prev, 0.5f, phase) against the reference's (float)((double)phase + (double)(filt +
+ * prev) / 2.0) (AudioSDR.cpp:732): halving is exact in binary64, and rounding the binary64 sum of two binary32-precision values
+ * to binary32 is innocuous double rounding (53 >= 2*24 + 2), so the single-rounding fma must agree for EVERY pair.  Checked on n
+ * pseudo-random pairs of float bit patterns (all exponents, denormals and zeros included; NaN / inf skipped) plus near-tie pairs. */
+uint64_t ao_check_pll_phase_update(uint32_t seed, uint64_t n) {
+  uint64_t bad = 0, s = seed * 2654435761u + 12345u;
+  for (uint64_t i = 0; i < n; i++) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    union { uint32_t u; float f; } a, b;
+    a.u = (uint32_t)(s >> 32); b.u = (uint32_t)s;
+    if ((i & 3) == 1) b.u = (a.u & 0x7F800000u) - ((uint32_t)(s >> 7) % 40u << 23) + (b.u & 0x807FFFFFu);   /* exponents 0..39 apart */
+    if ((i & 3) == 2) { b.u = (b.u & 0x80000000u) | ((a.u & 0x7F800000u) - (24u << 23)) | ((i & 4) ? 0u : 1u); }   /* half-ulp ties */
+    if (a.f != a.f || b.f != b.f || a.f - a.f != 0.0f || b.f - b.f != 0.0f) continue;
+    const float t = b.f;                                   /* filt + prev_filt as the reference forms it (float) */
+    const float want = (float)((double)a.f + (double)t / 2.0);
+    const float got = fmaf(t, 0.5f, a.f);
+    if (memcmp(&want, &got, 4) != 0) bad++;
+  }
+  return bad;
+}
+
 /* all 65,536 table phases: float32 interpolation == the reference's mixed float/double form (AudioSDR.h:369) */
 int ao_check_sin_interp_f32(void) {
   int bad = 0;

@@ -340,6 +340,18 @@ def test_reciprocal_division_is_exact_for_every_phase(ao):
     assert bad == 0
 
 
+def test_pll_phase_update_as_one_fma(ao):
+    """asdr_kernels.hip: phase_est = fmaf(filt + prev_filt, 0.5f, phase_est) == the reference's binary64 form (.cpp:732) for 6e7
+    random / near-tie operand pairs over all exponents (denormals included)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    L = ao.lib()
+    L.ao_check_pll_phase_update.argtypes = [C.c_uint32, C.c_uint64]; L.ao_check_pll_phase_update.restype = C.c_uint64
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        bad = sum(ex.map(lambda k: L.ao_check_pll_phase_update(1000 + k, 10_000_000), range(6)))
+    assert bad == 0
+
+
 def test_scale_division_and_f32_interpolation_are_exact(ao):
     L = ao.lib()
     assert L.ao_check_scale_division() == 0        # s/32767.0 for all int16
