@@ -571,21 +571,24 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
     roi[0].v = roi[1].v = roq[0].v = roq[1].v = rmi[0].v = rmi[1].v = rmq[0].v = rmq[1].v = make_int4(0, 0, 0, 0);
     uint32_t mkc[5] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};   // defined on every path
+    const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
+    float g_oi = gain_i, g_oq = gain_q, g_mi = 0.0f, g_mq = 0.0f, nb_avg0 = 0.0f;
+    if (nb_wave && nb_en) {
+      // the gains first: they are converted right away, and a wait for the oldest loads leaves all the others in flight
+      g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
+      nb_avg0 = S->nb_avg;
+      const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + kA), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + kA);
+      rmi[0].v = mid4[0]; rmi[1].v = mid4[8]; rmq[0].v = mid4[16]; rmq[1].v = mid4[24];   // Q row starts 128 samples = 16 int4 later
+      roi[0].v = old4[0]; roi[1].v = old4[8]; roq[0].v = old4[16]; roq[1].v = old4[24];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) mkc[r] = mrow[8 * r];   // codes of the carried mask[128..265]
+    }
+    // The input rows come LAST: with the blanker on, this block's samples only go into the ring (the chain works on the block that
+    // arrived two calls ago), so nothing below waits for them until that store -- and memory waits count loads in order.
     if (DO1 && valid) {
       const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
       const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
       ri[0].v = pi[0]; ri[1].v = pi[8]; rq[0].v = pq[0]; rq[1].v = pq[8];   // int4 #8 = 64 samples on
-    }
-    const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
-    float g_oi = gain_i, g_oq = gain_q, g_mi = 0.0f, g_mq = 0.0f, nb_avg0 = 0.0f;
-    if (nb_wave && nb_en) {
-      const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + kA), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + kA);
-      roi[0].v = old4[0]; roi[1].v = old4[8]; roq[0].v = old4[16]; roq[1].v = old4[24];   // Q row starts 128 samples = 16 int4 later
-      rmi[0].v = mid4[0]; rmi[1].v = mid4[8]; rmq[0].v = mid4[16]; rmq[1].v = mid4[24];
-#pragma unroll
-      for (int r = 0; r < 5; ++r) mkc[r] = mrow[8 * r];   // codes of the carried mask[128..265]
-      g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
-      nb_avg0 = S->nb_avg;
     }
     // mixer increment (AudioSDR.h:508-512) and the local-oscillator cache test (asdr_device.h LoEntry): hit = every channel of the
     // wave starts this block with exactly the cached phase and increment -> no recurrence, no table lookups, the pairs are read
@@ -601,16 +604,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // force when each block arrived: the scaled float is an exact function of (sample, gain), so re-scaling on
     // read reproduces the reference's stored floats bit for bit at a quarter of the HBM traffic.
     if (nb_wave) {
-      if (nb_en) {   // newest block -> third ring slot, with its gains
-        int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + kA);
-        ni[0] = ri[0].v; ni[8] = ri[1].v; ni[16] = rq[0].v; ni[24] = rq[1].v;
-        if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
-      }
-      if (tap_on) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { float xi[8], xq[8]; scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
-                                      TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq); }
-      }
+      // (the newest block goes to its ring slot after the envelopes, below)
     } else if (DO1) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -666,6 +660,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) mgt[j] = 0.0f;
+      }
+      if (nb_en) {   // newest block -> third ring slot, with its gains (blanker-off channels pass their own input: see above)
+        int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + kA);
+        ni[0] = ri[0].v; ni[8] = ri[1].v; ni[16] = rq[0].v; ni[24] = rq[1].v;
+        if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
+      }
+      if (tap_on) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { float xi[8], xq[8]; scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
+                                      TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq); }
       }
       WAVE_SYNC();
       TL(2);
