@@ -402,6 +402,62 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // WAVES: waves per workgroup.  1 everywhere except the SAM instantiation (4): there the per-sample PLL recurrence -- by far the
 // longest dependent chain of the whole path, one lane per channel -- is run for all 32 channels of the workgroup by ONE wave
 // (32 lanes busy instead of 8 in each of 4 waves) while the sibling waves wait at a workgroup barrier.
+// Folded Hilbert FIR, AudioSDR.cpp:99-110, output pairs E0 .. E0 + NE - 1 of this lane's eight (outputs i = 16 s8 + 2e, + 1):
+//   Q[i] = sum_k h[k] * (x[255 + i - 2k] - x[i + 2k + 1]),  k ascending, accumulate from 0.0
+// With PX[p] = (x[2p+1], x[2p+2]) the operands of the output pair e are PX[127 + p0 + e - k] and PX[p0 + e + k] (p0 = 8 s8): per
+// chunk of 8 taps two contiguous (NE + 7)-pair register windows (ds_read_b128).  v_pk_mul_f32 / v_pk_add_f32 round each half
+// exactly like the scalar ops, so the result is bit-identical to the scalar loop.  Lrow = the channel's LDS row (history at XP).
+template <int E0, int NE>
+__device__ __forceinline__ void hilbert_fir(const float *Lrow, int p0, v2f *acc2) {
+  constexpr int NW = NE + 7;
+  const v2f *PX = reinterpret_cast<const v2f *>(Lrow + XP) + E0;
+#pragma unroll 1
+  for (int kc = 0; kc < 8; ++kc) {
+    v2f dw[NW], uw[NW];   // dw[t] = PX[120 + p0 - 8kc + t], uw[t] = PX[p0 + 8kc + t]  (t = 0..NW-1, pairs counted from E0)
+    const float4 *dp = reinterpret_cast<const float4 *>(PX + 120 + p0 - 8 * kc);
+    const float4 *up = reinterpret_cast<const float4 *>(PX + p0 + 8 * kc);
+#pragma unroll
+    for (int q = 0; q < NW / 2; ++q) {
+      const float4 d4 = dp[q], u4 = up[q];
+      dw[2 * q] = (v2f){d4.x, d4.y}; dw[2 * q + 1] = (v2f){d4.z, d4.w};
+      uw[2 * q] = (v2f){u4.x, u4.y}; uw[2 * q + 1] = (v2f){u4.z, u4.w};
+    }
+    if (NW & 1) { dw[NW - 1] = PX[120 + p0 - 8 * kc + NW - 1]; uw[NW - 1] = PX[p0 + 8 * kc + NW - 1]; }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float hk = c_hilbert[8 * kc + kk];
+      const v2f hk2 = (v2f){hk, hk};
+      v2f d[NE];   // the pair-chains of a tap are independent: issue them interleaved (no dependent back-to-back pk ops)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) d[e] = dw[7 + e - kk] - uw[e + kk];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) d[e] = hk2 * d[e];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc2[e] += d[e];
+      SCHED_FENCE();
+    }
+  }
+}
+// Second wave of a role-2 workgroup of the streaming pipeline: nothing but the other half of the FIR, in step with the first
+// wave's three barriers per block (history staged | all reads done | both halves in W1).
+template <int STRIDE>
+__device__ __forceinline__ void asdr_stream_fir_helper(const UpdateArgs &a, float *lds) {
+  const int lane = threadIdx.x & 63, c8 = lane >> 3, s8 = lane & 7, k0 = 16 * s8;
+  float *L = lds + c8 * STRIDE;
+#pragma unroll 1
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    v2f acc2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc2[e] = (v2f){0.0f, 0.0f};
+    __syncthreads();
+    if (ABL_ON(ABL_HIL)) hilbert_fir<4, 4>(L, k0 >> 1, acc2);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 8 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
+    __syncthreads();
+  }
+}
+
 // ROLE: 0 = the whole chain (every launch but the streaming pipeline's).  1 / 2 / 3 = one third of it, for asdr_stream_kernel:
 // 1 = input scale + blanker + IF filter, 2 = mixer + Hilbert + sideband, 3 = audio filter + AGC + output (SSB-class modes,
 // no ALS).  A role skips the other thirds by seeing their enables as off; the rows that cross a boundary (IF output I/Q; the
@@ -1227,45 +1283,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
         for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
       }
-      v2f acc2[8];
+      // In the pipeline's role 2 the FIR is shared with the workgroup's second wave (asdr_stream_fir_helper): this wave computes the
+      // output pairs 0..3 of every lane, the helper 4..7, between two workgroup barriers.
+      constexpr int FIR_NE = (ROLE == 2) ? 4 : 8;
+      v2f acc2[FIR_NE];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
-      if (ABL_ON(ABL_HIL) && is_ssb) {
-        // This lane's 16 outputs i = k0 + 2e, k0 + 2e + 1 (e = 0..7), two per packed FP32 instruction:
-        //   Q[i] = sum_k h[k] * (x[255 + i - 2k] - x[i + 2k + 1]),  k ascending, accumulate from 0.0   (:99-110)
-        // With PX[p] = (x[2p+1], x[2p+2]) the operands of the output pair e are PX[127 + k0/2 + e - k] and
-        // PX[k0/2 + e + k]: per chunk of 8 taps two contiguous 15-pair register windows (ds_read_b128).  v_pk_mul_f32 /
-        // v_pk_add_f32 round each half exactly like the scalar ops, so the result is bit-identical to the scalar loop.
-        const v2f *PX = reinterpret_cast<const v2f *>(L + XP);
-        const int p0 = k0 >> 1;
-#pragma unroll 1
-        for (int kc = 0; kc < 8; ++kc) {
-          v2f dw[15], uw[15];   // dw[t] = PX[120 + p0 - 8kc + t], uw[t] = PX[p0 + 8kc + t]  (t = 0..14)
-          const float4 *dp = reinterpret_cast<const float4 *>(PX + 120 + p0 - 8 * kc);
-          const float4 *up = reinterpret_cast<const float4 *>(PX + p0 + 8 * kc);
-#pragma unroll
-          for (int q = 0; q < 7; ++q) {
-            const float4 d4 = dp[q], u4 = up[q];
-            dw[2 * q] = (v2f){d4.x, d4.y}; dw[2 * q + 1] = (v2f){d4.z, d4.w};
-            uw[2 * q] = (v2f){u4.x, u4.y}; uw[2 * q + 1] = (v2f){u4.z, u4.w};
-          }
-          dw[14] = PX[120 + p0 - 8 * kc + 14]; uw[14] = PX[p0 + 8 * kc + 14];
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const float hk = c_hilbert[8 * kc + kk];
-            const v2f hk2 = (v2f){hk, hk};
-            v2f d[8];   // the 8 pair-chains of a tap are independent: issue them interleaved (no dependent back-to-back pk ops)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d[e] = dw[7 + e - kk] - uw[e + kk];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d[e] = hk2 * d[e];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc2[e] += d[e];
-            SCHED_FENCE();
-          }
-        }
-      }
-      WAVE_SYNC();   // all history reads done: rows W0/W1 may overwrite the start of the history
+      for (int e = 0; e < FIR_NE; ++e) acc2[e] = (v2f){0.0f, 0.0f};
+      if (ROLE == 2) __syncthreads();   // the history is staged: the helper may read it
+      if (ABL_ON(ABL_HIL) && is_ssb) hilbert_fir<0, FIR_NE>(L, k0 >> 1, acc2);
+      if (ROLE == 2) __syncthreads(); else WAVE_SYNC();   // all history reads done: rows W0/W1 may overwrite the start of the history
       TL(9);
       if (!IDL_EARLY && is_ssb) {   // delayed I = previous block's mixed I (:111); requested here: the FIR has no registers to spare for it
 #pragma unroll
@@ -1273,9 +1299,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       if (is_ssb) {   // the FIR owns 16 contiguous outputs per lane; the combine works on the float-row pieces: hand over through W1
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
+        for (int e = 0; e < FIR_NE; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
       }
-      WAVE_SYNC();
+      if (ROLE == 2) __syncthreads(); else WAVE_SYNC();   // (the helper's half is in W1 as well)
       if (is_ssb) {   // sideband combine (:115-118) with the delayed I
         // x - y == x + (-y) exactly: the sideband is a sign bit, not a select between two forms (a wave-uniform
         // `sub_q ? a - b : a + b` per sample compiles to a scalar branch cascade per sample in the uniform-key instantiations)
@@ -1737,9 +1763,11 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
   }
 }
 
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_stream_kernel(UpdateArgs a) {
+extern "C" __global__ __launch_bounds__(128, ASDR_WAVES_PER_EU) void asdr_stream_kernel(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
-  const int role = (int)blockIdx.x / a.stream_waves;   // wave-uniform
+  const int role = (int)blockIdx.x / a.stream_waves;   // workgroup-uniform
+  // two waves per workgroup: the second one only exists for role 2, whose Hilbert FIR it shares (every other role: gone at once)
+  if (threadIdx.x >= 64) { if (role == 1) asdr_stream_fir_helper<ASDR_STRIDE>(a, lds); return; }
   if (role == 3) asdr_stream_lo_role(a, lds);
   else if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
   else if (role == 1) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 2>(a, lds);
@@ -1747,7 +1775,7 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_stream_
 }
 extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
   if (a->stream_waves <= 0) return 0;
-  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves + 1), dim3(64), 0, stream, *a);
+  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves + 1), dim3(128), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
