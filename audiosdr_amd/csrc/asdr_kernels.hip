@@ -485,7 +485,8 @@ __device__ __forceinline__ void stream_signal(uint32_t *p, uint32_t value, int l
 // four 16-byte pieces (p + 32 m floats, m = 0..3) of an exchange row, `sc1`; the loads are waited for inside
 __device__ __forceinline__ void xch_store4x4(float *p, v4f v0, v4f v1, v4f v2, v4f v3) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:128 sc1\n\t"
-               "global_store_dwordx4 %0, %3, off offset:256 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:384 sc1"
+               "global_store_dwordx4 %0, %3, off offset:256 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:384 sc1\n\t"
+               "s_nop 1"   // (a store wider than 8 bytes reads its data a wait state late: nothing may overwrite v3 right behind it)
                :: "v"(p), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
 }
 __device__ __forceinline__ void xch_load4x4(const float *p, v4f &v0, v4f &v1, v4f &v2, v4f &v3) {
@@ -1751,12 +1752,12 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
     v2f c2, s2;
     c2[0] = cos_f32(nullptr, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d); s2[0] = sin_f32(nullptr, p2.x, two_pi, K.inv_two_pi_d);
     c2[1] = cos_f32(nullptr, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d); s2[1] = sin_f32(nullptr, p2.y, two_pi, K.inv_two_pi_d);
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1"
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_nop 1"
                  :: "v"(e->c + 2 * lane), "v"(c2), "v"(e->s + 2 * lane), "v"(s2) : "memory");
     if (lane == 0) {
       v4f key;
       key[0] = start; key[1] = inc; key[2] = phase; key[3] = 0.0f;
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(e), "v"(key) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(e), "v"(key) : "memory");
     }
     stream_signal(my, (uint32_t)blk + 1u, lane);
     WAVE_SYNC();
