@@ -47,6 +47,9 @@ def configure_c2(sdr):
     sdr.enableAudioFilter()    # bw2700 from init(); NB + AGC are on by default
 
 
+SETTLE_LAUNCHES = 1500    # untimed launches in front of the timed region (>= --warmup): clocks settled, see main()
+
+
 def cpu_info():
     """CPU model and physical core count of this host (SURVEY.md 8d asks for both next to the baseline)."""
     model, phys = None, set()
@@ -198,6 +201,12 @@ def main():
         if not args.dry_run:
             torch.cuda.synchronize()
 
+    # The GPU's clocks need ~0.2 s of work to settle after idle (the first ~500 launches run ~3 % slower, a 20-step run right
+    # after start-up ~10 %): whatever --warmup says, at least SETTLE_LAUNCHES untimed launches precede the timed region.  The
+    # timed region is exactly --steps launches.
+    settle = max(0, SETTLE_LAUNCHES - args.warmup) if batch is not None else 0
+    for i in range(settle):
+        step(i)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -254,6 +263,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
+                       "untimed_launches_before_the_timed_region": settle + args.warmup,
                        "channels_per_gpu": n_ch, "block": BLOCK, "sharding": "channels, no collective",
                        "input": "tone + LCG noise per channel, no impulses: the blanker runs (envelope, average, threshold) but detects "
                                 "nothing, so its mask stays all ones; with an impulse in every block of every channel the same chain "
