@@ -151,6 +151,10 @@ typedef struct {
   uint32_t *stream_err;   /* set to 1 by a wave that gave up waiting (ASDR_STREAM_SPIN_LIMIT); read and cleared by the host at its next
                              synchronisation point */
   int32_t stream_waves;   /* waves per role = (workgroups - 1) / 3 */
+  float *xch_sam;         /* SAM sub-range as three launches (pre | PLL | post, asdr_launch_update): the IF output I, Q of the current block,
+                             one 8 KB tile per group of 8 schedule slots, [tile][sample][I, Q][slot in tile] -- the pre kernel's wave
+                             writes its tile whole, the PLL kernel's lanes (one channel each) read 32-byte segments of 8 tiles;
+                             NULL = the fused SAM kernel */
   LoEntry *lo_ring;       /* [ASDR_LO_RING] the streaming pipeline's oscillator role leaves block b's pairs in entry b % ASDR_LO_RING;
                              its progress counter is stream_prog[3 * stream_waves] */
   ChainConsts k;

@@ -175,6 +175,8 @@ struct asdr_batch {
   float *d_xch_a = nullptr, *d_xch_b = nullptr;
   uint32_t *d_stream_prog = nullptr;
   LoEntry *d_lo_ring = nullptr;
+  float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
+  size_t xch_sam_slots = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   long stat_stream_launches = 0;
@@ -596,7 +598,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
-                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring};
+                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam};
   for (void *p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -661,7 +663,19 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // batches (C5: 64 waves, 646 blocks) keep the in-kernel block loop: there a launch per 19-us block would be all overhead.
   int total_slots = 0;
   for (int i = 0; i < n_sub; i++) total_slots += subs[i].slots;
-  const bool per_block = n_blocks > 1 && total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES;
+  // SAM channels (no ALS) run as three launches per block -- everything in front of the PLL | the PLL with one LANE per channel |
+  // everything behind it -- through a 1 KB-per-slot exchange buffer: as a phase of one fused kernel the PLL's 128-step dependent
+  // chain kept a workgroup's other waves waiting (ASDR_SAM_FUSED=1 selects that kernel, for comparison).
+  static const bool sam_fused = getenv("ASDR_SAM_FUSED") != nullptr;
+  const bool sam_split = !sam_fused && b->kind_slots[ASDR_KERNEL_SAM] > 0;
+  if (sam_split && (size_t)b->kind_slots[ASDR_KERNEL_SAM] > b->xch_sam_slots) {
+    HIPCHK(hipStreamSynchronize(stream));
+    if (b->d_xch_sam) HIPCHK(hipFree(b->d_xch_sam));
+    b->xch_sam_slots = (size_t)b->kind_slots[ASDR_KERNEL_SAM];
+    HIPCHK(hipMalloc(&b->d_xch_sam, b->xch_sam_slots * 2 * ASDR_N * sizeof(float)));
+  }
+  a.xch_sam = sam_split ? b->d_xch_sam : nullptr;
+  const bool per_block = n_blocks > 1 && (sam_split || total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES);
   // Small batch, many blocks, one sub-range of uniform SSB-class waves, no taps: the block pipeline.
   static const bool no_stream = getenv("ASDR_NO_STREAM_PIPELINE") != nullptr;   // measurement switch (tools/bench_configs.py)
   if (!no_stream && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN && subs[0].uniform &&

@@ -402,6 +402,64 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // WAVES: waves per workgroup.  1 everywhere except the SAM instantiation (4): there the per-sample PLL recurrence -- by far the
 // longest dependent chain of the whole path, one lane per channel -- is run for all 32 channels of the workgroup by ONE wave
 // (32 lanes busy instead of 8 in each of 4 waves) while the sibling waves wait at a workgroup barrier.
+// SAM quadrature PLL, AudioSDR.cpp:688-749: one channel's 128 steps on ONE lane (strictly sequential).  ld(i, xr, xi) / st(i, xr, xi)
+// read / write the four IF samples i .. i + 3 of the channel (its LDS rows in the fused kernels, its exchange tile in the
+// stand-alone PLL kernel); Sc = the channel's state row.  Returns the lock flag after the block.
+template <bool TWO_SUMS, typename LD, typename ST>
+__device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, const float *sine, float two_pi, LD ld, ST st) {
+    float y_re = Sc->pll_y_re, y_im = Sc->pll_y_im, prev_filt = Sc->pll_prev_filt;
+    float d0 = Sc->pll_d0, d1 = Sc->pll_d1, phase_est = Sc->pll_phase_est, pfreq = Sc->pll_freq;
+    bool locked = false;
+#pragma unroll 1
+    for (int i = 0; i < ASDR_N; i += 4) {
+      float xr[4], xi[4];
+      ld(i, xr, xi);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float x_re = xr[u], x_im = xi[u];
+        const float d_re = x_re * y_re + x_im * y_im;
+        const float d_im = x_im * y_re - x_re * y_im;
+        const float err = approx_atan2<TWO_SUMS>(d_im, d_re, K.half_pi_f);
+        d1 = d0;
+        d0 = err - K.pll_a1 * d1;
+        const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
+        // (float)((double)phase_est + (double)(filt + prev_filt) / 2.0) (:732) as ONE binary32 fma: the halving is exact in
+        // binary64 and rounding the binary64 sum of two binary32-precision values to binary32 is innocuous double rounding
+        // (53 >= 2 * 24 + 2), so the single rounding of the exact value agrees for every operand pair (oracle
+        // ao_check_pll_phase_update).  Four binary64-rate operations less on the loop's dependent chain.
+        phase_est = __builtin_fmaf(filt + prev_filt, 0.5f, phase_est);
+        prev_filt = filt;
+        // The reference's two unbounded wrap loops (:735-736) never end once |phase_est| is so large that
+        // phase_est -+ twoPI == phase_est (infinity; or a huge step): there they stall one Teensy instance, here they would
+        // hang the wave and with it the batch.  Defined difference: at most ASDR_PLL_WRAP_MAX turns per sample, then the
+        // estimate restarts at 0.  A physical loop-filter step is below pi, i.e. one turn; the oracle mirrors the bound.
+        // Comparisons against the double PI are comparisons against the float just above it: no float lies between them
+        // (pe >= PI_D <=> pe >= pi_up; pe < -PI_D <=> pe <= -pi_up).  The first turn is a select; further turns (never for a
+        // finite loop-filter step) run in a loop that a wave enters only if one of its lanes still needs it.
+        { const float pi_up = 3.14159274101257324f;   // RN_float(PI) > PI_D
+          const float dn = phase_est - two_pi, up = phase_est + two_pi;
+          phase_est = (phase_est >= pi_up) ? dn : ((phase_est <= -pi_up) ? up : phase_est);
+          if (__any(phase_est >= pi_up || phase_est <= -pi_up)) {
+            int turns = 1;
+            while (phase_est >= pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est -= two_pi; ++turns; }
+            while (phase_est <= -pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
+            if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f;
+          } }
+        y_re = cos_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
+        y_im = sin_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d);
+        pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
+        locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
+        const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
+        xr[u] = locked ? o_re : x_re;      // rotated sample while locked (:720-723), else the sample stays
+        xi[u] = locked ? o_im : x_im;
+      }
+      st(i, xr, xi);
+    }
+    Sc->pll_y_re = y_re; Sc->pll_y_im = y_im; Sc->pll_prev_filt = prev_filt;
+    Sc->pll_d0 = d0; Sc->pll_d1 = d1; Sc->pll_phase_est = phase_est; Sc->pll_freq = pfreq;
+    return locked;
+}
+
 // Folded Hilbert FIR, AudioSDR.cpp:99-110, output pairs E0 .. E0 + NE - 1 of this lane's eight (outputs i = 16 s8 + 2e, + 1):
 //   Q[i] = sum_k h[k] * (x[255 + i - 2k] - x[i + 2k + 1]),  k ascending, accumulate from 0.0
 // With PX[p] = (x[2p+1], x[2p+2]) the operands of the output pair e are PX[127 + p0 + e - k] and PX[p0 + e + k] (p0 = 8 s8): per
@@ -498,10 +556,15 @@ __device__ __forceinline__ void xch_load4x4(const float *p, v4f &v0, v4f &v1, v4
 
 template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds_wg) {
-  constexpr bool DO1 = (ROLE == 0 || ROLE == 1), DO2 = (ROLE == 0 || ROLE == 2), DO3 = (ROLE == 0 || ROLE == 3);
+  // ROLE 4 / 5: the SAM sub-range as three launches -- 4 = everything in front of the PLL (scale, blanker, IF filter), then the
+  // stand-alone PLL kernel (asdr_sam_pll_kernel: one LANE per channel, 64 channels per wave -- the PLL is a 128-step dependent chain
+  // per channel, and as one phase of a fused kernel it kept a whole workgroup waiting for ~58 k cycles per block), 5 = everything
+  // behind it.  The IF rows cross in xch_sam; the lock flag in the status word.
+  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5), DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5);
+  constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
   // this wave's index in the launched schedule sub-range (the streaming pipeline launches its three roles one after the other)
-  const int wave_g = (ROLE == 0) ? (int)blockIdx.x * WAVES + wave : (int)blockIdx.x % a.stream_waves;
+  const int wave_g = STREAM ? (int)blockIdx.x % a.stream_waves : (int)blockIdx.x * WAVES + wave;
   float *const lds = lds_wg + wave * 8 * STRIDE;            // this wave's 8 channel rows
   const int lane = threadIdx.x & 63, c8 = lane >> 3, s8_ = lane & 7;
   float *const sine = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : nullptr;
@@ -522,7 +585,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const bool is_ssb = DO2 && ((mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                               (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode));
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
-  const bool is_am = (mode == ASDR_AMmode), is_sam = HAS_SAM && (mode == ASDR_SAMmode);
+  const bool is_am = (mode == ASDR_AMmode), is_sam = (HAS_SAM || ROLE >= 4) && (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
   const bool nb_en = DO1 && (pflags & ASDR_F_NB_EN), af_en = DO3 && (pflags & ASDR_F_AF_EN), agc_en = DO3 && (pflags & ASDR_F_AGC_EN);
   const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
@@ -536,7 +599,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // stores still happen: HBM holds the state after the call): mixer phase, frequency shift, Hilbert ring parity
   float carry_phase = 0.0f, carry_fsh = 0.0f;
   uint32_t carry_hs = 0u;
-  uint32_t *const my_prog = (ROLE == 0) ? nullptr : a.stream_prog + (ROLE - 1) * a.stream_waves + wave_g;
+  uint32_t *const my_prog = STREAM ? a.stream_prog + (ROLE - 1) * a.stream_waves + wave_g : nullptr;
 
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
@@ -546,7 +609,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int loff = loff_; asm volatile("" : "+v"(loff));
     int ch = ch_; asm volatile("" : "+v"(ch));
     int lane_i = lane; asm volatile("" : "+v"(lane_i));   // for the rarely taken paths: their addresses must not be hoisted (and spilled)
-    if (ROLE != 0) {   // streaming pipeline: wait for this block's input rows and for a free slot in the ring this role writes
+    if (STREAM) {   // streaming pipeline: wait for this block's input rows and for a free slot in the ring this role writes
       uint32_t *prog = a.stream_prog, *err = a.stream_err;
       const uint32_t b1 = (uint32_t)blk + 1u, freed = (blk >= ASDR_STREAM_DEPTH) ? (uint32_t)(blk - ASDR_STREAM_DEPTH + 1) : 0u;
       const bool need_in = (ROLE != 1) && seen_in < b1, need_free = (ROLE != 3) && seen_free < freed;
@@ -967,7 +1030,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     WAVE_SYNC();
     TL(4);
-    TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1);
+    if (DO1) { TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1); }
 
     // The IF pipeline's state and coefficients must be IN registers before the ring prefetches below are issued: memory waits
     // count loads in order, and a wait for these values placed after the (conditional) prefetches would be a wait for everything
@@ -1025,7 +1088,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     WAVE_SYNC();
     TL(5);
-    TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1);
+    if (DO1) { TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1); }
     // A role's own status bits go back with atomics: the three roles of a channel group update one word
     auto store_status_bits = [&](uint32_t mask) {
       if (lead) { atomicAnd(&S->status, ~mask); atomicOr(&S->status, status & mask); }
@@ -1050,63 +1113,30 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
 
+    // SAM as three launches: this wave's tile of the exchange buffer, [sample][I, Q][slot in tile] (8 KB, written / read whole)
+    float *const sam_tile = (ROLE >= 4) ? a.xch_sam + (size_t)wave_g * (2 * ASDR_N * 8) + c8 : nullptr;
+    if (ROLE == 4) {   // the IF output leaves for the PLL kernel; the rest of the chain is the post kernel's
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float vi[4], vq[4];
+        load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float *e = sam_tile + (size_t)(kF + 32 * m + j) * 16; e[0] = vi[j]; e[8] = vq[j]; }
+      }
+      if (lead) S->status = status;
+      continue;
+    }
     // ---- SAM: quadrature PLL, AudioSDR.cpp:688-749 (sequential per channel) ---------------------------------
     bool pll_locked = false;
     // One channel's 128 PLL steps on ONE lane: Lc = the channel's LDS rows, Sc = its state row.  Returns the lock flag.
     auto pll_run = [&](float *Lc, ChanSmall *Sc) -> bool {
-      float y_re = Sc->pll_y_re, y_im = Sc->pll_y_im, prev_filt = Sc->pll_prev_filt;
-      float d0 = Sc->pll_d0, d1 = Sc->pll_d1, phase_est = Sc->pll_phase_est, pfreq = Sc->pll_freq;
-      bool locked = false;
-#pragma unroll 1
-      for (int i = 0; i < ASDR_N; i += 4) {
-        float xr[4], xi[4];
-        { const float4 r4 = *reinterpret_cast<const float4 *>(Lc + W0 + i), i4 = *reinterpret_cast<const float4 *>(Lc + W1 + i);
-          xr[0] = r4.x; xr[1] = r4.y; xr[2] = r4.z; xr[3] = r4.w; xi[0] = i4.x; xi[1] = i4.y; xi[2] = i4.z; xi[3] = i4.w; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float x_re = xr[u], x_im = xi[u];
-          const float d_re = x_re * y_re + x_im * y_im;
-          const float d_im = x_im * y_re - x_re * y_im;
-          const float err = approx_atan2<HAS_ALS>(d_im, d_re, K.half_pi_f);
-          d1 = d0;
-          d0 = err - K.pll_a1 * d1;
-          const float filt = K.pll_b0 * d0 + K.pll_b1 * d1;
-          // (float)((double)phase_est + (double)(filt + prev_filt) / 2.0) (:732) as ONE binary32 fma: the halving is exact in
-          // binary64 and rounding the binary64 sum of two binary32-precision values to binary32 is innocuous double rounding
-          // (53 >= 2 * 24 + 2), so the single rounding of the exact value agrees for every operand pair (oracle
-          // ao_check_pll_phase_update).  Four binary64-rate operations less on the loop's dependent chain.
-          phase_est = __builtin_fmaf(filt + prev_filt, 0.5f, phase_est);
-          prev_filt = filt;
-          // The reference's two unbounded wrap loops (:735-736) never end once |phase_est| is so large that
-          // phase_est -+ twoPI == phase_est (infinity; or a huge step): there they stall one Teensy instance, here they would
-          // hang the wave and with it the batch.  Defined difference: at most ASDR_PLL_WRAP_MAX turns per sample, then the
-          // estimate restarts at 0.  A physical loop-filter step is below pi, i.e. one turn; the oracle mirrors the bound.
-          // Comparisons against the double PI are comparisons against the float just above it: no float lies between them
-          // (pe >= PI_D <=> pe >= pi_up; pe < -PI_D <=> pe <= -pi_up).  The first turn is a select; further turns (never for a
-          // finite loop-filter step) run in a loop that a wave enters only if one of its lanes still needs it.
-          { const float pi_up = 3.14159274101257324f;   // RN_float(PI) > PI_D
-            const float dn = phase_est - two_pi, up = phase_est + two_pi;
-            phase_est = (phase_est >= pi_up) ? dn : ((phase_est <= -pi_up) ? up : phase_est);
-            if (__any(phase_est >= pi_up || phase_est <= -pi_up)) {
-              int turns = 1;
-              while (phase_est >= pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est -= two_pi; ++turns; }
-              while (phase_est <= -pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
-              if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f;
-            } }
-          y_re = cos_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
-          y_im = sin_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d);
-          pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
-          locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
-          const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
-          xr[u] = locked ? o_re : x_re;      // rotated sample while locked (:720-723), else the sample stays
-          xi[u] = locked ? o_im : x_im;
-        }
-        *reinterpret_cast<float4 *>(Lc + W0 + i) = make_float4(xr[0], xr[1], xr[2], xr[3]);
-        *reinterpret_cast<float4 *>(Lc + W1 + i) = make_float4(xi[0], xi[1], xi[2], xi[3]);
-      }
-      Sc->pll_y_re = y_re; Sc->pll_y_im = y_im; Sc->pll_prev_filt = prev_filt;
-      Sc->pll_d0 = d0; Sc->pll_d1 = d1; Sc->pll_phase_est = phase_est; Sc->pll_freq = pfreq;
-      return locked;
+      return pll_loop<HAS_ALS>(Sc, K, sine, two_pi,
+        [&](int i, float *xr, float *xi) {
+          const float4 r4 = *reinterpret_cast<const float4 *>(Lc + W0 + i), i4 = *reinterpret_cast<const float4 *>(Lc + W1 + i);
+          xr[0] = r4.x; xr[1] = r4.y; xr[2] = r4.z; xr[3] = r4.w; xi[0] = i4.x; xi[1] = i4.y; xi[2] = i4.z; xi[3] = i4.w; },
+        [&](int i, const float *xr, const float *xi) {
+          *reinterpret_cast<float4 *>(Lc + W0 + i) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+          *reinterpret_cast<float4 *>(Lc + W1 + i) = make_float4(xi[0], xi[1], xi[2], xi[3]); });
     };
     if constexpr (HAS_SAM && WAVES > 1) {
       // Every wave of the workgroup has its IF output in LDS; wave 0 runs the PLL of all 8 * WAVES channels, one per lane.
@@ -1134,6 +1164,17 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       if (is_sam) pll_locked = Li[SCR0] != 0;
+    }
+    if (ROLE == 5) {   // the rows as the PLL kernel left them (rotated where it was locked), and its lock flag
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float vi[4], vq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float *e = sam_tile + (size_t)(kF + 32 * m + j) * 16; vi[j] = e[0]; vq[j] = e[8]; }
+        store4(L + W0 + kF + 32 * m, vi); store4(L + W1 + kF + 32 * m, vq);
+      }
+      if (is_sam) pll_locked = (status & ASDR_S_PLL_LOCKED) != 0u;
+      WAVE_SYNC();
     }
     // envelope detector runs for AM, and for SAM when the PLL is unlocked at the end of the block (:132)
     const bool do_env = is_am || (is_sam && !pll_locked);
@@ -1638,7 +1679,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         po[0] = ro[0].v; po[8] = ro[1].v;
       }
     }
-    if (ROLE == 0) { if (lead) S->status = status; }
+    if (!STREAM) { if (lead) S->status = status; }
     else { store_status_bits(ASDR_S_AGC_ACTIVE); sig_pending = (uint32_t)blk + 1u; }
     WAVE_SYNC();
     // Wave 0 of the designated launch leaves the NEXT block's local-oscillator pairs in the other cache entry (LoEntry).
@@ -1674,7 +1715,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     TL(15);
   }
-  if (ROLE != 0 && sig_pending) stream_signal(my_prog, sig_pending, lane);
+  if (STREAM && sig_pending) stream_signal(my_prog, sig_pending, lane);
 #undef P
 }
 
@@ -1699,6 +1740,38 @@ ASDR_KERNEL(asdr_update_kernel_sam, ASDR_SAM_WAVES * 8 * ASDR_STRIDE + 260, ASDR
 #endif
 ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true, 1)
 ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
+
+// SAM sub-range as three launches (asdr_launch_update): pre | PLL | post
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, false, 1, 4>(a, lds);
+}
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, false, 1, 5>(a, lds);
+}
+// One LANE per channel: lane l of workgroup w runs the PLL of schedule slot 64 w + l on the rows the pre kernel left in its tile.
+extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs a) {
+  __shared__ float sine[ASDR_SINE_TABLE_LEN];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
+  __syncthreads();
+  const int s = (int)blockIdx.x * 64 + lane;
+  if (s >= a.n_sched) return;
+  const int4 sl = *reinterpret_cast<const int4 *>(a.sched + s);   // {channel, mode, flags, -}
+  if (sl.x >= a.n_channels || (uint32_t)sl.y != ASDR_SAMmode) return;
+  ChanSmall *Sc = a.small + sl.x;
+  float *const xt = a.xch_sam + (size_t)(s >> 3) * (2 * ASDR_N * 8) + (s & 7);
+  const bool lk = pll_loop<false>(Sc, a.k, sine, a.k.two_pi_f,
+    [&](int i, float *xr, float *xi) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float *e = xt + (size_t)(i + u) * 16; xr[u] = e[0]; xi[u] = e[8]; } },
+    [&](int i, const float *xr, const float *xi) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { float *e = xt + (size_t)(i + u) * 16; e[0] = xr[u]; e[8] = xi[u]; } });
+  const uint32_t st = Sc->status;
+  Sc->status = (st & ~ASDR_S_PLL_LOCKED) | (lk ? ASDR_S_PLL_LOCKED : 0u);
+}
 
 // Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves),
 // workgroup 3W the oscillator role; all 3W + 1 workgroups must be resident together (the host launches it only for small batches).  Uniform-key SSB waves only.
@@ -1816,6 +1889,11 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
   if (variant == ASDR_KERNEL_ALS) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_SAM && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
+    hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + 63) / 64), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  }
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   return hipGetLastError() == hipSuccess ? 0 : -1;
