@@ -405,17 +405,18 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // SAM quadrature PLL, AudioSDR.cpp:688-749: one channel's 128 steps on ONE lane (strictly sequential).  ld(i, xr, xi) / st(i, xr, xi)
 // read / write the four IF samples i .. i + 3 of the channel (its LDS rows in the fused kernels, its exchange tile in the
 // stand-alone PLL kernel); Sc = the channel's state row.  Returns the lock flag after the block.
-template <bool TWO_SUMS, typename LD, typename ST>
+// CH = samples per loop trip (4 from LDS; 16 in the PLL kernel, whose accessor requests the next trip's samples from HBM first).
+template <bool TWO_SUMS, int CH, typename LD, typename ST>
 __device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, const float *sine, float two_pi, LD ld, ST st) {
     float y_re = Sc->pll_y_re, y_im = Sc->pll_y_im, prev_filt = Sc->pll_prev_filt;
     float d0 = Sc->pll_d0, d1 = Sc->pll_d1, phase_est = Sc->pll_phase_est, pfreq = Sc->pll_freq;
     bool locked = false;
 #pragma unroll 1
-    for (int i = 0; i < ASDR_N; i += 4) {
-      float xr[4], xi[4];
+    for (int i = 0; i < ASDR_N; i += CH) {
+      float xr[CH], xi[CH];
       ld(i, xr, xi);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < CH; ++u) {
         const float x_re = xr[u], x_im = xi[u];
         const float d_re = x_re * y_re + x_im * y_im;
         const float d_im = x_im * y_re - x_re * y_im;
@@ -1114,14 +1115,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
 
     // SAM as three launches: this wave's tile of the exchange buffer, [sample][I, Q][slot in tile] (8 KB, written / read whole)
-    float *const sam_tile = (ROLE >= 4) ? a.xch_sam + (size_t)wave_g * (2 * ASDR_N * 8) + c8 : nullptr;
+    // The tile moves as 512 sixteen-byte pieces, lane l on pieces l, l + 64, ..: piece p = (sample p / 4, I or Q = (p / 2) % 2, slots
+    // 4 (p % 2) .. + 3) -- one wave instruction moves 1 KB contiguous; the four values of a piece come from four channels' LDS rows.
+    float *const sam_tile = (ROLE >= 4) ? a.xch_sam + (size_t)wave_g * (2 * ASDR_N * 8) : nullptr;
+    float *const sam_lds = lds + (4 * (lane_i & 1)) * STRIDE + (((lane_i >> 1) & 1) ? W1 : W0) + (lane_i >> 2);
     if (ROLE == 4) {   // the IF output leaves for the PLL kernel; the rest of the chain is the post kernel's
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float vi[4], vq[4];
-        load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { float *e = sam_tile + (size_t)(kF + 32 * m + j) * 16; e[0] = vi[j]; e[8] = vq[j]; }
+      for (int k = 0; k < 8; ++k) {
+        const float *src = sam_lds + 16 * k;
+        *reinterpret_cast<float4 *>(sam_tile + 4 * (lane_i + 64 * k)) = make_float4(src[0], src[STRIDE], src[2 * STRIDE], src[3 * STRIDE]);
       }
       if (lead) S->status = status;
       continue;
@@ -1130,7 +1132,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     bool pll_locked = false;
     // One channel's 128 PLL steps on ONE lane: Lc = the channel's LDS rows, Sc = its state row.  Returns the lock flag.
     auto pll_run = [&](float *Lc, ChanSmall *Sc) -> bool {
-      return pll_loop<HAS_ALS>(Sc, K, sine, two_pi,
+      return pll_loop<HAS_ALS, 4>(Sc, K, sine, two_pi,
         [&](int i, float *xr, float *xi) {
           const float4 r4 = *reinterpret_cast<const float4 *>(Lc + W0 + i), i4 = *reinterpret_cast<const float4 *>(Lc + W1 + i);
           xr[0] = r4.x; xr[1] = r4.y; xr[2] = r4.z; xr[3] = r4.w; xi[0] = i4.x; xi[1] = i4.y; xi[2] = i4.z; xi[3] = i4.w; },
@@ -1166,12 +1168,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (is_sam) pll_locked = Li[SCR0] != 0;
     }
     if (ROLE == 5) {   // the rows as the PLL kernel left them (rotated where it was locked), and its lock flag
+      float4 pc[8];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float vi[4], vq[4];
+      for (int k = 0; k < 8; ++k) pc[k] = *reinterpret_cast<const float4 *>(sam_tile + 4 * (lane_i + 64 * k));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float *e = sam_tile + (size_t)(kF + 32 * m + j) * 16; vi[j] = e[0]; vq[j] = e[8]; }
-        store4(L + W0 + kF + 32 * m, vi); store4(L + W1 + kF + 32 * m, vq);
+      for (int k = 0; k < 8; ++k) {
+        float *dst = sam_lds + 16 * k;
+        dst[0] = pc[k].x; dst[STRIDE] = pc[k].y; dst[2 * STRIDE] = pc[k].z; dst[3 * STRIDE] = pc[k].w;
       }
       if (is_sam) pll_locked = (status & ASDR_S_PLL_LOCKED) != 0u;
       WAVE_SYNC();
@@ -1762,7 +1765,10 @@ extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs 
   if (sl.x >= a.n_channels || (uint32_t)sl.y != ASDR_SAMmode) return;
   ChanSmall *Sc = a.small + sl.x;
   float *const xt = a.xch_sam + (size_t)(s >> 3) * (2 * ASDR_N * 8) + (s & 7);
-  const bool lk = pll_loop<false>(Sc, a.k, sine, a.k.two_pi_f,
+  // (The kernel is bound by its instruction count -- ~120 per sample and lane, 61 k wave instructions per SIMD for C3, as many as
+  // the whole C2 chain -- not by these 32-byte accesses: 16-sample trips with the next trip's values requested ahead, and without
+  // the stores altogether, changed its 0.18 ms by less than 0.01 / 0.04 ms.)
+  const bool lk = pll_loop<false, 4>(Sc, a.k, sine, a.k.two_pi_f,
     [&](int i, float *xr, float *xi) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const float *e = xt + (size_t)(i + u) * 16; xr[u] = e[0]; xi[u] = e[8]; } },
