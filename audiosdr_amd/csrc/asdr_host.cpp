@@ -304,6 +304,8 @@ void fill_params(const Chan &c, ChanParams &p) {
 int kernel_kind(const ChanParams &p) {
   return (p.flags & ASDR_F_ALS_EN) ? ASDR_KERNEL_ALS : ((p.mode == ASDR_SAMmode) ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN);
 }
+// ASDR_SAM_FUSED=1: SAM channels through the fused 4-wave kernel instead of the pre | PLL | post launches (comparison switch)
+bool sam_fused_env() { static const bool v = getenv("ASDR_SAM_FUSED") != nullptr; return v; }
 uint64_t sched_key(const ChanParams &p) {
   return ((uint64_t)kernel_kind(p) << 60) | ((uint64_t)(p.mode & 0xFFFF) << 40) | ((uint64_t)(p.flags & 0xFF) << 32) |
          ((uint64_t)(p.if_table & 0xFF) << 24) | ((uint64_t)(p.audio_table & 0xFF) << 16) | (uint64_t)(p.agc_table & 0xFFFF);
@@ -357,7 +359,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
       const int k = (int)(order[i].first >> 60), g = j - i;
-      if (k == ASDR_KERNEL_SAM) rem[k] += g;   // the SAM instantiation has only the general form (4-wave workgroups)
+      if (k == ASDR_KERNEL_SAM && sam_fused_env()) rem[k] += g;   // the fused SAM instantiation has only the general form (4-wave workgroups)
       else { uni[k] += g / 8 * 8; rem[k] += g % 8; }
       i = j;
     }
@@ -372,7 +374,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
-      const int k = (int)(order[i].first >> 60), g = j - i, whole = (k == ASDR_KERNEL_SAM) ? 0 : g / 8 * 8;
+      const int k = (int)(order[i].first >> 60), g = j - i, whole = (k == ASDR_KERNEL_SAM && sam_fused_env()) ? 0 : g / 8 * 8;
       for (int t = 0; t < g; t++) {
         const int c = order[i + t].second;
         int &at = (t < whole) ? at_u[k] : at_m[k];
@@ -666,8 +668,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // SAM channels (no ALS) run as three launches per block -- everything in front of the PLL | the PLL with one LANE per channel |
   // everything behind it -- through a 1 KB-per-slot exchange buffer: as a phase of one fused kernel the PLL's 128-step dependent
   // chain kept a workgroup's other waves waiting (ASDR_SAM_FUSED=1 selects that kernel, for comparison).
-  static const bool sam_fused = getenv("ASDR_SAM_FUSED") != nullptr;
-  const bool sam_split = !sam_fused && b->kind_slots[ASDR_KERNEL_SAM] > 0;
+  const bool sam_split = !sam_fused_env() && b->kind_slots[ASDR_KERNEL_SAM] > 0;
   if (sam_split && (size_t)b->kind_slots[ASDR_KERNEL_SAM] > b->xch_sam_slots) {
     HIPCHK(hipStreamSynchronize(stream));
     if (b->d_xch_sam) HIPCHK(hipFree(b->d_xch_sam));
@@ -728,6 +729,8 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
         a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags;
       }
       a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
+      if (sam_split && subs[i].kind == ASDR_KERNEL_SAM)   // this sub-range's tiles (1 KB per slot, 8 slots per tile)
+        a.xch_sam = b->d_xch_sam + (size_t)(subs[i].first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
       if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
       if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }
     }

@@ -1753,6 +1753,15 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pos
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, false, 1, 5>(a, lds);
 }
+// ... and their forms for waves of one schedule key (scalar mode / enable tests)
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre_kernel_uniform(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 4>(a, lds);
+}
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_kernel_uniform(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 5>(a, lds);
+}
 // One LANE per channel: lane l of workgroup w runs the PLL of schedule slot 64 w + l on the rows the pre kernel left in its tile.
 extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs a) {
   __shared__ float sine[ASDR_SINE_TABLE_LEN];
@@ -1896,9 +1905,11 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   if (n_waves <= 0) return 0;
   if (variant == ASDR_KERNEL_ALS) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if (variant == ASDR_KERNEL_SAM && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
-    hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + 63) / 64), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   }
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
