@@ -404,3 +404,34 @@ def test_sam_lock_fraction_c3_sample(gpu, ao):
         assert np.array_equal(got[c].reshape(-1), o.update(I[c], Q[c]))
         assert f32_bits(st["sam_frequency"][c]) == f32_bits(np.float32(o.getSAMfrequency()))
     batch.close()
+
+
+def test_comparison_paths_still_bit_exact(gpu):
+    """Two code paths are kept behind environment switches for A/B measurements (read once per process, hence the child process):
+    ASDR_SAM_FUSED=1 = the fused 4-wave SAM kernel instead of the pre | PLL | post launches, ASDR_NO_STREAM_PIPELINE=1 = the in-kernel
+    block loop instead of the block pipeline.  Both must stay bit-exact against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import audiosdr_amd as A
+from oracle import asdr_oracle as ao
+from audiosdr_amd.synth import make_iq
+n_ch, T = 64, 12
+fc = 6890.0 + (np.arange(n_ch) %% 5 - 2) * 40.0
+I, Q = make_iq(n_ch, T, fc=fc, A=0.3, m=0.4, noise=0.02)
+for mode in (5, 1):                                   # SAM (fused kernel), LSB (in-kernel block loop, 8 uniform waves x 12 blocks)
+    b = A.AudioSDRBatch(n_ch); b.setDemodMode(mode); b.enableAudioFilter()
+    got = b.update(I, Q)
+    assert b.stream_pipeline_launches() == 0
+    for c in range(n_ch):
+        o = ao.OracleSDR(); o.setDemodMode(mode); o.enableAudioFilter()
+        assert np.array_equal(got[c], o.update(I[c], Q[c]).reshape(T, 128)), (mode, c)
+    b.close()
+print("ok")
+''' % (os.path.join(os.path.dirname(__file__), ".."), os.path.dirname(__file__))
+    env = dict(os.environ, ASDR_SAM_FUSED="1", ASDR_NO_STREAM_PIPELINE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
