@@ -175,6 +175,7 @@ struct asdr_batch {
   float *d_xch_a = nullptr, *d_xch_b = nullptr;
   uint32_t *d_stream_prog = nullptr;
   LoEntry *d_lo_ring = nullptr;
+  bool sam_split = false;           // decided when the schedule is built (enough SAM channels, ASDR_SAM_FUSED not set)
   float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
   size_t xch_sam_slots = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
@@ -304,6 +305,9 @@ void fill_params(const Chan &c, ChanParams &p) {
 int kernel_kind(const ChanParams &p) {
   return (p.flags & ASDR_F_ALS_EN) ? ASDR_KERNEL_ALS : ((p.mode == ASDR_SAMmode) ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN);
 }
+#ifndef ASDR_SAM_SPLIT_MIN_CHANNELS
+#define ASDR_SAM_SPLIT_MIN_CHANNELS 512
+#endif
 // ASDR_SAM_FUSED=1: SAM channels through the fused 4-wave kernel instead of the pre | PLL | post launches (comparison switch)
 bool sam_fused_env() { static const bool v = getenv("ASDR_SAM_FUSED") != nullptr; return v; }
 uint64_t sched_key(const ChanParams &p) {
@@ -355,11 +359,18 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     std::sort(order.begin(), order.end());   // (key, channel): equal keys stay in channel order
     // per kernel kind: slots of the whole waves of every key group, and of the groups' remainders
     int uni[3] = {0, 0, 0}, rem[3] = {0, 0, 0};
+    // SAM (no ALS) as three launches per block only when there are enough SAM channels to fill the PLL kernel's waves: a handful
+    // of them is quicker through the fused kernel (one launch, no exchange round trips)
+    int n_sam = 0;
+    for (int i = 0; i < b->n; i++) n_sam += ((int)(order[i].first >> 60) == ASDR_KERNEL_SAM);
+    static const int sam_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;   // (tests: 1)
+    b->sam_split = !sam_fused_env() && n_sam >= sam_min;
+    const bool sam_general_only = !b->sam_split;
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
       const int k = (int)(order[i].first >> 60), g = j - i;
-      if (k == ASDR_KERNEL_SAM && sam_fused_env()) rem[k] += g;   // the fused SAM instantiation has only the general form (4-wave workgroups)
+      if (k == ASDR_KERNEL_SAM && sam_general_only) rem[k] += g;   // the fused SAM instantiation has only the general form (4-wave workgroups)
       else { uni[k] += g / 8 * 8; rem[k] += g % 8; }
       i = j;
     }
@@ -374,7 +385,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
-      const int k = (int)(order[i].first >> 60), g = j - i, whole = (k == ASDR_KERNEL_SAM && sam_fused_env()) ? 0 : g / 8 * 8;
+      const int k = (int)(order[i].first >> 60), g = j - i, whole = (k == ASDR_KERNEL_SAM && sam_general_only) ? 0 : g / 8 * 8;
       for (int t = 0; t < g; t++) {
         const int c = order[i + t].second;
         int &at = (t < whole) ? at_u[k] : at_m[k];
@@ -668,7 +679,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // SAM channels (no ALS) run as three launches per block -- everything in front of the PLL | the PLL with one LANE per channel |
   // everything behind it -- through a 1 KB-per-slot exchange buffer: as a phase of one fused kernel the PLL's 128-step dependent
   // chain kept a workgroup's other waves waiting (ASDR_SAM_FUSED=1 selects that kernel, for comparison).
-  const bool sam_split = !sam_fused_env() && b->kind_slots[ASDR_KERNEL_SAM] > 0;
+  const bool sam_split = b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] > 0;
   if (sam_split && (size_t)b->kind_slots[ASDR_KERNEL_SAM] > b->xch_sam_slots) {
     HIPCHK(hipStreamSynchronize(stream));
     if (b->d_xch_sam) HIPCHK(hipFree(b->d_xch_sam));

@@ -435,3 +435,7 @@ print("ok")
     env = dict(os.environ, ASDR_SAM_FUSED="1", ASDR_NO_STREAM_PIPELINE="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+    # ... and the other way round: the pre | PLL | post launches for a batch below the size at which they are chosen (512 SAM channels)
+    env = dict(os.environ, ASDR_SAM_SPLIT_MIN="1", ASDR_NO_STREAM_PIPELINE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
