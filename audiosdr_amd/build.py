@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libasdr_hip.so")
 SOURCES = ["asdr_kernels.hip", "asdr_host.cpp", "asdr_front.hip", "asdr_front_host.cpp"]
-DEPS = SOURCES + ["asdr_device.h", "asdr_tables.h", "asdr_front_device.h", "asdr_front_tables.h",
+DEPS = SOURCES + ["asdr_device.h", "asdr_fir.h", "asdr_tables.h", "asdr_front_device.h", "asdr_front_tables.h",
                   os.path.join("..", "..", "include", "asdr.h"), os.path.join("..", "..", "include", "asdr_front.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-fast-math", "-fPIC", "-shared",

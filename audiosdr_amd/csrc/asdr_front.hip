@@ -10,6 +10,7 @@
 
 #include "asdr_front_device.h"
 #include "asdr_front_tables.h"
+#include "asdr_fir.h"
 
 #define WAVE_SYNC() __syncthreads() /* workgroup == one wave: a wave barrier + LDS/VMEM waits */
 
@@ -210,9 +211,12 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
     for (int q = 0; q < 8; ++q) reinterpret_cast<float4 *>(w + 32 * s8)[q] = h[q];
   }
 
+  // Delay line in LDS: sample x[m] of the reference's 384-sample window (two carried blocks + the newest) at w[m - 1], m = 1..383
+  // -- natural order shifted by one float (x[0] is never read), the layout the shared packed FIR wants (asdr_fir.h); the carried
+  // row in HBM holds w[0..255] = x[1..256] as it stands (its last word belongs to the next block and is overwritten first).
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    {   // newest block -> w[256..383], scaled (.cpp:56)
+    {   // newest block -> x[256..383] = w[255..382], scaled (.cpp:56)
       Raw8 r0, r1;
       r0.v = r1.v = make_int4(0, 0, 0, 0);
       if (valid) {
@@ -220,40 +224,20 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
         r0.v = p[0]; r1.v = p[1];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { w[256 + i0 + j] = unit_scale(r0.s[j]); w[256 + i0 + 8 + j] = unit_scale(r1.s[j]); }
+      for (int j = 0; j < 8; ++j) { w[255 + i0 + j] = unit_scale(r0.s[j]); w[255 + i0 + 8 + j] = unit_scale(r1.s[j]); }
     }
     WAVE_SYNC();
-    float acc[2][8];
+    // this lane's 16 outputs i0 + 2e, i0 + 2e + 1 (e = 0..7) as 8 packed pairs: AudioIQgenerator.cpp:60-76, taps c_iq_taps
+    v2f acc2[8];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[par][e] = 0.0f;
-#pragma unroll 1
-      for (int kc = 0; kc < 4; ++kc) {
-        // output i = i0 + par + 2e, tap k = 16kc + kk:  A = w[255 + i - 2k] = Aw[e - kk + 15],  B = w[i + 2k + 1] = Bw[e + kk]
-        const float *pa = w + (255 + i0 + par - 32 * kc - 30);
-        const float *pb = w + (i0 + par + 1 + 32 * kc);
-        float Aw[23], Bw[23];
-#pragma unroll
-        for (int t = 0; t < 23; ++t) { Aw[t] = pa[2 * t]; Bw[t] = pb[2 * t]; }
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const float c = c_iq_taps[16 * kc + kk];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = Aw[e - kk + 15] - Bw[e + kk];
-            const float pr = c * d;
-            acc[par][e] += pr;
-          }
-        }
-      }
-    }
+    for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
+    hilbert_fir_rows<0, 8>(w, i0 >> 1, acc2, c_iq_taps);
     if (valid) {   // .cpp:78-82: (int16_t)(float * 32767.0 * gain) in binary64; v_cvt_i32_f64 saturates like the ARM target
       int vi[16], vq[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float iv = w[128 + i0 + j];
-        const float qv = acc[j & 1][j >> 1];
+        const float iv = w[127 + i0 + j];          // x[128 + i0 + j]: the input delayed by one block
+        const float qv = acc2[j >> 1][j & 1];
         vi[j] = (int)(((double)iv * 32767.0) * (double)gain_i);
         vq[j] = (int)(((double)qv * 32767.0) * (double)gain_q);
       }
@@ -268,7 +252,7 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
       po[0] = oi[0].v; po[1] = oi[1].v; pq[0] = oq[0].v; pq[1] = oq[1].v;
     }
     WAVE_SYNC();
-    // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383];
+    // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383] (word 383 is padding);
     // source and destination of each phase are disjoint, 16 floats per lane
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {

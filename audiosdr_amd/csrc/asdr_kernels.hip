@@ -54,7 +54,6 @@
 
 #define PI_D 3.1415926535897932384626433832795 /* Arduino.h PI (double) */
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // one aligned VGPR quad (operand of the exchange rings' inline-assembly accesses)   // one aligned VGPR pair: operand of v_pk_mul_f32 / v_pk_add_f32
 
 // Build-time ablation mask for profiling builds (DESIGN.md "ablation"); the shipped library uses 0.
@@ -105,6 +104,7 @@ extern "C" int asdr_kernels_upload_tables(void) {
 #else
 #define SCHED_FENCE() do { } while (0)
 #endif
+#include "asdr_fir.h"
 // ---- scalar helpers (AudioSDR.h:358-446) ------------------------------------------------------------
 // Correctly rounded binary64 quotient x / c for a constant c with r = RN(1/c) (Markstein): q0 = RN(x*r),
 // rem = x - c*q0 exactly (fma), q = RN(q0 + rem*r) == RN(x/c).  Replaces the ~30-instruction IEEE f64 division
@@ -461,41 +461,10 @@ __device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, co
     return locked;
 }
 
-// Folded Hilbert FIR, AudioSDR.cpp:99-110, output pairs E0 .. E0 + NE - 1 of this lane's eight (outputs i = 16 s8 + 2e, + 1):
-//   Q[i] = sum_k h[k] * (x[255 + i - 2k] - x[i + 2k + 1]),  k ascending, accumulate from 0.0
-// With PX[p] = (x[2p+1], x[2p+2]) the operands of the output pair e are PX[127 + p0 + e - k] and PX[p0 + e + k] (p0 = 8 s8): per
-// chunk of 8 taps two contiguous (NE + 7)-pair register windows (ds_read_b128).  v_pk_mul_f32 / v_pk_add_f32 round each half
-// exactly like the scalar ops, so the result is bit-identical to the scalar loop.  Lrow = the channel's LDS row (history at XP).
+// Folded Hilbert FIR of the update kernels (asdr_fir.h): Lrow = the channel's LDS row (history at XP), taps c_hilbert.
 template <int E0, int NE>
 __device__ __forceinline__ void hilbert_fir(const float *Lrow, int p0, v2f *acc2) {
-  constexpr int NW = NE + 7;
-  const v2f *PX = reinterpret_cast<const v2f *>(Lrow + XP) + E0;
-#pragma unroll 1
-  for (int kc = 0; kc < 8; ++kc) {
-    v2f dw[NW], uw[NW];   // dw[t] = PX[120 + p0 - 8kc + t], uw[t] = PX[p0 + 8kc + t]  (t = 0..NW-1, pairs counted from E0)
-    const float4 *dp = reinterpret_cast<const float4 *>(PX + 120 + p0 - 8 * kc);
-    const float4 *up = reinterpret_cast<const float4 *>(PX + p0 + 8 * kc);
-#pragma unroll
-    for (int q = 0; q < NW / 2; ++q) {
-      const float4 d4 = dp[q], u4 = up[q];
-      dw[2 * q] = (v2f){d4.x, d4.y}; dw[2 * q + 1] = (v2f){d4.z, d4.w};
-      uw[2 * q] = (v2f){u4.x, u4.y}; uw[2 * q + 1] = (v2f){u4.z, u4.w};
-    }
-    if (NW & 1) { dw[NW - 1] = PX[120 + p0 - 8 * kc + NW - 1]; uw[NW - 1] = PX[p0 + 8 * kc + NW - 1]; }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const float hk = c_hilbert[8 * kc + kk];
-      const v2f hk2 = (v2f){hk, hk};
-      v2f d[NE];   // the pair-chains of a tap are independent: issue them interleaved (no dependent back-to-back pk ops)
-#pragma unroll
-      for (int e = 0; e < NE; ++e) d[e] = dw[7 + e - kk] - uw[e + kk];
-#pragma unroll
-      for (int e = 0; e < NE; ++e) d[e] = hk2 * d[e];
-#pragma unroll
-      for (int e = 0; e < NE; ++e) acc2[e] += d[e];
-      SCHED_FENCE();
-    }
-  }
+  hilbert_fir_rows<E0, NE>(Lrow + XP, p0, acc2, c_hilbert);
 }
 // Second wave of a role-2 workgroup of the streaming pipeline: nothing but the other half of the FIR, in step with the first
 // wave's three barriers per block (history staged | all reads done | both halves in W1).
