@@ -25,14 +25,13 @@ extern "C" int asdr_front_upload_tables(void) {
   return 0;
 }
 
-// (float)((double)s / 32767.0): correctly rounded binary64 quotient by the Markstein reciprocal form (mul + 2 fma;
-// exhaustively equal to true division for every int16, ao_front_check_div32767 in the CPU test-suite), then one
-// rounding to float32 -- the reference's `float(x)/32767.0` (AudioSDRpreProcessor.cpp:89-90, AudioIQgenerator.cpp:56).
+// (float)((double)s / 32767.0): the correctly rounded binary64 quotient as ONE multiply and ONE fma -- 1/32767 = r + r 2^-60 + ..
+// with r = RN(1/32767) = 0x1.0002000400080p-15, and fma(x, r, x * r 2^-60) equals true division for every int16 (exhaustive:
+// oracle ao_check_scale_division; asdr_kernels.hip div_i16_by_32767) -- then one rounding to float32: the reference's
+// `float(x)/32767.0` (AudioSDRpreProcessor.cpp:89-90, AudioIQgenerator.cpp:56).
 __device__ __forceinline__ float unit_scale(int s) {
-  const double x = (double)s, c = 32767.0, r = 1.0 / 32767.0;
-  const double q0 = x * r;
-  const double rem = __builtin_fma(-q0, c, x);
-  return (float)__builtin_fma(rem, r, q0);
+  const double x = (double)s;
+  return (float)__builtin_fma(x, 0x1.0002000400080p-15, x * 0x1.0002000400080p-75);
 }
 
 union Raw8 { int4 v; int16_t s[8]; };
