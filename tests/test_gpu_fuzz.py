@@ -3,7 +3,7 @@ pathological inputs.  Everything bit-exact against the oracle, through the C ABI
 import numpy as np
 import pytest
 
-from helpers import S, apply_setters, compare_status
+from helpers import Hip, S, apply_setters, compare_status
 
 pytestmark = pytest.mark.gpu
 
@@ -103,3 +103,51 @@ def test_pathological_inputs(gpu, ao):
         assert np.array_equal(got, want), mode
         compare_status(gpu, batch, orcs)
         batch.close()
+
+
+@pytest.mark.parametrize("seed,ssb_only", [(101, True), (102, True), (103, False), (104, False)])
+def test_fuzz_multi_block_calls(gpu, ao, seed, ssb_only):
+    """64 channels in groups of 8 that always share their configuration (so the waves keep one schedule key), random setter calls
+    between calls of 1 / 3 / 8 / 17 / 30 blocks.  With SSB-class modes only, the calls of 8 blocks and more run as the streaming
+    block pipeline; with all modes they run block by block or through the in-kernel block loop.  Every block against the oracle."""
+    from audiosdr_amd.synth import make_iq
+    rng = np.random.default_rng(seed)
+    n_ch, plan = 64, [int(rng.choice([1, 3, 8, 17, 30])) for _ in range(7)]
+    total = sum(plan)
+    grp_fc = 6890.0 + rng.uniform(-1500, 1500, n_ch // 8)
+    fc = np.repeat(grp_fc, 8)
+    I, Q = make_iq(n_ch, total, fc=fc, A=np.repeat(rng.uniform(0.02, 0.5, n_ch // 8), 8), m=0.3, fm=250.0,
+                   impulse_every=int(rng.integers(300, 900)))
+    batch = gpu.AudioSDRBatch(n_ch)
+    orcs = [ao.OracleSDR() for _ in range(n_ch)]
+
+    def random_group_setters(k):
+        out = []
+        for _ in range(k):
+            meth, args, _sel = _random_setter(rng)
+            if ssb_only and meth == "setDemodMode":
+                args = (int(rng.choice([0, 1, 2, 3, 6])),)
+            if meth in ("enableALSfilter", "setALSfilterParams") and ssb_only:
+                continue
+            groups = rng.random(n_ch // 8) < 0.35
+            out.append(S(meth, *args, sel=lambda c, g=groups: bool(g[c // 8])))
+        return out
+
+    apply_setters(batch, orcs, [S("setDemodMode", 1), S("disableALSfilter")] + random_group_setters(40))
+    hip = Hip()
+    pos = 0
+    for T in plan:
+        apply_setters(batch, orcs, random_group_setters(int(rng.integers(0, 3))))
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "seed %d call of %d blocks at %d, ch %d (mode %d)" % (seed, T, pos, c, orcs[c].getDemodMode())
+        pos += T
+    if ssb_only:
+        assert batch.stream_pipeline_launches() == sum(1 for T in plan if T >= 8)
+    compare_status(gpu, batch, orcs)
+    hip.free_all(); batch.close()
