@@ -27,6 +27,18 @@ def hipcc():
     return "hipcc"
 
 
+def source_sha256():
+    """sha256 over the library's sources, headers and build flags (path-independent, unlike the binary's hash: hipcc's output
+    depends on where the tree lives): stamps measurement files with the code they were taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update((" ".join(FLAGS) + " " + ARCH).encode())
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode()); h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True

@@ -249,10 +249,13 @@ def main():
                 pj = json.load(f)
             if n_ch == CHANNELS_PER_GPU and not args.dry_run:
                 import audiosdr_amd as A
-                if pj.get("library_sha256") == A.library_sha256():
+                from audiosdr_amd import build as _build
+                same_binary = pj.get("library_sha256") == A.library_sha256()
+                same_source = pj.get("source_sha256") is not None and pj.get("source_sha256") == _build.source_sha256()
+                if same_binary or same_source:   # (the binary's hash depends on the tree's path; the sources' does not)
                     traffic = pj.get("traffic_bytes_per_launch")
-                    traffic_source = "%s (builder-run rocprofv3 --pmc passes of this command on this library build, sha256 %s)" % (
-                        PMC_FILE, pj.get("library_sha256", "")[:12])
+                    traffic_source = "%s (builder-run rocprofv3 --pmc passes of this command on a library built from these sources: %s)" % (
+                        PMC_FILE, ("binary sha256 %s" % pj.get("library_sha256", "")[:12]) if same_binary else ("source sha256 %s" % pj.get("source_sha256", "")[:12]))
                 else:
                     traffic_source = "%s is from another build of the library: dropped" % PMC_FILE
         except Exception:

@@ -20,7 +20,10 @@ med = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
 import hashlib, os
 _lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "audiosdr_amd", "libasdr_hip.so")
 _sha = hashlib.sha256(open(_lib, "rb").read()).hexdigest() if os.path.exists(_lib) else None
-res = {"library_sha256": _sha, "kernel": "asdr_update_kernel", "workload": "bench.py C2, 65536 channels x 1 block per launch", "counters_median_per_launch": med}
+import sys as _sys
+_sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from audiosdr_amd import build as _build
+res = {"library_sha256": _sha, "source_sha256": _build.source_sha256(), "kernel": "asdr_update_kernel", "workload": "bench.py C2, 65536 channels x 1 block per launch", "counters_median_per_launch": med}
 if "FETCH_SIZE" in med and "WRITE_SIZE" in med:
     res["hbm_read_bytes"] = 2 * med["FETCH_SIZE"] * 1024
     res["hbm_write_bytes"] = med["WRITE_SIZE"] * 1024
