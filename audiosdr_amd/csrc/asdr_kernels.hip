@@ -348,7 +348,7 @@ template <bool CHECKED>
 __device__ __forceinline__ float als_dot(const float *w, const float *x, int top, int M) {
   float y = 0.0f;
   int q = 0;
-#pragma unroll 1
+#pragma unroll 2
   for (; q + 4 <= M; q += 4) {
     const float4 w4 = *reinterpret_cast<const float4 *>(w + q);
     const int t = top - q;
@@ -1565,6 +1565,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if constexpr (HAS_ALS) {
       if (ABL_ON(ABL_ALS) && __any(als_en)) {
         const int M = P.als_m, D = P.als_delay;
+        const float lam = P.als_lambda;   // (requested once, not in every tap-update epoch)
         const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
         float *gx = a.als_x + (size_t)ch * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
         if (als_en) {
@@ -1613,8 +1614,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_en && adaptive && nu < ASDR_N) {
               const float e = L[SCR1];
               const int iu = 128 + nu;
-              const float lam = P.als_lambda;
               if (als_safe) {
+#pragma unroll 2
                 for (int q = s8; q < M; q += 8) { const float gq = e * L[ALS_X + iu - D - q]; const float dq = lam * gq; L[ALS_W + q] += dq; }
               } else {
                 for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[ALS_W + q] += dq; }
