@@ -342,15 +342,18 @@ __device__ __forceinline__ uint32_t mask_encode4(float4 mv) {
 }
 
 // ALS FIR (AudioSDR.cpp:331-335): y = sum_{q < M} w[q] * x[top - q], q ascending, every product and sum separately rounded.
+// The taps sit in LDS de-interleaved: even taps at w[0..63], odd taps at w[64..127] (ALS_TAP), so that the two halves of a
+// channel's eight lanes can each fetch four of "their" taps with one ds_read_b128 (als_dot_split below).
+#define ALS_TAP(q) ((((q) & 1) << 6) + ((q) >> 1))
 // CHECKED = false requires every index top - q (q < M) to lie inside the 256-sample history; CHECKED = true reads 0.0
-// outside it (DESIGN.md "defined differences").  Four taps per ds_read_b128 of w.
+// outside it (DESIGN.md "defined differences").  One lane does the whole sum (static taps, or parameters outside the safe range).
 template <bool CHECKED>
 __device__ __forceinline__ float als_dot(const float *w, const float *x, int top, int M) {
   float y = 0.0f;
   int q = 0;
 #pragma unroll 2
   for (; q + 4 <= M; q += 4) {
-    const float4 w4 = *reinterpret_cast<const float4 *>(w + q);
+    const float2 we = *reinterpret_cast<const float2 *>(w + (q >> 1)), wo = *reinterpret_cast<const float2 *>(w + 64 + (q >> 1));
     const int t = top - q;
     float x0, x1, x2, x3;
     if (CHECKED) {
@@ -360,13 +363,47 @@ __device__ __forceinline__ float als_dot(const float *w, const float *x, int top
       x0 = x[t]; x1 = x[t - 1]; x2 = x[t - 2]; x3 = x[t - 3];
     }
     float p;
-    p = w4.x * x0; y += p; p = w4.y * x1; y += p; p = w4.z * x2; y += p; p = w4.w * x3; y += p;
+    p = we.x * x0; y += p; p = wo.x * x1; y += p; p = we.y * x2; y += p; p = wo.y * x3; y += p;
   }
   for (; q < M; ++q) {
     const int t = top - q;
     const float xv = CHECKED ? ((t >= 0 && t < 256) ? x[t] : 0.0f) : x[t];
-    const float p = w[q] * xv;
+    const float p = w[ALS_TAP(q)] * xv;
     y += p;
+  }
+  return y;
+}
+
+// lane + 4 of the same row of 16 (the other half of this channel's eight lanes); folds into the consuming v_add_f32 as a DPP operand
+__device__ __forceinline__ float dpp_row_shl4(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xF, 0xF, true));
+}
+
+// The same sum for the adaptive filter's four samples per tap set, on all eight lanes of the channel: lanes 0-3 hold the four
+// samples and lanes 4-7 the same four again; the low half multiplies the even taps, the high half the odd taps, and the low half
+// adds both products in tap order (its own, then the partner's through a DPP operand).  Same products, same additions, same
+// order -- half the multiplies and loads per lane.  The result is valid on lanes 0-3 only.  Taps past M contribute a +0.0
+// (the running sum starts at +0.0 and so is never -0.0: adding +0.0 leaves it unchanged); their operands are read but not used.
+// Requires the unchecked index range of als_dot<false>.  `h` = lane half (0 / 1), `xh` = x + top - h, `wh` = w + 64 h.
+__device__ __forceinline__ float als_dot_split(const float *wh, const float *xh, int M, int h) {
+  float y = 0.0f;
+  int q = 0;
+#pragma unroll 2
+  for (; q + 8 <= M; q += 8) {
+    const float4 w4 = *reinterpret_cast<const float4 *>(wh + (q >> 1));
+    const float x0 = xh[-q], x1 = xh[-q - 2], x2 = xh[-q - 4], x3 = xh[-q - 6];
+    const float p0 = w4.x * x0, p1 = w4.y * x1, p2 = w4.z * x2, p3 = w4.w * x3;
+    y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
+    y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
+  }
+  if (q < M) {
+    const int rem = M - q - h;   // this half's taps q + 2t + h exist for 2t < rem
+    const float4 w4 = *reinterpret_cast<const float4 *>(wh + (q >> 1));
+    const float x0 = xh[-q], x1 = xh[-q - 2], x2 = xh[-q - 4], x3 = xh[-q - 6];
+    float p0 = w4.x * x0, p1 = w4.y * x1, p2 = w4.z * x2, p3 = w4.w * x3;
+    p0 = (0 < rem) ? p0 : 0.0f; p1 = (2 < rem) ? p1 : 0.0f; p2 = (4 < rem) ? p2 : 0.0f; p3 = (6 < rem) ? p3 : 0.0f;
+    y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
+    y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
   }
   return y;
 }
@@ -1576,7 +1613,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           for (int m = 0; m < 4; ++m) {
             store4(L + ALS_X + kF + 32 * m, tx + 4 * m);            // previous block
             store4(L + ALS_X + 128 + kF + 32 * m, tn + 4 * m); store4(gx + 32 * m, tn + 4 * m);
-            store4(L + ALS_W + kF + 32 * m, tw + 4 * m);
+            { float *we = L + ALS_W + ((kF + 32 * m) >> 1);   // taps de-interleaved (ALS_TAP)
+              *reinterpret_cast<float2 *>(we) = make_float2(tw[4 * m], tw[4 * m + 2]);
+              *reinterpret_cast<float2 *>(we + 64) = make_float2(tw[4 * m + 1], tw[4 * m + 3]); }
           }
         }
         WAVE_SYNC();
@@ -1584,6 +1623,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // every history index i - D - q (i = 128..255, q < M) is inside [0, 256) iff D >= 0 and D + M <= 129: true for the
         // reference's defaults (M 55, D 3) and checked per wave
         const bool als_safe = __all(!als_en || (D >= 0 && D + M <= 129));
+        const int M_u = __builtin_amdgcn_readfirstlane(M);
+        const bool als_m_uniform = __all(als_en && adaptive && M == M_u);   // the usual case: one filter length in the wave
         if (__any(als_en && !adaptive)) {
           if (als_en && !adaptive) {
             for (int j = 0; j < 16; ++j) {
@@ -1600,11 +1641,21 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           for (int ep = -1; ep < 32; ++ep) {
             const int base = (ep < 0) ? 0 : 4 * ep + 1;
             const int cntn = (ep < 0) ? 1 : ((ep == 31) ? 3 : 4);
-            const int n = base + s8;
+            const int n = base + (s8 & 3);
             const bool mine = als_en && adaptive && (s8 < cntn);
-            if (mine) {
+            if (als_safe) {   // all eight lanes of the channel share the sum (als_dot_split); lanes 0-3 keep the results
+              const int i = 128 + n, h = s8 >> 2;
+              float y = 0.0f;
+              if (als_m_uniform) y = als_dot_split(L + ALS_W + 64 * h, L + ALS_X + (i - D - h), M_u, h);   // scalar loop count
+              else if (als_en && adaptive) y = als_dot_split(L + ALS_W + 64 * h, L + ALS_X + (i - D - h), M, h);
+              if (mine) {
+                const float e = L[ALS_X + i] - y;
+                L[ALS_OUT + n] = notch ? e : y;
+                if ((n & 3) == 0) L[SCR1] = e;
+              }
+            } else if (mine) {
               const int i = 128 + n;
-              const float y = als_safe ? als_dot<false>(L + ALS_W, L + ALS_X, i - D, M) : als_dot<true>(L + ALS_W, L + ALS_X, i - D, M);
+              const float y = als_dot<true>(L + ALS_W, L + ALS_X, i - D, M);
               const float e = L[ALS_X + i] - y;
               L[ALS_OUT + n] = notch ? e : y;
               if ((n & 3) == 0) L[SCR1] = e;
@@ -1614,11 +1665,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_en && adaptive && nu < ASDR_N) {
               const float e = L[SCR1];
               const int iu = 128 + nu;
-              if (als_safe) {
+              if (als_m_uniform && als_safe) {   // scalar trip count: every lane owns taps s8 + 8k for k < M / 8, some one more
+                const float *xq = L + ALS_X + iu - D - s8;
+                float *wq = L + ALS_W + ALS_TAP(s8);
+                const int nfull = M_u >> 3;
 #pragma unroll 2
-                for (int q = s8; q < M; q += 8) { const float gq = e * L[ALS_X + iu - D - q]; const float dq = lam * gq; L[ALS_W + q] += dq; }
+                for (int k = 0; k < nfull; ++k) { const float gq = e * xq[-8 * k]; const float dq = lam * gq; wq[4 * k] += dq; }
+                if (s8 + 8 * nfull < M_u) { const float gq = e * xq[-8 * nfull]; const float dq = lam * gq; wq[4 * nfull] += dq; }
+              } else if (als_safe) {
+#pragma unroll 2
+                for (int q = s8; q < M; q += 8) { const float gq = e * L[ALS_X + iu - D - q]; const float dq = lam * gq; L[ALS_W + ALS_TAP(q)] += dq; }
               } else {
-                for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[ALS_W + q] += dq; }
+                for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[ALS_W + ALS_TAP(q)] += dq; }
               }
             }
             WAVE_SYNC();
@@ -1627,7 +1685,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         WAVE_SYNC();
         if (als_en) {
 #pragma unroll 1
-          for (int m = 0; m < 4; ++m) { float t[4]; load4(L + ALS_W + kF + 32 * m, t); store4(gw + 32 * m, t); }
+          for (int m = 0; m < 4; ++m) {
+            const float *we = L + ALS_W + ((kF + 32 * m) >> 1);
+            const float2 e2 = *reinterpret_cast<const float2 *>(we), o2 = *reinterpret_cast<const float2 *>(we + 64);
+            const float t[4] = {e2.x, o2.x, e2.y, o2.y};
+            store4(gw + 32 * m, t);
+          }
         }
       }
     }
