@@ -167,6 +167,8 @@ typedef struct {
 #define ASDR_KERNEL_PLAIN 0
 #define ASDR_KERNEL_SAM 1
 #define ASDR_KERNEL_ALS 2
+#define ASDR_KERNEL_ALS_SMALL 3   /* ALS, not SAM, taps <= 64 and delay + taps <= 65: compact rows (asdr_kernels.hip, ALS section) */
+#define ASDR_KERNEL_KINDS 4
 #ifndef ASDR_SAM_WAVES
 #define ASDR_SAM_WAVES 4
 #endif   /* waves (x 8 channels) per workgroup of the SAM instantiation: one of them runs every channel's PLL */

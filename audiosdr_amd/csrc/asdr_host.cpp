@@ -117,6 +117,7 @@ float time_constant(float ms) {  // AudioSDR.cpp:448/553: exp(log(0.1) / (FS*ms/
 
 }  // namespace
 
+#define ASDR_AUX_STREAMS (2 * ASDR_KERNEL_KINDS - 1)   /* every sub-range but the first runs on a helper stream */
 struct asdr_batch {
   int n = 0, device = 0;
   hipStream_t stream = nullptr;  // used by the host-pointer entry point and by getters
@@ -138,8 +139,8 @@ struct asdr_batch {
   // to whole waves with the dummy channel: one SAM or ALS channel no longer demotes the whole batch.
   // Inside a sub-range the whole waves of each key group come first ("uniform" waves: 8 real channels, one key -> the
   // instantiation with scalar mode/flag tests), then the groups' remainders packed together ("mixed").
-  int kind_first[3] = {0, 0, 0}, kind_slots[3] = {0, 0, 0}, kind_uniform_slots[3] = {0, 0, 0};
-  bool kind_direct[3] = {false, false, false};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
+  int kind_first[ASDR_KERNEL_KINDS] = {0, 0, 0, 0}, kind_slots[ASDR_KERNEL_KINDS] = {0, 0, 0, 0}, kind_uniform_slots[ASDR_KERNEL_KINDS] = {0, 0, 0, 0};
+  bool kind_direct[ASDR_KERNEL_KINDS] = {false, false, false, false};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
   // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
   long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
   // device
@@ -167,8 +168,8 @@ struct asdr_batch {
   size_t tev_used = 0;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_last = nullptr;  // recorded after every launch: a call on another stream waits for it first
-  hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // helper streams for concurrent sub-range launches
-  hipEvent_t ev_fork = nullptr, ev_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t aux[ASDR_AUX_STREAMS] = {};   // helper streams for concurrent sub-range launches
+  hipEvent_t ev_fork = nullptr, ev_join[ASDR_AUX_STREAMS] = {};
   bool ev_last_valid = false;
   LoEntry *d_lo = nullptr;       // local-oscillator cache, 2 entries (asdr_device.h)
   // streaming pipeline (asdr_stream_kernel): exchange rings and progress counters, allocated at its first use
@@ -303,7 +304,12 @@ void fill_params(const Chan &c, ChanParams &p) {
 // so that a wave's 8 channels take the same branches.  Rows of I/Q/out and of every state array are per channel, so the
 // grouping costs nothing in coalescing.
 int kernel_kind(const ChanParams &p) {
-  return (p.flags & ASDR_F_ALS_EN) ? ASDR_KERNEL_ALS : ((p.mode == ASDR_SAMmode) ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN);
+  if (p.flags & ASDR_F_ALS_EN) {
+    // a short filter on a channel that needs no PLL fits the plain instantiation's LDS rows (12 instead of 9 waves per CU)
+    const bool small = p.mode != ASDR_SAMmode && p.als_m >= 0 && p.als_m <= 64 && p.als_delay >= 0 && p.als_delay + p.als_m <= 65;
+    return small ? ASDR_KERNEL_ALS_SMALL : ASDR_KERNEL_ALS;
+  }
+  return (p.mode == ASDR_SAMmode) ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN;
 }
 #ifndef ASDR_SAM_SPLIT_MIN_CHANNELS
 #define ASDR_SAM_SPLIT_MIN_CHANNELS 512
@@ -358,7 +364,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     for (int i = 0; i < b->n; i++) order[i] = {sched_key(b->hp[i]), i};
     std::sort(order.begin(), order.end());   // (key, channel): equal keys stay in channel order
     // per kernel kind: slots of the whole waves of every key group, and of the groups' remainders
-    int uni[3] = {0, 0, 0}, rem[3] = {0, 0, 0};
+    int uni[ASDR_KERNEL_KINDS] = {0, 0, 0, 0}, rem[ASDR_KERNEL_KINDS] = {0, 0, 0, 0};
     // SAM (no ALS) as three launches per block only when there are enough SAM channels to fill the PLL kernel's waves: a handful
     // of them is quicker through the fused kernel (one launch, no exchange round trips)
     int n_sam = 0;
@@ -375,13 +381,13 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       i = j;
     }
     int pos = 0;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
       b->kind_first[k] = pos; b->kind_uniform_slots[k] = uni[k]; b->kind_slots[k] = uni[k] + ((rem[k] + 7) / 8) * 8;
       pos += b->kind_slots[k];
     }
     b->sched.assign(pos, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});   // padding = the dummy channel
-    int at_u[3], at_m[3];
-    for (int k = 0; k < 3; k++) { at_u[k] = b->kind_first[k]; at_m[k] = b->kind_first[k] + uni[k]; }
+    int at_u[ASDR_KERNEL_KINDS], at_m[ASDR_KERNEL_KINDS];
+    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) { at_u[k] = b->kind_first[k]; at_m[k] = b->kind_first[k] + uni[k]; }
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
@@ -393,7 +399,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       }
       i = j;
     }
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
       const SlotInfo *sl = b->sched.data() + b->kind_first[k];
       bool direct = b->kind_uniform_slots[k] > 0;
       for (int j = 1; j < b->kind_uniform_slots[k] && direct; j++)
@@ -561,7 +567,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     if (ok && hipEventCreate(&b->rev1) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
-    for (int i = 0; i < 5 && ok; i++) {
+    for (int i = 0; i < ASDR_AUX_STREAMS && ok; i++) {
       if (hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking) != hipSuccess) ok = false;
       if (ok && hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess) ok = false;
     }
@@ -620,7 +626,7 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->rev1) hipEventDestroy(b->rev1);
   if (b->ev_last) hipEventDestroy(b->ev_last);
   if (b->ev_fork) hipEventDestroy(b->ev_fork);
-  for (int i = 0; i < 5; i++) { if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]); if (b->aux[i]) hipStreamDestroy(b->aux[i]); }
+  for (int i = 0; i < ASDR_AUX_STREAMS; i++) { if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]); if (b->aux[i]) hipStreamDestroy(b->aux[i]); }
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -658,13 +664,15 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   else if (b->time_calls) { e0 = b->ev0; e1 = b->ev1; }
-  // Up to six sub-ranges of the sorted schedule (3 kernel instantiations x {uniform, mixed waves}).  They touch disjoint channels,
+  // Up to eight sub-ranges of the sorted schedule (4 kernel instantiations x {uniform, mixed waves}).  They touch disjoint channels,
   // so they run CONCURRENTLY: the first on the caller's stream, the others on the batch's helper streams, forked behind an
   // event and joined before the call's end marker -- launched back to back on one stream the short ones (a handful of waves of
   // the slowest instantiation) would each add a whole wave lifetime to the step.  Heaviest instantiation first.
   struct Sub { int kind, uniform, first, slots; };
-  Sub subs[6]; int n_sub = 0;
-  for (int k = 2; k >= 0; k--) {
+  Sub subs[2 * ASDR_KERNEL_KINDS]; int n_sub = 0;
+  static const int heaviest_first[ASDR_KERNEL_KINDS] = {ASDR_KERNEL_ALS, ASDR_KERNEL_ALS_SMALL, ASDR_KERNEL_SAM, ASDR_KERNEL_PLAIN};
+  for (int kk = 0; kk < ASDR_KERNEL_KINDS; kk++) {
+    const int k = heaviest_first[kk];
     if (b->kind_slots[k] == 0) continue;
     const int nu = b->kind_uniform_slots[k], nm = b->kind_slots[k] - nu;
     if (nu > 0) subs[n_sub++] = Sub{k, 1, b->kind_first[k], nu};

@@ -46,11 +46,8 @@
 // AGC overlay
 #define AGC_GV 128   // per sample: the envelope value whose compressor gain applies (-1 = gain carried in)
 #define AGC_TAB 256  // this channel's gain table (row of 132 floats)
-// ALS overlay (516 variant only)
-#define ALS_X 128    // [0..255] previous + current block
-#define ALS_W 384    // [0..127] taps
-#define ALS_OUT W0   // in place: the input was copied to ALS_X first
-#define SCR1 513     // ALS error broadcast word
+// ALS overlay: from word 128 (the layout constants are in the body's ALS section: they depend on the row length)
+#define ALS_OUT W0   // in place: the input is copied to the overlay first
 
 #define PI_D 3.1415926535897932384626433832795 /* Arduino.h PI (double) */
 
@@ -342,18 +339,19 @@ __device__ __forceinline__ uint32_t mask_encode4(float4 mv) {
 }
 
 // ALS FIR (AudioSDR.cpp:331-335): y = sum_{q < M} w[q] * x[top - q], q ascending, every product and sum separately rounded.
-// The taps sit in LDS de-interleaved: even taps at w[0..63], odd taps at w[64..127] (ALS_TAP), so that the two halves of a
+// The taps sit in LDS de-interleaved: even taps at w[0..WH), odd taps at w[WH..2 WH) (ALS_TAP; WH = 64, or 32 in the compact
+// layout of the 388-float rows, see the ALS section of the body), so that the two halves of a
 // channel's eight lanes can each fetch four of "their" taps with one ds_read_b128 (als_dot_split below).
-#define ALS_TAP(q) ((((q) & 1) << 6) + ((q) >> 1))
+#define ALS_TAP(q, wh) ((((q) & 1) ? (wh) : 0) + ((q) >> 1))
 // CHECKED = false requires every index top - q (q < M) to lie inside the 256-sample history; CHECKED = true reads 0.0
 // outside it (DESIGN.md "defined differences").  One lane does the whole sum (static taps, or parameters outside the safe range).
-template <bool CHECKED>
+template <bool CHECKED, int WH>
 __device__ __forceinline__ float als_dot(const float *w, const float *x, int top, int M) {
   float y = 0.0f;
   int q = 0;
 #pragma unroll 2
   for (; q + 4 <= M; q += 4) {
-    const float2 we = *reinterpret_cast<const float2 *>(w + (q >> 1)), wo = *reinterpret_cast<const float2 *>(w + 64 + (q >> 1));
+    const float2 we = *reinterpret_cast<const float2 *>(w + (q >> 1)), wo = *reinterpret_cast<const float2 *>(w + WH + (q >> 1));
     const int t = top - q;
     float x0, x1, x2, x3;
     if (CHECKED) {
@@ -368,7 +366,7 @@ __device__ __forceinline__ float als_dot(const float *w, const float *x, int top
   for (; q < M; ++q) {
     const int t = top - q;
     const float xv = CHECKED ? ((t >= 0 && t < 256) ? x[t] : 0.0f) : x[t];
-    const float p = w[ALS_TAP(q)] * xv;
+    const float p = w[ALS_TAP(q, WH)] * xv;
     y += p;
   }
   return y;
@@ -384,7 +382,7 @@ __device__ __forceinline__ float dpp_row_shl4(float v) {
 // adds both products in tap order (its own, then the partner's through a DPP operand).  Same products, same additions, same
 // order -- half the multiplies and loads per lane.  The result is valid on lanes 0-3 only.  Taps past M contribute a +0.0
 // (the running sum starts at +0.0 and so is never -0.0: adding +0.0 leaves it unchanged); their operands are read but not used.
-// Requires the unchecked index range of als_dot<false>.  `h` = lane half (0 / 1), `xh` = x + top - h, `wh` = w + 64 h.
+// Requires the unchecked index range of als_dot<false>.  `h` = lane half (0 / 1), `xh` = x + top - h, `wh` = w + WH h.
 __device__ __forceinline__ float als_dot_split(const float *wh, const float *xh, int M, int h) {
   float y = 0.0f;
   int q = 0;
@@ -1598,39 +1596,60 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     TL(14);
     TAP_ROW(ASDR_TAP_AGC, W0);
 
-    // ---- ALS adaptive notch / peak filter, AudioSDR.cpp:324-352 (516-float instantiation only) -----------------
+    // ---- ALS adaptive notch / peak filter, AudioSDR.cpp:324-352 (ALS instantiations only) -------------------------
+    // LDS overlay from word 128 of the channel's row: [kept tail of the previous block | current block | even taps | odd taps | e].
+    //   516-float rows: 128 + 128 + 64 + 64 (any M <= 128, any delay)                      -> 9 waves per CU
+    //   388-float rows: 64 + 128 + 32 + 32 (M <= 64 and delay + M <= 65: the host's choice) -> 12 waves per CU: the filter is
+    //   a chain of dependent operations and its throughput follows the resident waves (profiles/README.md, occupancy experiment)
     if constexpr (HAS_ALS) {
+      constexpr bool COMPACT = (STRIDE == ASDR_STRIDE);
+      constexpr int AH = COMPACT ? 64 : 128;       // history kept from the previous block
+      constexpr int XB = 128 - (128 - AH);         // L[XB + idx] = sample idx of the reference's 256-sample buffer (idx >= 128 - AH)
+      constexpr int AW = XB + 256;                 // taps
+      constexpr int WH = AH / 2;                   // taps per half (ALS_TAP)
+      constexpr int SCR = AW + 2 * WH + 1;         // error broadcast word
+      constexpr int M0 = COMPACT ? 2 : 0;          // first 32-float piece of the previous block / number of tap pieces kept
+      constexpr int NW = COMPACT ? 2 : 4;
       if (ABL_ON(ABL_ALS) && __any(als_en)) {
         const int M = P.als_m, D = P.als_delay;
         const float lam = P.als_lambda;   // (requested once, not in every tap-update epoch)
         const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
         float *gx = a.als_x + (size_t)ch * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
         if (als_en) {
-          float tx[16], tw[16], tn[16];   // all eight row loads in flight together
-#pragma unroll
-          for (int m = 0; m < 4; ++m) { load4(gx + 32 * m, tx + 4 * m); load4(gw + 32 * m, tw + 4 * m); load4(L + W0 + kF + 32 * m, tn + 4 * m); }
+          float tx[16], tw[16], tn[16];   // all row loads in flight together
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            store4(L + ALS_X + kF + 32 * m, tx + 4 * m);            // previous block
-            store4(L + ALS_X + 128 + kF + 32 * m, tn + 4 * m); store4(gx + 32 * m, tn + 4 * m);
-            { float *we = L + ALS_W + ((kF + 32 * m) >> 1);   // taps de-interleaved (ALS_TAP)
+            if (m >= M0) load4(gx + 32 * m, tx + 4 * m);
+            if (m < NW) load4(gw + 32 * m, tw + 4 * m);
+            load4(L + W0 + kF + 32 * m, tn + 4 * m);
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            if (m >= M0) store4(L + XB + kF + 32 * m, tx + 4 * m);            // previous block
+            store4(L + XB + 128 + kF + 32 * m, tn + 4 * m); store4(gx + 32 * m, tn + 4 * m);
+            if (m < NW) {
+              float *we = L + AW + ((kF + 32 * m) >> 1);   // taps de-interleaved (ALS_TAP)
               *reinterpret_cast<float2 *>(we) = make_float2(tw[4 * m], tw[4 * m + 2]);
-              *reinterpret_cast<float2 *>(we + 64) = make_float2(tw[4 * m + 1], tw[4 * m + 3]); }
+              *reinterpret_cast<float2 *>(we + WH) = make_float2(tw[4 * m + 1], tw[4 * m + 3]);
+            }
           }
         }
         WAVE_SYNC();
-#define ALS_HIST(idx) (((idx) >= 0 && (idx) < 256) ? L[ALS_X + (idx)] : 0.0f)
-        // every history index i - D - q (i = 128..255, q < M) is inside [0, 256) iff D >= 0 and D + M <= 129: true for the
-        // reference's defaults (M 55, D 3) and checked per wave
-        const bool als_safe = __all(!als_en || (D >= 0 && D + M <= 129));
+#define ALS_HIST(idx) (((idx) >= 0 && (idx) < 256) ? L[XB + (idx)] : 0.0f)
+        // every history index i - D - q (i = 128..255, q < M) is inside the kept window iff D >= 0 and D + M <= AH + 1: true for
+        // the reference's defaults (M 55, D 3) and checked per wave.  (The host sends a channel to a compact instantiation only
+        // if it is: the checked forms are compiled for the 516-float rows alone.)
+        const bool als_safe = COMPACT || __all(!als_en || (D >= 0 && D + M <= AH + 1));
         const int M_u = __builtin_amdgcn_readfirstlane(M);
         const bool als_m_uniform = __all(als_en && adaptive && M == M_u);   // the usual case: one filter length in the wave
         if (__any(als_en && !adaptive)) {
           if (als_en && !adaptive) {
             for (int j = 0; j < 16; ++j) {
               const int i = 128 + k0 + j;
-              const float y = als_safe ? als_dot<false>(L + ALS_W, L + ALS_X, i - D, M) : als_dot<true>(L + ALS_W, L + ALS_X, i - D, M);
-              const float e = L[ALS_X + i] - y;
+              float y;
+              if constexpr (COMPACT) y = als_dot<false, WH>(L + AW, L + XB, i - D, M);
+              else y = als_safe ? als_dot<false, WH>(L + AW, L + XB, i - D, M) : als_dot<true, WH>(L + AW, L + XB, i - D, M);
+              const float e = L[XB + i] - y;
               L[ALS_OUT + k0 + j] = notch ? e : y;
             }
           }
@@ -1646,37 +1665,41 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_safe) {   // all eight lanes of the channel share the sum (als_dot_split); lanes 0-3 keep the results
               const int i = 128 + n, h = s8 >> 2;
               float y = 0.0f;
-              if (als_m_uniform) y = als_dot_split(L + ALS_W + 64 * h, L + ALS_X + (i - D - h), M_u, h);   // scalar loop count
-              else if (als_en && adaptive) y = als_dot_split(L + ALS_W + 64 * h, L + ALS_X + (i - D - h), M, h);
+              if (als_m_uniform) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
+              else if (als_en && adaptive) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M, h);
               if (mine) {
-                const float e = L[ALS_X + i] - y;
+                const float e = L[XB + i] - y;
                 L[ALS_OUT + n] = notch ? e : y;
-                if ((n & 3) == 0) L[SCR1] = e;
+                if ((n & 3) == 0) L[SCR] = e;
               }
             } else if (mine) {
-              const int i = 128 + n;
-              const float y = als_dot<true>(L + ALS_W, L + ALS_X, i - D, M);
-              const float e = L[ALS_X + i] - y;
-              L[ALS_OUT + n] = notch ? e : y;
-              if ((n & 3) == 0) L[SCR1] = e;
+              if constexpr (!COMPACT) {
+                const int i = 128 + n;
+                const float y = als_dot<true, WH>(L + AW, L + XB, i - D, M);
+                const float e = L[XB + i] - y;
+                L[ALS_OUT + n] = notch ? e : y;
+                if ((n & 3) == 0) L[SCR] = e;
+              }
             }
             WAVE_SYNC();
             const int nu = (ep < 0) ? 0 : 4 * ep + 4;   // the updating sample of this epoch
             if (als_en && adaptive && nu < ASDR_N) {
-              const float e = L[SCR1];
+              const float e = L[SCR];
               const int iu = 128 + nu;
               if (als_m_uniform && als_safe) {   // scalar trip count: every lane owns taps s8 + 8k for k < M / 8, some one more
-                const float *xq = L + ALS_X + iu - D - s8;
-                float *wq = L + ALS_W + ALS_TAP(s8);
+                const float *xq = L + XB + iu - D - s8;
+                float *wq = L + AW + ALS_TAP(s8, WH);
                 const int nfull = M_u >> 3;
 #pragma unroll 2
                 for (int k = 0; k < nfull; ++k) { const float gq = e * xq[-8 * k]; const float dq = lam * gq; wq[4 * k] += dq; }
                 if (s8 + 8 * nfull < M_u) { const float gq = e * xq[-8 * nfull]; const float dq = lam * gq; wq[4 * nfull] += dq; }
               } else if (als_safe) {
 #pragma unroll 2
-                for (int q = s8; q < M; q += 8) { const float gq = e * L[ALS_X + iu - D - q]; const float dq = lam * gq; L[ALS_W + ALS_TAP(q)] += dq; }
+                for (int q = s8; q < M; q += 8) { const float gq = e * L[XB + iu - D - q]; const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
               } else {
-                for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[ALS_W + ALS_TAP(q)] += dq; }
+                if constexpr (!COMPACT) {
+                  for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
+                }
               }
             }
             WAVE_SYNC();
@@ -1685,9 +1708,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         WAVE_SYNC();
         if (als_en) {
 #pragma unroll 1
-          for (int m = 0; m < 4; ++m) {
-            const float *we = L + ALS_W + ((kF + 32 * m) >> 1);
-            const float2 e2 = *reinterpret_cast<const float2 *>(we), o2 = *reinterpret_cast<const float2 *>(we + 64);
+          for (int m = 0; m < NW; ++m) {
+            const float *we = L + AW + ((kF + 32 * m) >> 1);
+            const float2 e2 = *reinterpret_cast<const float2 *>(we), o2 = *reinterpret_cast<const float2 *>(we + WH);
             const float t[4] = {e2.x, o2.x, e2.y, o2.y};
             store4(gw + 32 * m, t);
           }
@@ -1774,8 +1797,15 @@ ASDR_KERNEL(asdr_update_kernel_sam, ASDR_SAM_WAVES * 8 * ASDR_STRIDE + 260, ASDR
 #ifndef ASDR_ALS_WAVES_PER_EU
 #define ASDR_ALS_WAVES_PER_EU 3   /* LDS allows 9 waves/CU: needs 3 on one SIMD */
 #endif
-ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, true, 1)
-ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
+#ifndef ASDR_ALS_LDS_PAD
+#define ASDR_ALS_LDS_PAD 0        /* occupancy experiments only: extra floats of LDS per wave (tools/ablate.py) */
+#endif
+ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260 + ASDR_ALS_LDS_PAD, ASDR_ALS_WAVES_PER_EU, 516, true, true, true, 1)
+ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260 + ASDR_ALS_LDS_PAD, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
+// ALS with a short filter (taps <= 64, delay + taps <= 65: the reference's defaults are 55 and 3) on a channel that is not in SAM
+// mode: the filter's rows fit the plain instantiation's 388 floats per channel -> 12 waves per CU
+ASDR_KERNEL(asdr_update_kernel_als_small, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, true, false, true, 1)
+ASDR_KERNEL(asdr_update_kernel_als_small_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, true, false, false, 1)
 
 // SAM sub-range as three launches (asdr_launch_update): pre | PLL | post
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre_kernel(UpdateArgs a) {
@@ -1932,11 +1962,12 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
   }
 }
 
-// `variant`: ASDR_KERNEL_PLAIN / _SAM / _ALS; `uniform`: every wave of the sub-range holds 8 real channels with one schedule key
+// `variant`: ASDR_KERNEL_PLAIN / _SAM / _ALS / _ALS_SMALL; `uniform`: every wave of the sub-range holds 8 real channels with one schedule key
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
   if (variant == ASDR_KERNEL_ALS) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if (variant == ASDR_KERNEL_SAM && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
     if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
