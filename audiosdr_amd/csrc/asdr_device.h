@@ -168,7 +168,9 @@ typedef struct {
 #define ASDR_KERNEL_SAM 1
 #define ASDR_KERNEL_ALS 2
 #define ASDR_KERNEL_ALS_SMALL 3   /* ALS, not SAM, taps <= 64 and delay + taps <= 65: compact rows (asdr_kernels.hip, ALS section) */
-#define ASDR_KERNEL_KINDS 4
+#define ASDR_KERNEL_SAM_ALS 4     /* SAM mode + such a short ALS filter: pre | PLL | post launches like _SAM (post with the filter) when the batch
+                                     runs its SAM channels that way, the _ALS instantiation otherwise */
+#define ASDR_KERNEL_KINDS 5
 #ifndef ASDR_SAM_WAVES
 #define ASDR_SAM_WAVES 4
 #endif   /* waves (x 8 channels) per workgroup of the SAM instantiation: one of them runs every channel's PLL */

@@ -139,8 +139,8 @@ struct asdr_batch {
   // to whole waves with the dummy channel: one SAM or ALS channel no longer demotes the whole batch.
   // Inside a sub-range the whole waves of each key group come first ("uniform" waves: 8 real channels, one key -> the
   // instantiation with scalar mode/flag tests), then the groups' remainders packed together ("mixed").
-  int kind_first[ASDR_KERNEL_KINDS] = {0, 0, 0, 0}, kind_slots[ASDR_KERNEL_KINDS] = {0, 0, 0, 0}, kind_uniform_slots[ASDR_KERNEL_KINDS] = {0, 0, 0, 0};
-  bool kind_direct[ASDR_KERNEL_KINDS] = {false, false, false, false};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
+  int kind_first[ASDR_KERNEL_KINDS] = {}, kind_slots[ASDR_KERNEL_KINDS] = {}, kind_uniform_slots[ASDR_KERNEL_KINDS] = {};
+  bool kind_direct[ASDR_KERNEL_KINDS] = {};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
   // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
   long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
   // device
@@ -306,8 +306,8 @@ void fill_params(const Chan &c, ChanParams &p) {
 int kernel_kind(const ChanParams &p) {
   if (p.flags & ASDR_F_ALS_EN) {
     // a short filter on a channel that needs no PLL fits the plain instantiation's LDS rows (12 instead of 9 waves per CU)
-    const bool small = p.mode != ASDR_SAMmode && p.als_m >= 0 && p.als_m <= 64 && p.als_delay >= 0 && p.als_delay + p.als_m <= 65;
-    return small ? ASDR_KERNEL_ALS_SMALL : ASDR_KERNEL_ALS;
+    const bool small = p.als_m >= 0 && p.als_m <= 64 && p.als_delay >= 0 && p.als_delay + p.als_m <= 65;
+    return !small ? ASDR_KERNEL_ALS : (p.mode == ASDR_SAMmode ? ASDR_KERNEL_SAM_ALS : ASDR_KERNEL_ALS_SMALL);
   }
   return (p.mode == ASDR_SAMmode) ? ASDR_KERNEL_SAM : ASDR_KERNEL_PLAIN;
 }
@@ -364,11 +364,11 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     for (int i = 0; i < b->n; i++) order[i] = {sched_key(b->hp[i]), i};
     std::sort(order.begin(), order.end());   // (key, channel): equal keys stay in channel order
     // per kernel kind: slots of the whole waves of every key group, and of the groups' remainders
-    int uni[ASDR_KERNEL_KINDS] = {0, 0, 0, 0}, rem[ASDR_KERNEL_KINDS] = {0, 0, 0, 0};
+    int uni[ASDR_KERNEL_KINDS] = {}, rem[ASDR_KERNEL_KINDS] = {};
     // SAM (no ALS) as three launches per block only when there are enough SAM channels to fill the PLL kernel's waves: a handful
     // of them is quicker through the fused kernel (one launch, no exchange round trips)
     int n_sam = 0;
-    for (int i = 0; i < b->n; i++) n_sam += ((int)(order[i].first >> 60) == ASDR_KERNEL_SAM);
+    for (int i = 0; i < b->n; i++) { const int k = (int)(order[i].first >> 60); n_sam += (k == ASDR_KERNEL_SAM || k == ASDR_KERNEL_SAM_ALS); }
     static const int sam_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;   // (tests: 1)
     b->sam_split = !sam_fused_env() && n_sam >= sam_min;
     const bool sam_general_only = !b->sam_split;
@@ -664,13 +664,13 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   else if (b->time_calls) { e0 = b->ev0; e1 = b->ev1; }
-  // Up to eight sub-ranges of the sorted schedule (4 kernel instantiations x {uniform, mixed waves}).  They touch disjoint channels,
+  // Up to ten sub-ranges of the sorted schedule (5 kernel kinds x {uniform, mixed waves}).  They touch disjoint channels,
   // so they run CONCURRENTLY: the first on the caller's stream, the others on the batch's helper streams, forked behind an
   // event and joined before the call's end marker -- launched back to back on one stream the short ones (a handful of waves of
   // the slowest instantiation) would each add a whole wave lifetime to the step.  Heaviest instantiation first.
   struct Sub { int kind, uniform, first, slots; };
   Sub subs[2 * ASDR_KERNEL_KINDS]; int n_sub = 0;
-  static const int heaviest_first[ASDR_KERNEL_KINDS] = {ASDR_KERNEL_ALS, ASDR_KERNEL_ALS_SMALL, ASDR_KERNEL_SAM, ASDR_KERNEL_PLAIN};
+  static const int heaviest_first[ASDR_KERNEL_KINDS] = {ASDR_KERNEL_ALS, ASDR_KERNEL_SAM_ALS, ASDR_KERNEL_ALS_SMALL, ASDR_KERNEL_SAM, ASDR_KERNEL_PLAIN};
   for (int kk = 0; kk < ASDR_KERNEL_KINDS; kk++) {
     const int k = heaviest_first[kk];
     if (b->kind_slots[k] == 0) continue;
@@ -687,11 +687,12 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // SAM channels (no ALS) run as three launches per block -- everything in front of the PLL | the PLL with one LANE per channel |
   // everything behind it -- through a 1 KB-per-slot exchange buffer: as a phase of one fused kernel the PLL's 128-step dependent
   // chain kept a workgroup's other waves waiting (ASDR_SAM_FUSED=1 selects that kernel, for comparison).
-  const bool sam_split = b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] > 0;
-  if (sam_split && (size_t)b->kind_slots[ASDR_KERNEL_SAM] > b->xch_sam_slots) {
+  const int sam_slots = b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS];
+  const bool sam_split = b->sam_split && sam_slots > 0;
+  if (sam_split && (size_t)sam_slots > b->xch_sam_slots) {
     HIPCHK(hipStreamSynchronize(stream));
     if (b->d_xch_sam) HIPCHK(hipFree(b->d_xch_sam));
-    b->xch_sam_slots = (size_t)b->kind_slots[ASDR_KERNEL_SAM];
+    b->xch_sam_slots = (size_t)sam_slots;
     HIPCHK(hipMalloc(&b->d_xch_sam, b->xch_sam_slots * 2 * ASDR_N * sizeof(float)));
   }
   a.xch_sam = sam_split ? b->d_xch_sam : nullptr;
@@ -750,6 +751,8 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
       a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM)   // this sub-range's tiles (1 KB per slot, 8 slots per tile)
         a.xch_sam = b->d_xch_sam + (size_t)(subs[i].first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
+      if (sam_split && subs[i].kind == ASDR_KERNEL_SAM_ALS)   // ... behind those of the SAM kind
+        a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + subs[i].first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
       if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
       if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }
     }
@@ -1101,7 +1104,8 @@ int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
   b->agc_pool_dirty = false;
   if (stats) {
     stats[0] = b->stat_rows_refilled; stats[1] = rebuilt ? 1 : 0;
-    stats[2] = (long long)(b->kind_slots[0] / 8) | ((long long)(b->kind_slots[1] / 8) << 21) | ((long long)(b->kind_slots[2] / 8) << 42);
+    stats[2] = (long long)(b->kind_slots[ASDR_KERNEL_PLAIN] / 8) | ((long long)(b->kind_slots[ASDR_KERNEL_SAM] / 8) << 21) |
+               ((long long)((b->kind_slots[ASDR_KERNEL_ALS] + b->kind_slots[ASDR_KERNEL_ALS_SMALL] + b->kind_slots[ASDR_KERNEL_SAM_ALS]) / 8) << 42);
     long long live = 0;
     for (uint32_t r : b->agc_refs) live += (r != 0);
     stats[3] = live;

@@ -383,25 +383,58 @@ __device__ __forceinline__ float dpp_row_shl4(float v) {
 // order -- half the multiplies and loads per lane.  The result is valid on lanes 0-3 only.  Taps past M contribute a +0.0
 // (the running sum starts at +0.0 and so is never -0.0: adding +0.0 leaves it unchanged); their operands are read but not used.
 // Requires the unchecked index range of als_dot<false>.  `h` = lane half (0 / 1), `xh` = x + top - h, `wh` = w + WH h.
+struct AlsGroup { float4 w; float x0, x1, x2, x3; };   // one half's operands of a group of eight taps
+__device__ __forceinline__ void als_group_load(AlsGroup &G, const float *wh, const float *xh, int g) {
+  G.w = *reinterpret_cast<const float4 *>(wh + 4 * g);
+  G.x0 = xh[-8 * g]; G.x1 = xh[-8 * g - 2]; G.x2 = xh[-8 * g - 4]; G.x3 = xh[-8 * g - 6];
+}
+__device__ __forceinline__ float als_group_sum(float y, const AlsGroup &G) {
+  const float p0 = G.w.x * G.x0, p1 = G.w.y * G.x1, p2 = G.w.z * G.x2, p3 = G.w.w * G.x3;
+  y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
+  y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
+  return y;
+}
+__device__ __forceinline__ float als_group_sum_tail(float y, const AlsGroup &G, int rem) {   // this half's taps exist for 2t < rem
+  float p0 = G.w.x * G.x0, p1 = G.w.y * G.x1, p2 = G.w.z * G.x2, p3 = G.w.w * G.x3;
+  p0 = (0 < rem) ? p0 : 0.0f; p1 = (2 < rem) ? p1 : 0.0f; p2 = (4 < rem) ? p2 : 0.0f; p3 = (6 < rem) ? p3 : 0.0f;
+  y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
+  y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
+  return y;
+}
+// M per lane (channels of different filter lengths in one wave): a divergent loop, one group at a time
 __device__ __forceinline__ float als_dot_split(const float *wh, const float *xh, int M, int h) {
   float y = 0.0f;
-  int q = 0;
-#pragma unroll 2
-  for (; q + 8 <= M; q += 8) {
-    const float4 w4 = *reinterpret_cast<const float4 *>(wh + (q >> 1));
-    const float x0 = xh[-q], x1 = xh[-q - 2], x2 = xh[-q - 4], x3 = xh[-q - 6];
-    const float p0 = w4.x * x0, p1 = w4.y * x1, p2 = w4.z * x2, p3 = w4.w * x3;
-    y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
-    y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
+  const int n_full = M >> 3;
+  AlsGroup A;
+  for (int g = 0; g < n_full; ++g) { als_group_load(A, wh, xh, g); y = als_group_sum(y, A); }
+  if (M & 7) { als_group_load(A, wh, xh, n_full); y = als_group_sum_tail(y, A, (M & 7) - h); }
+  return y;
+}
+// M the same in the whole wave (a scalar): software-pipelined over two operand sets -- group g + 1's operands are requested
+// before group g's sums, so the LDS round trip is off the chain of dependent additions.  The request past the last group reads
+// inside the row and is dropped.
+__device__ __forceinline__ float als_dot_split_uniform(const float *wh, const float *xh, int M, int h) {
+  float y = 0.0f;
+  const int n_full = M >> 3, rem = (M & 7) - h;
+  AlsGroup A, B;
+  als_group_load(A, wh, xh, 0);
+  int g = 0;
+#pragma unroll 1
+  for (; g + 2 <= n_full; g += 2) {
+    als_group_load(B, wh, xh, g + 1);
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the requests below the sums to reuse their registers)
+    y = als_group_sum(y, A);
+    als_group_load(A, wh, xh, g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    y = als_group_sum(y, B);
   }
-  if (q < M) {
-    const int rem = M - q - h;   // this half's taps q + 2t + h exist for 2t < rem
-    const float4 w4 = *reinterpret_cast<const float4 *>(wh + (q >> 1));
-    const float x0 = xh[-q], x1 = xh[-q - 2], x2 = xh[-q - 4], x3 = xh[-q - 6];
-    float p0 = w4.x * x0, p1 = w4.y * x1, p2 = w4.z * x2, p3 = w4.w * x3;
-    p0 = (0 < rem) ? p0 : 0.0f; p1 = (2 < rem) ? p1 : 0.0f; p2 = (4 < rem) ? p2 : 0.0f; p3 = (6 < rem) ? p3 : 0.0f;
-    y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
-    y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
+  if (g < n_full) {
+    als_group_load(B, wh, xh, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    y = als_group_sum(y, A);
+    if (M & 7) y = als_group_sum_tail(y, B, rem);
+  } else if (M & 7) {
+    y = als_group_sum_tail(y, A, rem);
   }
   return y;
 }
@@ -1665,7 +1698,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_safe) {   // all eight lanes of the channel share the sum (als_dot_split); lanes 0-3 keep the results
               const int i = 128 + n, h = s8 >> 2;
               float y = 0.0f;
-              if (als_m_uniform) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
+              if (als_m_uniform) y = als_dot_split_uniform(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
               else if (als_en && adaptive) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M, h);
               if (mine) {
                 const float e = L[XB + i] - y;
@@ -1686,13 +1719,23 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_en && adaptive && nu < ASDR_N) {
               const float e = L[SCR];
               const int iu = 128 + nu;
-              if (als_m_uniform && als_safe) {   // scalar trip count: every lane owns taps s8 + 8k for k < M / 8, some one more
+              if (als_m_uniform && als_safe) {
+                // lane s8 owns taps s8 + 8k (k < nk).  Eight of them per step, all operands requested together and all results
+                // written together: one LDS round trip per step instead of one per tap.  Steps run to a multiple of 8 taps per
+                // lane: the surplus ones (still inside the tap rows: M <= 64 -> k <= 7, M <= 128 -> k <= 15) are written back unchanged.
                 const float *xq = L + XB + iu - D - s8;
                 float *wq = L + AW + ALS_TAP(s8, WH);
-                const int nfull = M_u >> 3;
-#pragma unroll 2
-                for (int k = 0; k < nfull; ++k) { const float gq = e * xq[-8 * k]; const float dq = lam * gq; wq[4 * k] += dq; }
-                if (s8 + 8 * nfull < M_u) { const float gq = e * xq[-8 * nfull]; const float dq = lam * gq; wq[4 * nfull] += dq; }
+                const int nk = (M_u - s8 + 7) >> 3, nk_max = (M_u + 7) >> 3;
+#pragma unroll 1
+                for (int k0 = 0; k0 < nk_max; k0 += 8) {
+                  float xv[8], wv[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) { xv[j] = xq[-8 * (k0 + j)]; wv[j] = wq[4 * (k0 + j)]; }
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) { const float gq = e * xv[j]; const float dq = lam * gq; const float wn = wv[j] + dq; wv[j] = (k0 + j < nk) ? wn : wv[j]; }
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) wq[4 * (k0 + j)] = wv[j];
+                }
               } else if (als_safe) {
 #pragma unroll 2
                 for (int q = s8; q < M; q += 8) { const float gq = e * L[XB + iu - D - q]; const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
@@ -1824,6 +1867,15 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_kernel_uniform(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 5>(a, lds);
+}
+// ... and for SAM channels with a short ALS filter (ASDR_KERNEL_SAM_ALS): the filter is the post role's last stage, on the compact rows
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_als_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, true, false, false, 1, 5>(a, lds);
+}
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_als_kernel_uniform(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, true, false, true, 1, 5>(a, lds);
 }
 // One LANE per channel: lane l of workgroup w runs the PLL of schedule slot 64 w + l on the rows the pre kernel left in its tile.
 extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs a) {
@@ -1962,18 +2014,23 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
   }
 }
 
-// `variant`: ASDR_KERNEL_PLAIN / _SAM / _ALS / _ALS_SMALL; `uniform`: every wave of the sub-range holds 8 real channels with one schedule key
+// `variant`: ASDR_KERNEL_PLAIN / _SAM / _ALS / _ALS_SMALL / _SAM_ALS; `uniform`: every wave of the sub-range holds 8 real channels with one schedule key
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (variant == ASDR_KERNEL_ALS) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  if (variant == ASDR_KERNEL_ALS || (variant == ASDR_KERNEL_SAM_ALS && a->xch_sam == nullptr)) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
-  else if (variant == ASDR_KERNEL_SAM && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
+  else if ((variant == ASDR_KERNEL_SAM || variant == ASDR_KERNEL_SAM_ALS) && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
     if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + 63) / 64), dim3(64), 0, stream, *a);
-    if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (variant == ASDR_KERNEL_SAM_ALS) {
+      if (uniform) hipLaunchKernelGGL(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+      else hipLaunchKernelGGL(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    } else {
+      if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+      else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    }
   }
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }

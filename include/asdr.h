@@ -196,7 +196,7 @@ int asdr_kernel_timing_end(asdr_batch_t *b, float *ms, int cap);
  * tables) changed.  asdr_control_plane_flush() runs the HOST half of that step on a control-plane-only batch (ASDR_NO_DEVICE;
  * refused on a device batch, where the next update() does it) and reports what it did:
  *   stats[0] = parameter rows refilled, stats[1] = 1 if the schedule was rebuilt, stats[2] = waves in the plain / SAM / ALS
- *   sub-ranges packed as plain | sam << 21 | als << 42, stats[3] = AGC gain tables alive in the pool. */
+ *   sub-ranges (ALS: the three kinds with the filter enabled together) packed as plain | sam << 21 | als << 42, stats[3] = AGC gain tables alive in the pool. */
 int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]);
 /* The derived constants the hot path runs with, as the host evaluated them from the reference's in-class initialisers and
  * setters (AudioSDR.h:238-239, 249-284; AudioSDR.cpp:447, 563-566) -- exposed so that an independent restatement of that

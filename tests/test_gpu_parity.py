@@ -439,3 +439,53 @@ print("ok")
     env = dict(os.environ, ASDR_SAM_SPLIT_MIN="1", ASDR_NO_STREAM_PIPELINE="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_als_kernel_kinds(gpu, ao):
+    """The ALS filter runs in one of three kernel kinds (asdr_host.cpp kernel_kind): short tap sets (taps <= 64, delay + taps <= 65)
+    on the compact 388-float rows, SAM channels with such a filter through the pre | PLL | post launches (>= 512 SAM channels in
+    the batch), everything else on the 516-float rows.  One batch with all of them, filter lengths at the limits of the compact
+    layout, notch / peak, adaptive / static, a 3-block call (one launch per block with the SAM launches) -- every variety vs the oracle,
+    and the tap rows in HBM keep their natural order (a parameter change moves a channel between kinds mid-stream)."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, T = 1400, 3
+    I, Q = make_iq(n_ch, 3 * T, fc=6890.0 + (np.arange(n_ch) % 9 - 4) * 35.0, A=0.3, m=0.4, f2=7600.0, a2=0.12, noise=0.01)
+    variety = [  # (mode, (M, lambda, delay) or None, peak, static)
+        (5, None, False, False), (5, (64, 0.5, 1), False, False), (5, (65, 0.5, 0), False, False), (5, (100, 0.25, 7), True, False),
+        (1, None, False, False), (1, (64, 0.5, 1), True, False), (1, (61, 0.3, 4), False, True), (1, (62, 0.5, 4), False, False),
+        (4, (8, 0.5, 0), False, False), (0, (7, 0.5, 58), False, False), (6, (1, 0.5, 64), False, False), (2, (0, 0.5, 3), False, False),
+        (5, (55, 0.5, 3), False, True), (3, (128, 0.05, 1), False, False),
+    ]
+    def configure(s, v, ch=None):
+        kw = {} if ch is None else {"ch": ch}
+        mode, par, peak, static = v
+        s.setDemodMode(mode, **kw); s.setNoiseBlankerThresholdDb(10.0, **kw); s.enableALSfilter(**kw)
+        if par is not None: s.setALSfilterParams(*par, **kw)
+        if peak: s.setALSfilterPeak(**kw)
+        if static: s.setALSfilterStatic(**kw)
+    b = gpu.AudioSDRBatch(n_ch)
+    b.setDemodMode(5); b.setNoiseBlankerThresholdDb(10.0); b.enableALSfilter()      # 1400 SAM + ALS channels: the three-launch path
+    kind_of = {}
+    for c in range(0, n_ch, 3):                                                     # every third channel: one of the varieties
+        kind_of[c] = variety[(c // 3) % len(variety)]
+        configure(b, kind_of[c], ch=c)
+    got = [b.update(I[:, :T], Q[:, :T])]
+    # mid-stream: a compact-layout channel gets a long filter (moves to the 516-float rows with its taps), and back
+    b.setALSfilterParams(90, 0.5, 3, ch=1); got.append(b.update(I[:, T:2 * T], Q[:, T:2 * T]))
+    b.setALSfilterParams(40, 0.5, 3, ch=1); got.append(b.update(I[:, 2 * T:], Q[:, 2 * T:]))
+    got = np.concatenate(got, axis=1)
+    checked = set()
+    for c in list(range(0, 3 * len(variety) * 2, 3)) + [1, 2, n_ch - 1, n_ch - 2]:
+        o = ao.OracleSDR()
+        if c in kind_of: configure(o, kind_of[c])
+        else: o.setDemodMode(5); o.setNoiseBlankerThresholdDb(10.0); o.enableALSfilter()
+        if c == 1:
+            w = [o.update(I[c, :T], Q[c, :T])]; o.setALSfilterParams(90, 0.5, 3)
+            w.append(o.update(I[c, T:2 * T], Q[c, T:2 * T])); o.setALSfilterParams(40, 0.5, 3); w.append(o.update(I[c, 2 * T:], Q[c, 2 * T:]))
+            want = np.concatenate(w)
+        else:
+            want = o.update(I[c], Q[c])
+        assert np.array_equal(got[c].reshape(-1), want.reshape(-1)), (c, kind_of.get(c))
+        checked.add(kind_of.get(c))
+    assert len(checked) == len(variety) + 1
+    b.close()
