@@ -117,7 +117,7 @@ float time_constant(float ms) {  // AudioSDR.cpp:448/553: exp(log(0.1) / (FS*ms/
 
 }  // namespace
 
-#define ASDR_AUX_STREAMS (2 * ASDR_KERNEL_KINDS - 1)   /* every sub-range but the first runs on a helper stream */
+#define ASDR_AUX_STREAMS (ASDR_KERNEL_KINDS + 1)   /* every sub-range but the first runs on a helper stream */
 struct asdr_batch {
   int n = 0, device = 0;
   hipStream_t stream = nullptr;  // used by the host-pointer entry point and by getters
@@ -140,6 +140,7 @@ struct asdr_batch {
   // Inside a sub-range the whole waves of each key group come first ("uniform" waves: 8 real channels, one key -> the
   // instantiation with scalar mode/flag tests), then the groups' remainders packed together ("mixed").
   int kind_first[ASDR_KERNEL_KINDS] = {}, kind_slots[ASDR_KERNEL_KINDS] = {}, kind_uniform_slots[ASDR_KERNEL_KINDS] = {};
+  int left_first = 0, left_slots = 0, left_kind = ASDR_KERNEL_PLAIN;   // the key groups' remainders of all kinds: one sub-range, one launch
   bool kind_direct[ASDR_KERNEL_KINDS] = {};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
   // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
   long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
@@ -372,12 +373,16 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     static const int sam_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;   // (tests: 1)
     b->sam_split = !sam_fused_env() && n_sam >= sam_min;
     const bool sam_general_only = !b->sam_split;
+    // The remainders (< 8 channels) of all key groups share ONE sub-range behind the kinds' whole waves, run by one launch of a
+    // general instantiation: as a launch per kind they were up to five more streams of a handful of long-lived waves each, and
+    // streams that share a hardware queue run one after the other (profiles/README.md: C4's last 80 us were four such waves).
+    int left = 0; bool left_general = false;
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
       const int k = (int)(order[i].first >> 60), g = j - i;
       if (k == ASDR_KERNEL_SAM && sam_general_only) rem[k] += g;   // the fused SAM instantiation has only the general form (4-wave workgroups)
-      else { uni[k] += g / 8 * 8; rem[k] += g % 8; }
+      else { uni[k] += g / 8 * 8; left += g % 8; if (g % 8) left_general = left_general || (k != ASDR_KERNEL_PLAIN); }
       i = j;
     }
     int pos = 0;
@@ -385,16 +390,20 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       b->kind_first[k] = pos; b->kind_uniform_slots[k] = uni[k]; b->kind_slots[k] = uni[k] + ((rem[k] + 7) / 8) * 8;
       pos += b->kind_slots[k];
     }
+    b->left_first = pos; b->left_slots = (left + 7) / 8 * 8; b->left_kind = left_general ? ASDR_KERNEL_ALS : ASDR_KERNEL_PLAIN;
+    pos += b->left_slots;
     b->sched.assign(pos, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});   // padding = the dummy channel
-    int at_u[ASDR_KERNEL_KINDS], at_m[ASDR_KERNEL_KINDS];
+    int at_u[ASDR_KERNEL_KINDS], at_m[ASDR_KERNEL_KINDS], at_left = b->left_first;
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) { at_u[k] = b->kind_first[k]; at_m[k] = b->kind_first[k] + uni[k]; }
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
-      const int k = (int)(order[i].first >> 60), g = j - i, whole = (k == ASDR_KERNEL_SAM && sam_general_only) ? 0 : g / 8 * 8;
+      const int k = (int)(order[i].first >> 60), g = j - i;
+      const bool fused = (k == ASDR_KERNEL_SAM && sam_general_only);
+      const int whole = fused ? 0 : g / 8 * 8;
       for (int t = 0; t < g; t++) {
         const int c = order[i + t].second;
-        int &at = (t < whole) ? at_u[k] : at_m[k];
+        int &at = (t < whole) ? at_u[k] : (fused ? at_m[k] : at_left);
         b->sched[at++] = SlotInfo{c, b->hp[c].mode, b->hp[c].flags, 0u};
       }
       i = j;
@@ -664,13 +673,14 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
   else if (b->time_calls) { e0 = b->ev0; e1 = b->ev1; }
-  // Up to ten sub-ranges of the sorted schedule (5 kernel kinds x {uniform, mixed waves}).  They touch disjoint channels,
+  // Up to seven sub-ranges of the sorted schedule (the whole waves of 5 kernel kinds, the fused SAM kernel's general waves, the remainders).  They touch disjoint channels,
   // so they run CONCURRENTLY: the first on the caller's stream, the others on the batch's helper streams, forked behind an
   // event and joined before the call's end marker -- launched back to back on one stream the short ones (a handful of waves of
   // the slowest instantiation) would each add a whole wave lifetime to the step.  Heaviest instantiation first.
   struct Sub { int kind, uniform, first, slots; };
-  Sub subs[2 * ASDR_KERNEL_KINDS]; int n_sub = 0;
+  Sub subs[ASDR_KERNEL_KINDS + 2]; int n_sub = 0;
   static const int heaviest_first[ASDR_KERNEL_KINDS] = {ASDR_KERNEL_ALS, ASDR_KERNEL_SAM_ALS, ASDR_KERNEL_ALS_SMALL, ASDR_KERNEL_SAM, ASDR_KERNEL_PLAIN};
+  if (b->left_slots > 0) subs[n_sub++] = Sub{b->left_kind, 0, b->left_first, b->left_slots};   // a few long-lived waves: started first
   for (int kk = 0; kk < ASDR_KERNEL_KINDS; kk++) {
     const int k = heaviest_first[kk];
     if (b->kind_slots[k] == 0) continue;
@@ -1104,8 +1114,9 @@ int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
   b->agc_pool_dirty = false;
   if (stats) {
     stats[0] = b->stat_rows_refilled; stats[1] = rebuilt ? 1 : 0;
-    stats[2] = (long long)(b->kind_slots[ASDR_KERNEL_PLAIN] / 8) | ((long long)(b->kind_slots[ASDR_KERNEL_SAM] / 8) << 21) |
-               ((long long)((b->kind_slots[ASDR_KERNEL_ALS] + b->kind_slots[ASDR_KERNEL_ALS_SMALL] + b->kind_slots[ASDR_KERNEL_SAM_ALS]) / 8) << 42);
+    const int lw = b->left_slots / 8;   // the remainders' waves count with the kind whose general kernel runs them
+    stats[2] = (long long)(b->kind_slots[ASDR_KERNEL_PLAIN] / 8 + (b->left_kind == ASDR_KERNEL_PLAIN ? lw : 0)) | ((long long)(b->kind_slots[ASDR_KERNEL_SAM] / 8) << 21) |
+               ((long long)((b->kind_slots[ASDR_KERNEL_ALS] + b->kind_slots[ASDR_KERNEL_ALS_SMALL] + b->kind_slots[ASDR_KERNEL_SAM_ALS]) / 8 + (b->left_kind == ASDR_KERNEL_ALS ? lw : 0)) << 42);
     long long live = 0;
     for (uint32_t r : b->agc_refs) live += (r != 0);
     stats[3] = live;

@@ -189,10 +189,11 @@ def test_incremental_control_plane(A):
     st = b.control_plane_flush()
     assert st["rows_refilled"] == 1 and st["schedule_rebuilt"]
     assert st["waves_sam"] == 1 and st["waves_plain"] == (n - 1 + 7) // 8 and st["waves_als"] == 0
-    b.enableALSfilter(ch=123); b.enableALSfilter(ch=7)   # ALS wins over SAM for the instantiation; SAM + ALS is a kind of its own
+    b.enableALSfilter(ch=123); b.enableALSfilter(ch=7)   # two more kinds (SAM + ALS, ALS): one channel each
     st = b.control_plane_flush()
-    assert st["schedule_rebuilt"] and st["waves_sam"] == 0 and st["waves_als"] == 2 and st["waves_plain"] == (n - 2 + 7) // 8
-    b.setALSfilterParams(100, 0.5, 3, ch=123); b.setALSfilterParams(100, 0.5, 3, ch=7)   # a long filter: both on the 516-float rows
+    # the remainders of all key groups -- 6 plain channels and these two -- share ONE wave of the general (ALS) instantiation
+    assert st["schedule_rebuilt"] and st["waves_sam"] == 0 and st["waves_als"] == 1 and st["waves_plain"] == n // 8 - 1
+    b.setALSfilterParams(100, 0.5, 3, ch=123); b.setALSfilterParams(100, 0.5, 3, ch=7)   # a long filter: another kind again
     st = b.control_plane_flush()
     assert st["schedule_rebuilt"] and st["waves_als"] == 1
     b.setMute(1)                                      # broadcast: bulk refill, flags are part of the key
