@@ -738,6 +738,11 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     b->lo_parity ^= 1u;
     return 0;
   }
+  // The largest sub-range runs on the caller's stream: back-to-back calls then follow each other there without a gap, the helper
+  // streams' joins (shorter kernels) are already satisfied when it ends, and only their starts pay the fork event's latency
+  // (C4: 28 us per call with the remainders' launch on the caller's stream).
+  int main_sub = 0;
+  for (int i = 1; i < n_sub; i++) if (subs[i].slots > subs[main_sub].slots) main_sub = i;
   const int n_launch = per_block ? n_blocks : 1;
   float *const taps = a.taps;
   if (e0) HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
@@ -749,9 +754,9 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
       a.taps = (lb == n_launch - 1) ? taps : nullptr;   // the taps are those of the call's last block
     }
     if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
-    for (int i = 0; i < n_sub; i++) {
-      hipStream_t s = (i == 0) ? stream : b->aux[i - 1];
-      if (i > 0) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
+    for (int i = 0, n_aux = 0; i < n_sub; i++) {
+      hipStream_t s = (i == main_sub) ? stream : b->aux[n_aux++];
+      if (i != main_sub) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
       a.sched = b->d_sched + subs[i].first; a.n_sched = subs[i].slots;
       a.direct_ch0 = -1;
       if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
@@ -764,8 +769,9 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM_ALS)   // ... behind those of the SAM kind
         a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + subs[i].first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
       if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
-      if (i > 0) { HIPCHK(hipEventRecord(b->ev_join[i - 1], s)); HIPCHK(hipStreamWaitEvent(stream, b->ev_join[i - 1], 0)); }
+      if (i != main_sub) HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
     }
+    for (int j = 0; j + 1 < n_sub; j++) HIPCHK(hipStreamWaitEvent(stream, b->ev_join[j], 0));   // behind the caller's stream's own launch
   }
   if (e1) HIPCHK(hipEventRecord(e1, stream));
   b->ev_last_valid = true;
