@@ -439,6 +439,41 @@ __device__ __forceinline__ float als_dot_split_uniform(const float *wh, const fl
   return y;
 }
 
+// ... and for a filter length known at compile time (the reference's default, ALS_M_DEFAULT = 55 taps, AudioSDR.h:198): fully
+// unrolled -- immediate LDS offsets instead of pointer arithmetic, no loop control, the last group's existence tests folded.
+#define ALS_M_DEFAULT 55
+template <int MC>
+__device__ __forceinline__ float als_dot_split_const(const float *wh, const float *xh, int h) {
+  constexpr int NF = MC >> 3, R = MC & 7, NG = NF + (R ? 1 : 0);
+  float y = 0.0f;
+  AlsGroup G[2];
+  als_group_load(G[0], wh, xh, 0);
+#pragma unroll
+  for (int g = 0; g < NF; ++g) {
+    if (g + 1 < NG) als_group_load(G[(g + 1) & 1], wh, xh, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    y = als_group_sum(y, G[g & 1]);
+  }
+  if (R) y = als_group_sum_tail(y, G[NF & 1], R - h);
+  return y;
+}
+// The tap update w[q] += lambda * (e * x[iu - D - q]) (AudioSDR.cpp:341-343) of lane s8's taps q = s8 + 8k, for MC taps in all:
+// every operand requested before the first product, every result written after the last.
+template <int MC>
+__device__ __forceinline__ void als_tap_update_const(const float *xq, float *wq, float e, float lam, int s8) {
+  constexpr int NF = MC >> 3, R = MC & 7, NK = NF + (R ? 1 : 0);
+  float xv[NK], wv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { xv[k] = xq[-8 * k]; wv[k] = wq[4 * k]; }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const float gq = e * xv[k]; const float dq = lam * gq; const float wn = wv[k] + dq;
+    wv[k] = (k < NF || s8 < R) ? wn : wv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) wq[4 * k] = wv[k];
+}
+
 // keeps the instruction scheduler from interleaving all iterations of a fully unrolled loop (register pressure)
 // A register array that is written under a condition and read later under the same condition must still be DEFINED on every
 // path of the block-loop iteration: otherwise its value "from the previous iteration" is formally live around the whole loop
@@ -1675,6 +1710,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const bool als_safe = COMPACT || __all(!als_en || (D >= 0 && D + M <= AH + 1));
         const int M_u = __builtin_amdgcn_readfirstlane(M);
         const bool als_m_uniform = __all(als_en && adaptive && M == M_u);   // the usual case: one filter length in the wave
+        const bool als_m_default = als_m_uniform && als_safe && M_u == ALS_M_DEFAULT;   // ... and the reference's default one
         if (__any(als_en && !adaptive)) {
           if (als_en && !adaptive) {
             for (int j = 0; j < 16; ++j) {
@@ -1698,7 +1734,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_safe) {   // all eight lanes of the channel share the sum (als_dot_split); lanes 0-3 keep the results
               const int i = 128 + n, h = s8 >> 2;
               float y = 0.0f;
-              if (als_m_uniform) y = als_dot_split_uniform(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
+              if (als_m_default) y = als_dot_split_const<ALS_M_DEFAULT>(L + AW + WH * h, L + XB + (i - D - h), h);
+              else if (als_m_uniform) y = als_dot_split_uniform(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
               else if (als_en && adaptive) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M, h);
               if (mine) {
                 const float e = L[XB + i] - y;
@@ -1719,7 +1756,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             if (als_en && adaptive && nu < ASDR_N) {
               const float e = L[SCR];
               const int iu = 128 + nu;
-              if (als_m_uniform && als_safe) {
+              if (als_m_default) {
+                als_tap_update_const<ALS_M_DEFAULT>(L + XB + iu - D - s8, L + AW + ALS_TAP(s8, WH), e, lam, s8);
+              } else if (als_m_uniform && als_safe) {
                 // lane s8 owns taps s8 + 8k (k < nk).  Eight of them per step, all operands requested together and all results
                 // written together: one LDS round trip per step instead of one per tap.  Steps run to a multiple of 8 taps per
                 // lane: the surplus ones (still inside the tap rows: M <= 64 -> k <= 7, M <= 128 -> k <= 15) are written back unchanged.
