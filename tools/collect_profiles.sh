@@ -4,6 +4,7 @@
 #   kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command (default flags, CPU baseline leg skipped; kernel rows only)
 #   pmc.json              rocprofv3 --pmc passes of the same command (tools/prof_pmc2.sh; HBM traffic = 2*FETCH_SIZE + WRITE_SIZE)
 #   configs_1gpu.jsonl    tools/bench_configs.py: BASELINE configs 1-5 on one GPU with their parity checks
+#   c3_kernel_stats.csv, c4_kernel_stats.csv   rocprofv3 --kernel-trace --stats of tools/bench_configs.py c3 / c4 (which launches, how long)
 set -u
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -17,4 +18,9 @@ f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
 bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc" > "$OUT/pmc.log" 2>&1
 cp "$OUT/pmc.json" "$OUT/pmc_final.json" 2>/dev/null
 python3 tools/bench_configs.py c1 c2 c2s c3 c4 c5 > "$OUT/configs_1gpu.jsonl" 2> "$OUT/configs.err"
+for c in c3 c4; do
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python3 "$ROOT/tools/bench_configs.py" $c > "$OUT/stats_$c.log" 2>&1 )
+  f=$(find "$OUT/stats_$c" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${c}_kernel_stats.csv"
+done
 cat "$OUT/bench.json"; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/configs_1gpu.jsonl"
