@@ -61,6 +61,38 @@ def test_fuzz_control_surface(gpu, ao, seed):
     batch.close()
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_fuzz_whole_waves(gpu, ao, seed):
+    """The same fuzz with the channels configured in groups of 8 (48 groups x 8 channels x 24 blocks): whole waves of one schedule
+    key, i.e. the uniform-key instantiations of every kernel kind (plain, SAM, ALS on the compact and on the long rows), with
+    the groups moving between kinds mid-stream.  (With 40 individually configured channels nearly every channel is a remainder
+    and runs in the general kernel.)"""
+    from audiosdr_amd.synth import make_iq
+    rng = np.random.default_rng(seed)
+    n_grp, n_blk = 48, 24
+    n_ch = 8 * n_grp
+    fc = 6890.0 + rng.uniform(-1800, 1800, n_ch)
+    I, Q = make_iq(n_ch, n_blk, fc=fc, A=rng.uniform(0.01, 0.6, n_ch), m=0.4, fm=300.0, impulse_every=int(rng.integers(300, 900)),
+                   f2=fc + 700.0, a2=0.05)
+    batch = gpu.AudioSDRBatch(n_ch)
+    orcs = [ao.OracleSDR() for _ in range(n_ch)]
+    for _ in range(80):
+        meth, args, _sel = _random_setter(rng)
+        mask = rng.random(n_grp) < 0.3
+        apply_setters(batch, orcs, [S(meth, *args, sel=lambda c, m=mask: bool(m[c // 8]))])
+    for b in range(n_blk):
+        for _ in range(int(rng.integers(0, 4))):
+            meth, args, _sel = _random_setter(rng)
+            mask = rng.random(n_grp) < 0.2
+            apply_setters(batch, orcs, [S(meth, *args, sel=lambda c, m=mask: bool(m[c // 8]))])
+        got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b], Q[c, b])
+            assert np.array_equal(got[c], want), "seed %d block %d ch %d (mode %d)" % (seed, b, c, orcs[c].getDemodMode())
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
 @pytest.mark.parametrize("mode", [1, 4, 5])
 def test_decay_into_denormals(gpu, ao, mode):
     """Signal for 12 blocks, then digital silence for 400 blocks: biquad, AGC, blanker-average and PLL states decay
