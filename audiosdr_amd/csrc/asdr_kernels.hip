@@ -77,7 +77,6 @@ __constant__ float c_bq_pool[ASDR_N_BQ_TABLES][ASDR_BQ_COEFS];
 __constant__ float c_hilbert[ASDR_HILBERT_TAPS];
 __constant__ float c_sine[ASDR_SINE_TABLE_LEN];
 __constant__ float c_mask_val[8];       // blanker mask: code -> value
-__constant__ uint8_t c_mask_code[64];  // blanker mask: bits 20..25 of the value -> code
 
 extern "C" int asdr_kernels_upload_tables(void) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_bq_pool), asdr_bq_pool, sizeof(asdr_bq_pool)) != hipSuccess) return -1;
@@ -85,11 +84,7 @@ extern "C" int asdr_kernels_upload_tables(void) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_sine), asdr_sine_table, sizeof(asdr_sine_table)) != hipSuccess) return -1;
   {   // blanker mask codes (AudioSDR.cpp:608, 623, 630: the mask only ever holds these seven values)
     const float val[8] = {0.0f, 1.0f, (float)0.933, (float)0.750, (float)0.500, (float)0.250, (float)0.067, 1.0f};
-    uint8_t code[64];
-    for (int i = 0; i < 64; i++) code[i] = 1;
-    for (int c = 0; c < 7; c++) { uint32_t b; memcpy(&b, &val[c], 4); code[(b >> 20) & 0x3F] = (uint8_t)c; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_mask_val), val, sizeof val) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_mask_code), code, sizeof code) != hipSuccess) return -1;
   }
   return 0;
 }
@@ -319,22 +314,30 @@ __device__ __forceinline__ void scale8(const int16_t *s, double g, float *out) {
     if ((j & 1) == 1) SCHED_FENCE();
   }
 }
-// The blanker mask only ever holds {0, 1, .933, .750, .500, .250, .067} (AudioSDR.cpp:608, 623, 630): one byte each in HBM.
-// Both directions go through small tables in constant memory (gathers through L1): the blanker's general path is rare, and
-// select chains on seven float literals made the compiler keep ~30 literals in VGPRs for the whole kernel.
-// Code -> value: c_mask_val[code].  Value -> code: bits 20..25 of the float are distinct for the seven values
-// (0.0: 0x00, 0.067: 0x18, 0.25: 0x28, 0.5: 0x30, 0.75: 0x34, 0.933: 0x36, 1.0: 0x38); any other value maps to code 1 like
-// the select chain did.
-__device__ __forceinline__ float mask_decode(uint32_t c) { return c_mask_val[c & 7u]; }
-__device__ __forceinline__ uint32_t mask_encode(float v) {
-  const uint32_t code = c_mask_code[(__float_as_uint(v) >> 20) & 0x3Fu];
-  return (c_mask_val[code] == v) ? code : 1u;   // exact match only (any other non-zero value is code 1)
+// The blanker mask only ever holds {0, 1, .933, .750, .500, .250, .067} (AudioSDR.cpp:608, 623, 630): one byte each in HBM
+// (codes 0..6 in that order).  Neither direction touches memory (round 2: gathers through L1 in both directions were half of
+// what the blanker's general path costs over the quiet one):
+// Code -> value: every lane holds c_mask_val[lane & 7] (`tabv`, one load per wave on the general path); a lookup is a
+//   ds_bpermute from lane `code` -- the LDS crossbar, no LDS memory.  (Select chains on the seven literals made the compiler keep
+//   ~30 literals in VGPRs for the whole kernel.)
+// Value -> code: bits 21..25 of the float are distinct for the seven values (0.0: 0, .067: 12, .25: 20, .5: 24, .75: 26,
+//   .933: 27, 1.0: 28); three times that, less 36 (mod 64: 0.0 lands on 28), indexes 3-bit fields of one 64-bit constant.
+//   The mask rows are only ever written with these seven values (decoded codes, the 1.0 fill, the 0.0 zeroing, the ramp
+//   read from the same table), so no other bit pattern can arrive here.
+#define ASDR_MASK_MAGIC 0x14c4005000006ull   /* fields: [0] = 6, [24] = 5, [36] = 4, [42] = 3, [45] = 2, [48] = 1, [28] = 0 */
+// `group4` = 4 x the first lane of the caller's group of 8 lanes: a lane reads from its OWN group (the lanes of one channel are
+// active together; ds_bpermute returns 0 for an inactive source lane).  Call it with the whole group active.
+__device__ __forceinline__ float mask_decode_byte(float tabv, uint32_t group4, uint32_t word, int k) {   // byte k of a code word
+  const uint32_t sh = (k == 0) ? (word << 2) : (word >> (8 * k - 2));
+  const uint32_t addr = (sh & 0x1Cu) | group4;   // (code * 4: codes < 8)
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)addr, __float_as_int(tabv)));
 }
-// four entries -> one code word.  The codes are made opaque before they are shifted: otherwise `(match ? code : 1) << 8k` becomes a
-// select against the literals 0x100 / 0x10000 / 0x1000000, which the compiler parks in three VGPRs for the whole kernel.
-__device__ __forceinline__ uint32_t mask_encode4(float4 mv) {
-  uint32_t c0 = mask_encode(mv.x), c1 = mask_encode(mv.y), c2 = mask_encode(mv.z), c3 = mask_encode(mv.w);
-  asm volatile("" : "+v"(c1), "+v"(c2), "+v"(c3));
+__device__ __forceinline__ uint32_t mask_encode(float v) {
+  const uint32_t idx = (__float_as_uint(v) >> 21) & 0x1Fu;
+  return (uint32_t)(ASDR_MASK_MAGIC >> ((idx * 3u - 36u) & 63u)) & 7u;
+}
+__device__ __forceinline__ uint32_t mask_encode4(float4 mv) {   // four entries -> one code word
+  const uint32_t c0 = mask_encode(mv.x), c1 = mask_encode(mv.y), c2 = mask_encode(mv.z), c3 = mask_encode(mv.w);
   return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
 }
 
@@ -991,6 +994,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (nb_slow) {
         float mk[16];
         DEFINE_ALL_PATHS(mk, 16);
+        const float mask_tab = c_mask_val[lane_i & 7];   // code -> value, one entry per lane (mask_decode_byte)
+        const uint32_t group4 = (uint32_t)(lane_i & 56) << 2;
         ph_ready = false;          // the count bytes below overlay the PH row: the phase sequence is recomputed after the blanker
         WAVE_SYNC();               // every lane has read its averages: the B row is dead
         if (nb_en) {
@@ -1034,9 +1039,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
           for (int r = 0; r < 5; ++r) {
             const int e = 32 * r + 4 * s8;
-            if (e < ASDR_NB_MASK_USED + 2)
-              *reinterpret_cast<float4 *>(L + NB_MSK + e) = make_float4(mask_decode(mkc[r] & 0xFFu), mask_decode((mkc[r] >> 8) & 0xFFu),
-                                                                         mask_decode((mkc[r] >> 16) & 0xFFu), mask_decode(mkc[r] >> 24));
+            const float4 dv = make_float4(mask_decode_byte(mask_tab, group4, mkc[r], 0), mask_decode_byte(mask_tab, group4, mkc[r], 1),
+                                          mask_decode_byte(mask_tab, group4, mkc[r], 2), mask_decode_byte(mask_tab, group4, mkc[r], 3));   // (all 8 lanes)
+            if (e < ASDR_NB_MASK_USED + 2) *reinterpret_cast<float4 *>(L + NB_MSK + e) = dv;
           }
           float one = 1.0f; asm volatile("" : "+v"(one));   // materialised here, not parked in a VGPR at kernel entry
 #pragma unroll
@@ -1071,7 +1076,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           // for the whole kernel
           float trans_dn[7];
 #pragma unroll
-          for (int q = 0; q < 5; ++q) trans_dn[q] = c_mask_val[2 + q];
+          for (int q = 0; q < 5; ++q) trans_dn[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mask_tab), 2 + q));
           trans_dn[5] = 0.0f; trans_dn[6] = 0.0f;
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
