@@ -270,7 +270,7 @@ def main():
                        "channels_per_gpu": n_ch, "block": BLOCK, "sharding": "channels, no collective",
                        "input": "tone + LCG noise per channel, no impulses: the blanker runs (envelope, average, threshold) but detects "
                                 "nothing, so its mask stays all ones; with an impulse in every block of every channel the same chain "
-                                "is ~8 % slower (tools/bench_configs.py c2)"},
+                                "is ~9 % slower (tools/bench_configs.py c2)"},
             "roofline": {"bound": "hbm", "kernel": "asdr_update_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 5),
