@@ -93,6 +93,48 @@ def test_fuzz_whole_waves(gpu, ao, seed):
     batch.close()
 
 
+@pytest.mark.parametrize("seed", [31, 32])
+def test_fuzz_large_mixed_batch(gpu, ao, seed):
+    """4,000 channels with random modes, enables and ALS filter shapes (both sides of the compact layout's limits), enough SAM
+    channels for the three-launch SAM path, calls of 1-3 blocks, parameters changing between calls: every kernel kind in whole waves
+    AND the remainders' sub-range in one schedule, three times rebuilt.  Every channel against the oracle."""
+    from audiosdr_amd.synth import make_iq
+    rng = np.random.default_rng(seed)
+    n_ch = 4000
+    calls = [int(x) for x in rng.integers(1, 4, 4)]
+    n_blk = sum(calls)
+    fc = 6890.0 + rng.uniform(-1500, 1500, n_ch)
+    I, Q = make_iq(n_ch, n_blk, fc=fc, A=rng.uniform(0.05, 0.5, n_ch), m=0.4, fm=300.0, impulse_every=int(rng.integers(400, 900)), f2=fc + 600.0, a2=0.08)
+    batch = gpu.AudioSDRBatch(n_ch)
+    orcs = [ao.OracleSDR() for _ in range(n_ch)]
+    shapes = [(55, 0.5, 3.0), (64, 0.5, 1.0), (65, 0.25, 0.0), (32, 0.5, 33.0), (32, 0.5, 34.0), (100, 0.05, 7.0), (8, 0.5, 0.0), (128, 0.05, 1.0)]
+    def reconfigure(frac):
+        grp = rng.integers(0, 24, n_ch)            # 24 configuration groups of ~167 channels: whole waves + a remainder each
+        pick = rng.random(24) < frac
+        for g in np.nonzero(pick)[0]:
+            sel = lambda c, g=g: grp[c] == g
+            st = [S("setDemodMode", int(rng.choice([0, 1, 2, 4, 5, 5, 5, 6]))), S("setNoiseBlankerThresholdDb", 10.0)]
+            if rng.random() < 0.7:
+                st += [S("enableALSfilter"), S("setALSfilterParams", *shapes[int(rng.integers(0, len(shapes)))])]
+                if rng.random() < 0.3: st.append(S("setALSfilterPeak"))
+                if rng.random() < 0.2: st.append(S("setALSfilterStatic"))
+            else:
+                st.append(S("disableALSfilter"))
+            if rng.random() < 0.5: st.append(S("enableAudioFilter"))
+            apply_setters(batch, orcs, [S(m, *a, sel=sel) for (m, a, _s) in st])
+    reconfigure(1.0)
+    b0 = 0
+    for T in calls:
+        got = batch.update(I[:, b0:b0 + T], Q[:, b0:b0 + T])
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b0:b0 + T], Q[c, b0:b0 + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "seed %d blocks %d.. ch %d (mode %d)" % (seed, b0, c, orcs[c].getDemodMode())
+        b0 += T
+        reconfigure(0.3)
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
 @pytest.mark.parametrize("mode", [1, 4, 5])
 def test_decay_into_denormals(gpu, ao, mode):
     """Signal for 12 blocks, then digital silence for 400 blocks: biquad, AGC, blanker-average and PLL states decay
