@@ -53,7 +53,7 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 # every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
-            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
+            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
             "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_set_launch_timing", "asdr_region_timing_begin", "asdr_region_timing_end", "asdr_update_device_strided", "asdr_capture_open",
             "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read"] +
@@ -116,6 +116,8 @@ def load_library(path=None):
     L.asdr_kernel_timing_begin.argtypes = [vp, _i]; L.asdr_kernel_timing_begin.restype = _i
     if path is None or hasattr(L, "asdr_stream_pipeline_launches"):
         L.asdr_stream_pipeline_launches.argtypes = [vp]; L.asdr_stream_pipeline_launches.restype = C.c_long
+    if path is None or hasattr(L, "asdr_schedule_layout"):
+        L.asdr_schedule_layout.argtypes = [vp, C.POINTER(C.c_int)]; L.asdr_schedule_layout.restype = _i
     if path is None or hasattr(L, "asdr_region_timing_begin"):
         L.asdr_set_launch_timing.argtypes = [vp, _i]; L.asdr_set_launch_timing.restype = _i
         L.asdr_region_timing_begin.argtypes = [vp, vp]; L.asdr_region_timing_begin.restype = _i
@@ -228,6 +230,14 @@ class AudioSDRBatch:
 
     def stream_pipeline_launches(self):
         return int(self._L.asdr_stream_pipeline_launches(self._h))
+
+    def schedule_layout(self):
+        """Slots (8 per wave) per kernel kind, the remainders' sub-range and its kernel kind, the SAM launch form (asdr.h)."""
+        out = (C.c_int * 8)()
+        self._chk(self._L.asdr_schedule_layout(self._h, out))
+        v = list(out)
+        return {"plain": v[0], "sam": v[1], "als_long": v[2], "als_compact": v[3], "sam_als": v[4], "remainders": v[5],
+                "remainder_kind": v[6], "sam_three_launches": bool(v[7])}
 
     def set_launch_timing(self, on):
         self._chk(self._L.asdr_set_launch_timing(self._h, 1 if on else 0))

@@ -1111,6 +1111,13 @@ unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]) {
 
 long asdr_stream_pipeline_launches(asdr_batch_t *b) { return b ? b->stat_stream_launches : -1; }
 
+int asdr_schedule_layout(asdr_batch_t *b, int out[8]) {
+  if (!b || !out) return fail("null argument");
+  for (int k = 0; k < ASDR_KERNEL_KINDS; k++) out[k] = b->kind_slots[k];
+  out[5] = b->left_slots; out[6] = b->left_slots ? b->left_kind : -1; out[7] = b->sam_split ? 1 : 0;
+  return 0;
+}
+
 int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
   if (!b) return fail("null batch");
   if (b->device != ASDR_NO_DEVICE) return fail("asdr_control_plane_flush is for control-plane-only batches: a device batch flushes in update()");

@@ -209,6 +209,14 @@ unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]);
  * on consecutive blocks at the same time).  Results are bit-identical to the block-by-block path; the counter
  * exists so that tests and benchmarks can tell which path ran. */
 long asdr_stream_pipeline_launches(asdr_batch_t *b);
+/* The wave schedule as the last flush built it (the next update's launches; a control-plane-only batch: after
+ * asdr_control_plane_flush), in schedule slots (8 per wave): out[0..4] = the sub-ranges of whole waves of one settings group by
+ * kernel kind -- 0 plain, 1 SAM, 2 ALS on the long rows, 3 ALS on the compact rows (taps <= 64, delay + taps <= 65, not SAM),
+ * 4 SAM + such an ALS filter -- (kind 1 also holds the SAM remainders when a batch with fewer than 512 SAM channels runs them in
+ * the fused SAM kernel), out[5] = the sub-range of all other remainders (< 8 channels per settings group), out[6] = the kind of the
+ * general kernel that runs it (0 or 2; -1 if empty), out[7] = 1 if SAM channels run as pre | PLL | post launches.  For tests and
+ * capacity planning; DESIGN.md 3.1. */
+int asdr_schedule_layout(asdr_batch_t *b, int out[8]);
 /* Library / build identification string (contains "gfx950"). */
 const char *asdr_version(void);
 

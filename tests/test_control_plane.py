@@ -218,3 +218,53 @@ def test_agc_table_pool_is_shared_and_compacted(A):
     v = [b.getAGClookup(100, ch=c) for c in range(16)]
     assert v[0] == v[8] and v[1] == v[9] and v[0] != v[1]
     b.close()
+
+
+def test_schedule_layout_kinds_and_remainders(A):
+    """asdr_schedule_layout after a control-plane flush: which kernel kind a channel's settings select (asdr_host.cpp kernel_kind:
+    the ALS filter on the compact rows needs taps <= 64, delay >= 0 and delay + taps <= 65 and a mode other than SAM; SAM + such a
+    filter is a kind of its own), whole waves per settings group, ONE sub-range for the remainders of all groups, and the launch
+    form of the SAM channels (three launches from 512 SAM channels)."""
+    n = 4096
+    b = A.AudioSDRBatch(n, device=-1)
+    b.control_plane_flush()
+    lay = b.schedule_layout()
+    assert lay == {"plain": n, "sam": 0, "als_long": 0, "als_compact": 0, "sam_als": 0, "remainders": 0, "remainder_kind": -1,
+                   "sam_three_launches": False}
+    # channels 0..99: ALS with the default 55 taps / delay 3 -> compact; 96 in whole waves, 4 remainders (+ 4 plain remainders: n - 100 = 8k + 4)
+    for c in range(100):
+        b.enableALSfilter(ch=c)
+    b.control_plane_flush()
+    lay = b.schedule_layout()
+    assert lay["als_compact"] == 96 and lay["plain"] == (n - 100) // 8 * 8 and lay["als_long"] == 0
+    assert lay["remainders"] == 8 and lay["remainder_kind"] == 2      # 4 ALS + 4 plain channels: one wave of the general (ALS) kernel
+    # the limits of the compact layout, 8 channels each (their own settings groups differ only in the filter shape -> same group
+    # key, so they stay in the ALS sub-ranges by kind)
+    shapes = {(64, 1): "als_compact", (64, 2): "als_long", (65, 0): "als_long", (1, 64): "als_compact", (1, 65): "als_long",
+              (0, 3): "als_compact", (128, 0): "als_long"}
+    base = 200
+    for i, (m_d, kind) in enumerate(shapes.items()):
+        for c in range(base + 8 * i, base + 8 * i + 8):
+            b.enableALSfilter(ch=c); b.setALSfilterParams(m_d[0], 0.5, float(m_d[1]), ch=c)
+    b.control_plane_flush()
+    lay2 = b.schedule_layout()
+    n_compact = sum(8 for k in shapes.values() if k == "als_compact"); n_long = sum(8 for k in shapes.values() if k == "als_long")
+    assert lay2["als_compact"] + lay2["als_long"] + lay2["plain"] + lay2["remainders"] >= n
+    assert lay2["als_long"] == n_long                                   # 4 x 8 channels, whole waves
+    assert lay2["als_compact"] == 96 + n_compact
+    # SAM: 600 channels -> the three-launch form; 8 of them with a compact ALS filter -> kind "sam_als"; below 512 -> the fused kernel
+    for c in range(1000, 1600):
+        b.setDemodMode(A.SAMmode, ch=c)
+    for c in range(1000, 1008):
+        b.enableALSfilter(ch=c)
+    b.control_plane_flush()
+    lay3 = b.schedule_layout()
+    assert lay3["sam_three_launches"] and lay3["sam"] == 592 and lay3["sam_als"] == 8
+    for c in range(1100, 1600):
+        b.setDemodMode(A.USBmode, ch=c)
+    b.control_plane_flush()
+    lay4 = b.schedule_layout()
+    # 92 SAM channels left (1008..1099): the fused kernel's general waves, padded to 96 slots; the 8 SAM + ALS channels keep their
+    # kind (its launch then uses the long-row ALS kernel, which carries the PLL)
+    assert not lay4["sam_three_launches"] and lay4["sam"] == 96 and lay4["sam_als"] == 8
+    b.close()
