@@ -53,7 +53,7 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 # every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
-            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
+            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_set_exact_unknown_mode", "asdr_get_exact_unknown_mode", "asdr_stream_pipeline_recoveries", "asdr_stream_pipeline_max_groups", "asdr_set_stream_pipeline", "asdr_set_sam_launch_form", "asdr_debug_set_stream_spin_limit", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
             "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_set_launch_timing", "asdr_region_timing_begin", "asdr_region_timing_end", "asdr_update_device_strided", "asdr_capture_open",
             "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read"] +
@@ -116,6 +116,15 @@ def load_library(path=None):
     L.asdr_kernel_timing_begin.argtypes = [vp, _i]; L.asdr_kernel_timing_begin.restype = _i
     if path is None or hasattr(L, "asdr_stream_pipeline_launches"):
         L.asdr_stream_pipeline_launches.argtypes = [vp]; L.asdr_stream_pipeline_launches.restype = C.c_long
+    if path is None or hasattr(L, "asdr_set_stream_pipeline"):
+        L.asdr_stream_pipeline_recoveries.argtypes = [vp]; L.asdr_stream_pipeline_recoveries.restype = C.c_long
+        L.asdr_stream_pipeline_max_groups.argtypes = [vp]; L.asdr_stream_pipeline_max_groups.restype = _i
+        L.asdr_set_stream_pipeline.argtypes = [vp, _i]; L.asdr_set_stream_pipeline.restype = _i
+        L.asdr_set_sam_launch_form.argtypes = [vp, _i, _i]; L.asdr_set_sam_launch_form.restype = _i
+        L.asdr_debug_set_stream_spin_limit.argtypes = [vp, _u]; L.asdr_debug_set_stream_spin_limit.restype = _i
+    if path is None or hasattr(L, "asdr_set_exact_unknown_mode"):
+        L.asdr_set_exact_unknown_mode.argtypes = [vp, _i]; L.asdr_set_exact_unknown_mode.restype = _i
+        L.asdr_get_exact_unknown_mode.argtypes = [vp]; L.asdr_get_exact_unknown_mode.restype = _i
     if path is None or hasattr(L, "asdr_schedule_layout"):
         L.asdr_schedule_layout.argtypes = [vp, C.POINTER(C.c_int)]; L.asdr_schedule_layout.restype = _i
     if path is None or hasattr(L, "asdr_region_timing_begin"):
@@ -228,8 +237,28 @@ class AudioSDRBatch:
     def last_kernel_ms(self):
         return float(self._L.asdr_last_kernel_ms(self._h))
 
+    def set_exact_unknown_mode(self, on=True):
+        """Keep every block's post-ALS audio row so that unknown mode values re-process it as the reference does (default on)."""
+        self._chk(self._L.asdr_set_exact_unknown_mode(self._h, 1 if on else 0))
+
     def stream_pipeline_launches(self):
         return int(self._L.asdr_stream_pipeline_launches(self._h))
+
+    def stream_pipeline_recoveries(self):
+        """Pipeline calls whose bounded wait ran out and that were re-run on the in-kernel block loop from the snapshot (asdr.h)."""
+        return int(self._L.asdr_stream_pipeline_recoveries(self._h))
+
+    def stream_pipeline_max_groups(self):
+        return int(self._L.asdr_stream_pipeline_max_groups(self._h))
+
+    def set_stream_pipeline(self, on=True):
+        self._chk(self._L.asdr_set_stream_pipeline(self._h, 1 if on else 0))
+
+    def set_sam_launch_form(self, fused=False, split_min_channels=0):
+        self._chk(self._L.asdr_set_sam_launch_form(self._h, 1 if fused else 0, int(split_min_channels)))
+
+    def debug_set_stream_spin_limit(self, polls):
+        self._chk(self._L.asdr_debug_set_stream_spin_limit(self._h, int(polls)))
 
     def schedule_layout(self):
         """Slots (8 per wave) per kernel kind, the remainders' sub-range and its kernel kind, the SAM launch form (asdr.h)."""

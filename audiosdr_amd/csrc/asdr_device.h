@@ -14,6 +14,8 @@
  *   hil_i    float       [C+1][2][128]     1 KiB  ring of mixed I blocks (this block, previous = the 128-sample delay)
  *   als_x    float       [C+1][128]        512 B  previous ALS input block
  *   als_w    float       [C+1][128]        512 B  ALS coefficients
+ *   audio_prev float     [C+1][128]        512 B  _audioOut as the block left it (after the audio filter / AGC / ALS): what an
+ *                                                 unknown mode value re-processes (AudioSDR.cpp:84,122,149-161)
  *   agc_tab  float       [T][132]                 pool of distinct AGC gain tables (130 used)
  */
 #ifndef ASDR_DEVICE_H_
@@ -123,6 +125,11 @@ typedef struct {
   int16_t *nb_hist;
   uint8_t *nb_mask;
   float *hil_q, *hil_i, *als_x, *als_w;
+  float *audio_prev;      /* [n_channels + 1][128] the member _audioOut (AudioSDR.h:169) as the previous block left it, i.e. after the audio
+                             filter, AGC and ALS: a mode value outside 0..6 runs neither demodulator (AudioSDR.cpp:84, 122) and the post
+                             stages process this row AGAIN (:149-161).  Written by every block of every channel (the kernel cannot know
+                             which block is a channel's last with a known mode); NULL = not kept, unknown modes process silence
+                             (asdr_set_exact_unknown_mode(b, 0)) */
   const float *agc_tab;
   const SlotInfo *sched;  /* per wave slot: channel index (padded to a multiple of 8 with the dummy channel n_channels),
                              mode and flags -- one 16-B load instead of the dependent chain sched -> params */
@@ -148,8 +155,12 @@ typedef struct {
   float *xch_b;           /* [n_channels][ASDR_STREAM_DEPTH][128]:    demodulated audio (role 2 -> role 3) */
   uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch (zeroed before it); [3 * stream_waves] =
                              the oscillator role's progress */
-  uint32_t *stream_err;   /* set to 1 by a wave that gave up waiting (ASDR_STREAM_SPIN_LIMIT); read and cleared by the host at its next
-                             synchronisation point */
+  uint32_t *stream_err;   /* [0] set to 1 by a wave that gave up waiting (stream_spin_limit polls): every wave of the launch then leaves
+                             at its next wait, and the launches the host enqueues BEHIND the pipeline (asdr_stream_restore_kernel, the
+                             gated in-kernel block loop, asdr_stream_ack_kernel) put the channels' state back and run the call again:
+                             a pipeline that could not make progress costs time, never results.  [1] = calls recovered that way so far */
+  uint32_t stream_spin_limit;   /* polls before a wait gives up (ASDR_STREAM_SPIN_LIMIT; tests shrink it to inject a timeout) */
+  const uint32_t *run_if; /* non-NULL: the launch is the pipeline's fallback -- every wave returns at once unless *run_if != 0 */
   int32_t stream_waves;   /* waves per role = (workgroups - 1) / 3 */
   float *xch_sam;         /* SAM sub-range as three launches (pre | PLL | post, asdr_launch_update): the IF output I, Q of the current block,
                              one 8 KB tile per group of 8 schedule slots, [tile][sample][I, Q][slot in tile] -- the pre kernel's wave
@@ -161,7 +172,11 @@ typedef struct {
 } UpdateArgs;
 #define ASDR_STREAM_DEPTH 4
 #define ASDR_LO_RING 8
-#define ASDR_STREAM_SPIN_LIMIT (1u << 18)   /* bounded waits: a broken pipeline ends with the error flag set, never with a hung GPU */
+#define ASDR_STREAM_SPIN_LIMIT (1u << 18)   /* bounded waits: a pipeline whose roles are not co-resident ends with the error flag set and is
+                                               re-run on the in-kernel block loop from a snapshot of the state (asdr_host.cpp), never with a hung GPU */
+#define ASDR_STREAM_FAIL 0xFFFFFFFFu        /* stream_wait: gave up (or another wave of the launch had) */
+/* per-channel state a pipeline call advances (plain instantiation, SSB-class modes): what the snapshot in front of it holds */
+#define ASDR_SNAP_BYTES (448 + 1536 + ASDR_NB_MASK_ROW + 1024 + 1024 + 512)   /* ChanSmall, nb_hist, nb_mask, hil_q, hil_i, audio_prev */
 
 /* instantiations of the update kernel (asdr_launch_update) */
 #define ASDR_KERNEL_PLAIN 0

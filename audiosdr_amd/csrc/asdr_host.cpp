@@ -34,6 +34,9 @@
 #define ASDR_STREAM_MIN_BLOCKS 8
 #endif
 extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream);
+extern "C" int asdr_stream_capacity(int device, int *compute_units);
+extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int restore, hipStream_t stream);
+extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream);
 extern "C" int asdr_kernels_upload_tables(void);
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
@@ -134,6 +137,7 @@ struct asdr_batch {
   std::vector<uint8_t> dirty_flag;
   bool all_dirty = true;               // first flush, or so many dirty rows that one bulk upload is cheaper
   bool sched_dirty = true, reset_pending = true, agc_pool_dirty = true;
+  bool agc_refs_changed = true;        // a setter moved a channel to another gain table since the last compaction check
   int reset_lo = 0x7fffffff, reset_hi = -1;   // rows with pending reset bits lie in [reset_lo, reset_hi]
   // The sorted schedule is launched as up to three sub-ranges, one per kernel instantiation (plain / SAM / ALS), each padded
   // to whole waves with the dummy channel: one SAM or ALS channel no longer demotes the whole batch.
@@ -151,6 +155,8 @@ struct asdr_batch {
   uint8_t *d_nb_mask = nullptr;
   float *d_hil_q = nullptr, *d_hil_i = nullptr, *d_als_x = nullptr,
         *d_als_w = nullptr, *d_agc_tab = nullptr, *d_taps = nullptr;
+  float *d_audio_prev = nullptr;   // _audioOut of the previous block, per channel (unknown mode values re-process it: AudioSDR.cpp:149-161)
+  bool exact_unknown_mode = true;  // asdr_set_exact_unknown_mode
   size_t agc_tab_cap = 0;
   SlotInfo *d_sched = nullptr;
   uint32_t *d_reset = nullptr;
@@ -177,7 +183,17 @@ struct asdr_batch {
   float *d_xch_a = nullptr, *d_xch_b = nullptr;
   uint32_t *d_stream_prog = nullptr;
   LoEntry *d_lo_ring = nullptr;
-  bool sam_split = false;           // decided when the schedule is built (enough SAM channels, ASDR_SAM_FUSED not set)
+  // Launch-form switches.  Their defaults come from the environment WHEN THE BATCH IS CREATED (ASDR_SAM_FUSED, ASDR_SAM_SPLIT_MIN,
+  // ASDR_NO_STREAM_PIPELINE: comparison switches of the measurement tools); asdr_set_sam_launch_form / asdr_set_stream_pipeline change
+  // them per batch afterwards.
+  bool sam_fused = false;           // SAM channels through the fused 4-wave kernel instead of the pre | PLL | post launches
+  int sam_split_min = 512;          // ... which are chosen from this many SAM channels on
+  bool stream_pipeline = true;      // small multi-block calls may run as the block pipeline (asdr_stream_kernel)
+  int stream_max_waves = 0;         // channel groups the pipeline may hold: 3 w + 1 workgroups must be co-resident, one per compute unit
+  uint32_t stream_spin_limit = ASDR_STREAM_SPIN_LIMIT;
+  void *d_stream_snap = nullptr;    // snapshot of the state a pipeline call advances (asdr_kernels.hip "the pipeline as a transaction")
+  long stat_stream_recoveries = 0;  // pipeline calls that gave up and were re-run on the in-kernel block loop (read back at synchronisation points)
+  bool sam_split = false;           // decided when the schedule is built (enough SAM channels, not sam_fused)
   float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
   size_t xch_sam_slots = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
@@ -218,12 +234,15 @@ void rebuild_agc(asdr_batch *b, Chan &c) {  // agc_createLookupTable(): also clo
   const int old = c.agc_table;
   c.agc_table = find_agc_table(b, c.agc_threshold, c.agc_slope, c.agc_knee);
   b->agc_refs[c.agc_table]++;
+  b->agc_refs_changed = true;
   if (old >= 0 && old < (int)b->agc_refs.size() && b->agc_refs[old] > 0) b->agc_refs[old]--;
   c.agc_slot129 = b->agc_pool[c.agc_table].v[129];
 }
 
 // Drop tables no channel uses any more (a UI knob sweep leaves one dead table per step) once they outnumber the live ones.
 void compact_agc_pool(asdr_batch *b) {
+  if (!b->agc_refs_changed) return;   // (every update call comes through here: no scan of the pool unless a reference moved)
+  b->agc_refs_changed = false;
   size_t live = 0;
   for (uint32_t r : b->agc_refs) live += (r != 0);
   if (b->agc_pool.size() < 64 || b->agc_pool.size() <= 2 * live) return;
@@ -315,8 +334,6 @@ int kernel_kind(const ChanParams &p) {
 #ifndef ASDR_SAM_SPLIT_MIN_CHANNELS
 #define ASDR_SAM_SPLIT_MIN_CHANNELS 512
 #endif
-// ASDR_SAM_FUSED=1: SAM channels through the fused 4-wave kernel instead of the pre | PLL | post launches (comparison switch)
-bool sam_fused_env() { static const bool v = getenv("ASDR_SAM_FUSED") != nullptr; return v; }
 uint64_t sched_key(const ChanParams &p) {
   return ((uint64_t)kernel_kind(p) << 60) | ((uint64_t)(p.mode & 0xFFFF) << 40) | ((uint64_t)(p.flags & 0xFF) << 32) |
          ((uint64_t)(p.if_table & 0xFF) << 24) | ((uint64_t)(p.audio_table & 0xFF) << 16) | (uint64_t)(p.agc_table & 0xFFFF);
@@ -370,8 +387,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     // of them is quicker through the fused kernel (one launch, no exchange round trips)
     int n_sam = 0;
     for (int i = 0; i < b->n; i++) { const int k = (int)(order[i].first >> 60); n_sam += (k == ASDR_KERNEL_SAM || k == ASDR_KERNEL_SAM_ALS); }
-    static const int sam_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;   // (tests: 1)
-    b->sam_split = !sam_fused_env() && n_sam >= sam_min;
+    b->sam_split = !b->sam_fused && n_sam >= b->sam_split_min;
     const bool sam_general_only = !b->sam_split;
     // The remainders (< 8 channels) of all key groups share ONE sub-range behind the kinds' whole waves, run by one launch of a
     // general instantiation: as a launch per kind they were up to five more streams of a handful of long-lived waves each, and
@@ -475,6 +491,7 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
   a.params = b->d_params; a.small = b->d_small;
   a.nb_hist = b->d_nb_hist; a.nb_mask = b->d_nb_mask; a.hil_q = b->d_hil_q; a.hil_i = b->d_hil_i;
   a.als_x = b->d_als_x; a.als_w = b->d_als_w; a.agc_tab = b->d_agc_tab;
+  a.audio_prev = b->exact_unknown_mode ? b->d_audio_prev : nullptr;
   a.sched = b->d_sched; a.n_sched = 0; a.n_channels = b->n;   // the launcher sets the sub-range
   a.taps = b->taps_on ? b->d_taps : nullptr;
   a.nb_phase = b->nb_phase;
@@ -507,18 +524,17 @@ void each(asdr_batch *b, int ch, F f) {
 }
 const Chan *get(asdr_batch *b, int ch) { return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr; }
 
-// Error word of the streaming pipeline (a wave gave up waiting for its neighbour role: ASDR_STREAM_SPIN_LIMIT): read, and cleared,
-// at the host's synchronisation points (asdr_synchronize, asdr_update, the status / capture readers).
+// The streaming pipeline's recovery counter (a wave gave up waiting for its neighbour role, the call was re-run on the in-kernel
+// block loop from the snapshot: asdr_kernels.hip "the pipeline as a transaction"): read back at the host's synchronisation points
+// (asdr_synchronize, asdr_update, the status / capture readers).  Results are exact either way; this is only a statistic.
 int check_stream_error(asdr_batch *b) {
   if (!b->stream_launched || !b->d_stream_prog) return 0;
   HIPCHK(hipStreamSynchronize(b->last_stream));
-  uint32_t *word = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1, flag = 0;
-  HIPCHK(hipMemcpy(&flag, word, sizeof flag, hipMemcpyDeviceToHost));
+  uint32_t *word = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1, v[2] = {0, 0};
+  HIPCHK(hipMemcpy(v, word, sizeof v, hipMemcpyDeviceToHost));
   b->stream_launched = false;
-  if (flag) {
-    HIPCHK(hipMemset(word, 0, sizeof flag));
-    return fail("streaming pipeline: a wave timed out waiting for its neighbour role (the results of those calls are invalid)");
-  }
+  b->stat_stream_recoveries = (long)v[1];
+  if (v[0]) return fail("streaming pipeline: error word still set after the recovery launches (internal error)");
   return 0;
 }
 
@@ -549,6 +565,9 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   if (n_channels <= 0 || n_channels > (1 << 20)) { fail("n_channels must be in 1..1048576"); return nullptr; }
   asdr_batch *b = new asdr_batch();
   b->n = n_channels; b->device = device;
+  b->sam_fused = getenv("ASDR_SAM_FUSED") != nullptr;
+  b->sam_split_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;
+  b->stream_pipeline = getenv("ASDR_NO_STREAM_PIPELINE") == nullptr;
   const size_t rows = (size_t)n_channels + 1;
   if (device != ASDR_NO_DEVICE) {
     int ndev = 0;
@@ -565,6 +584,8 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_hil_i, rows * 256 * sizeof(float));
     alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
     alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
+    alloc((void **)&b->d_audio_prev, rows * 128 * sizeof(float));
+    if (ok && hipMemset(b->d_audio_prev, 0, rows * 128 * sizeof(float)) != hipSuccess) ok = false;
     alloc((void **)&b->d_sched, (rows + 32) * sizeof(SlotInfo));   // three sub-ranges, each padded to a whole wave
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
     alloc((void **)&b->d_lo, 2 * sizeof(LoEntry));
@@ -581,6 +602,15 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
       if (ok && hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess) ok = false;
     }
     if (ok && asdr_kernels_upload_tables() != 0) ok = false;
+    if (ok) {
+      // The pipeline's hand-off is measured for one workgroup per compute unit, and its roles wait for each other: 3 w + 1 workgroups
+      // must fit the device at once (occupancy query, not an assumption about the part) and stay within one per compute unit.
+      int cus = 0;
+      const int cap = asdr_stream_capacity(device, &cus);
+      const int wg = cap < cus ? cap : cus;
+      b->stream_max_waves = wg >= 4 ? (wg - 1) / 3 : 0;
+      if (b->stream_max_waves > ASDR_STREAM_MAX_WAVES) b->stream_max_waves = ASDR_STREAM_MAX_WAVES;
+    }
     if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
   }
 
@@ -626,7 +656,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
-                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam};
+                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap};
   for (void *p : ptrs) if (p) hipFree(p);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -701,23 +731,34 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   const bool sam_split = b->sam_split && sam_slots > 0;
   if (sam_split && (size_t)sam_slots > b->xch_sam_slots) {
     HIPCHK(hipStreamSynchronize(stream));
-    if (b->d_xch_sam) HIPCHK(hipFree(b->d_xch_sam));
-    b->xch_sam_slots = (size_t)sam_slots;
-    HIPCHK(hipMalloc(&b->d_xch_sam, b->xch_sam_slots * 2 * ASDR_N * sizeof(float)));
+    float *grown = nullptr;
+    HIPCHK(hipMalloc(&grown, (size_t)sam_slots * 2 * ASDR_N * sizeof(float)));   // (pointer and size change only once this succeeded)
+    if (b->d_xch_sam) hipFree(b->d_xch_sam);
+    b->d_xch_sam = grown; b->xch_sam_slots = (size_t)sam_slots;
   }
   a.xch_sam = sam_split ? b->d_xch_sam : nullptr;
   const bool per_block = n_blocks > 1 && (sam_split || total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES);
-  // Small batch, many blocks, one sub-range of uniform SSB-class waves, no taps: the block pipeline.
-  static const bool no_stream = getenv("ASDR_NO_STREAM_PIPELINE") != nullptr;   // measurement switch (tools/bench_configs.py)
-  if (!no_stream && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN && subs[0].uniform &&
-      b->plain_uniform_ssb && !b->taps_on && subs[0].slots / 8 <= ASDR_STREAM_MAX_WAVES) {
+  // Small batch, many blocks, one sub-range of uniform SSB-class waves, no taps: the block pipeline -- as a transaction: a snapshot of
+  // the state in front of it, and behind it the launches that put the state back and run the call on the in-kernel block loop if a
+  // role's bounded wait fired (asdr_kernels.hip).  3 w + 1 workgroups must be co-resident: w <= stream_max_waves (occupancy query at
+  // asdr_create, at most one workgroup per compute unit).
+  if (b->stream_pipeline && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN && subs[0].uniform &&
+      b->plain_uniform_ssb && !b->taps_on && subs[0].slots / 8 <= b->stream_max_waves) {
     const int w = subs[0].slots / 8;
-    if (!b->d_xch_a) {
-      HIPCHK(hipMalloc(&b->d_xch_a, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * 2 * ASDR_N * sizeof(float)));
-      HIPCHK(hipMalloc(&b->d_xch_b, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)));
-      HIPCHK(hipMalloc(&b->d_stream_prog, (size_t)(3 * ((b->n + 7) / 8) + 2) * sizeof(uint32_t)));   // [+1] = the persistent error word
-      HIPCHK(hipMemsetAsync(b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1, 0, sizeof(uint32_t), stream));
-      HIPCHK(hipMalloc(&b->d_lo_ring, ASDR_LO_RING * sizeof(LoEntry)));
+    if (!b->d_xch_a) {   // first use: every buffer, or none (a failed allocation leaves the batch on the other launch forms)
+      float *xa = nullptr, *xb = nullptr; uint32_t *prog = nullptr; LoEntry *ring = nullptr; void *snap = nullptr;
+      const size_t n_prog = (size_t)(3 * ((b->n + 7) / 8) + 3);   // [.. + 1] = the error word, [.. + 2] = the recovery counter
+      bool ok = hipMalloc(&xa, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * 2 * ASDR_N * sizeof(float)) == hipSuccess &&
+                hipMalloc(&xb, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)) == hipSuccess &&
+                hipMalloc(&prog, n_prog * sizeof(uint32_t)) == hipSuccess &&
+                hipMalloc(&ring, ASDR_LO_RING * sizeof(LoEntry)) == hipSuccess &&
+                hipMalloc(&snap, (size_t)ASDR_STREAM_MAX_WAVES * 8 * ASDR_SNAP_BYTES) == hipSuccess &&
+                hipMemsetAsync(prog, 0, n_prog * sizeof(uint32_t), stream) == hipSuccess;
+      if (!ok) {
+        for (void *p : {(void *)xa, (void *)xb, (void *)prog, (void *)ring, snap}) if (p) hipFree(p);
+        return fail("streaming pipeline: out of device memory for its exchange rings");
+      }
+      b->d_xch_a = xa; b->d_xch_b = xb; b->d_stream_prog = prog; b->d_lo_ring = ring; b->d_stream_snap = snap;
     }
     HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));   // stream-ordered behind the previous launch
     a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
@@ -725,9 +766,17 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; }
     a.lo_write = 0u;
     a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_err = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1;
-    a.stream_waves = w; a.lo_ring = b->d_lo_ring;
+    a.stream_waves = w; a.lo_ring = b->d_lo_ring; a.stream_spin_limit = b->stream_spin_limit;
     if (e0) HIPCHK(hipEventRecord(e0, stream));
+    if (asdr_launch_stream_snapshot(&a, b->d_stream_snap, 0, stream) != 0) return fail("stream snapshot launch failed");
     if (asdr_launch_stream(&a, stream) != 0) return fail("stream kernel launch failed");
+    if (asdr_launch_stream_snapshot(&a, b->d_stream_snap, 1, stream) != 0) return fail("stream restore launch failed");
+    {   // the same call on the in-kernel block loop, gated on the error word: its waves return at once when the pipeline completed
+      UpdateArgs f = a;
+      f.run_if = a.stream_err; f.stream_waves = 0; f.xch_a = nullptr; f.xch_b = nullptr; f.stream_prog = nullptr; f.lo_ring = nullptr;
+      if (asdr_launch_update(&f, ASDR_KERNEL_PLAIN, 1, stream) != 0) return fail("stream fallback launch failed");
+    }
+    if (asdr_launch_stream_ack(a.stream_err, stream) != 0) return fail("stream acknowledge launch failed");
     if (e1) HIPCHK(hipEventRecord(e1, stream));
     b->stream_launched = true; b->stat_stream_launches++;
     b->ev_last_valid = true;
@@ -1110,6 +1159,38 @@ unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]) {
 }
 
 long asdr_stream_pipeline_launches(asdr_batch_t *b) { return b ? b->stat_stream_launches : -1; }
+long asdr_stream_pipeline_recoveries(asdr_batch_t *b) {
+  if (!b) return -1;
+  if (b->device != ASDR_NO_DEVICE && b->stream_launched) { if (hipSetDevice(b->device) != hipSuccess || check_stream_error(b) != 0) return -1; }
+  return b->stat_stream_recoveries;
+}
+int asdr_stream_pipeline_max_groups(asdr_batch_t *b) { return b ? b->stream_max_waves : -1; }
+int asdr_set_stream_pipeline(asdr_batch_t *b, int on) { if (!b) return fail("null batch"); b->stream_pipeline = on != 0; return 0; }
+int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels) {
+  if (!b) return fail("null batch");
+  b->sam_fused = fused != 0;
+  b->sam_split_min = split_min_channels > 0 ? split_min_channels : ASDR_SAM_SPLIT_MIN_CHANNELS;
+  b->sched_dirty = true;
+  return 0;
+}
+int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls) {
+  if (!b) return fail("null batch");
+  b->stream_spin_limit = polls ? polls : ASDR_STREAM_SPIN_LIMIT;
+  return 0;
+}
+
+int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on) {
+  if (!b) return fail("null batch");
+  const bool want = on != 0;
+  if (want && !b->exact_unknown_mode && b->device != ASDR_NO_DEVICE) {   // rows not kept meanwhile: silence until a block stores them again
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->last_stream));
+    HIPCHK(hipMemset(b->d_audio_prev, 0, ((size_t)b->n + 1) * 128 * sizeof(float)));
+  }
+  b->exact_unknown_mode = want;
+  return 0;
+}
+int asdr_get_exact_unknown_mode(asdr_batch_t *b) { return b ? (b->exact_unknown_mode ? 1 : 0) : -1; }
 
 int asdr_schedule_layout(asdr_batch_t *b, int out[8]) {
   if (!b || !out) return fail("null argument");

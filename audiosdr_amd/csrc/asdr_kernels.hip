@@ -603,11 +603,15 @@ __device__ __forceinline__ void asdr_stream_fir_helper(const UpdateArgs &a, floa
 // CU's stores never refresh).  One wave per workgroup, one workgroup per CU (the host caps the pipeline at 3 x waves <= 255).
 // Spin-wait until *p >= target (all lanes read the same word); false = gave up (error flag set, see ASDR_STREAM_SPIN_LIMIT).
 // Returns the counter value it saw (>= target; the caller keeps it: a producer that is several blocks ahead is polled once).
-__device__ __forceinline__ uint32_t stream_wait(const uint32_t *p, uint32_t target, uint32_t *err) {
+// ASDR_STREAM_FAIL = this wave gave up after `limit` polls (it sets the launch's error word), or another wave had (the word is
+// looked at every 64 polls): the caller leaves its block loop -- the host has a snapshot of the state and re-runs the call.
+__device__ __forceinline__ uint32_t stream_wait(const uint32_t *p, uint32_t target, uint32_t *err, uint32_t limit) {
   uint32_t spins = 0, v;
   while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > ASDR_STREAM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = target; break; }
+    ++spins;
+    if (spins > limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = ASDR_STREAM_FAIL; break; }
+    if ((spins & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { v = ASDR_STREAM_FAIL; break; }
   }
   asm volatile("" ::: "memory");   // no load of the handed-off rows may be moved in front of the poll
   return v;
@@ -638,6 +642,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // behind it.  The IF rows cross in xch_sam; the lock flag in the status word.
   constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5), DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5);
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
+  if (ROLE == 0 && a.run_if != nullptr && *a.run_if == 0u) return;   // the pipeline's fallback launch: nothing to do unless the pipeline gave up
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
   // this wave's index in the launched schedule sub-range (the streaming pipeline launches its three roles one after the other)
   const int wave_g = STREAM ? (int)blockIdx.x % a.stream_waves : (int)blockIdx.x * WAVES + wave;
@@ -690,8 +695,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const uint32_t b1 = (uint32_t)blk + 1u, freed = (blk >= ASDR_STREAM_DEPTH) ? (uint32_t)(blk - ASDR_STREAM_DEPTH + 1) : 0u;
       const bool need_in = (ROLE != 1) && seen_in < b1, need_free = (ROLE != 3) && seen_free < freed;
       if ((need_in || need_free) && sig_pending) { stream_signal(my_prog, sig_pending, lane); sig_pending = 0u; }   // publish before blocking
-      if (need_in) seen_in = stream_wait(prog + (ROLE - 2) * a.stream_waves + wave_g, b1, err);       // the previous role has stored block blk
-      if (need_free) seen_free = stream_wait(prog + ROLE * a.stream_waves + wave_g, freed, err);      // the next role has left slot blk % DEPTH
+      if (need_in) { seen_in = stream_wait(prog + (ROLE - 2) * a.stream_waves + wave_g, b1, err, a.stream_spin_limit); if (seen_in == ASDR_STREAM_FAIL) break; }   // the previous role has stored block blk
+      if (need_free) { seen_free = stream_wait(prog + ROLE * a.stream_waves + wave_g, freed, err, a.stream_spin_limit); if (seen_free == ASDR_STREAM_FAIL) break; }   // the next role has left slot blk % DEPTH
     }
     const ChanParams *Pp = row_ptr(a.params, (uint32_t)ch * (uint32_t)sizeof(ChanParams));
     ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
@@ -740,7 +745,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     uint32_t lo_kp, lo_ki;
     float lo_end;
     if (ROLE == 2) {
-      if (seen_lo < (uint32_t)blk + 1u) seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves, (uint32_t)blk + 1u, a.stream_err);
+      if (seen_lo < (uint32_t)blk + 1u) { seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves, (uint32_t)blk + 1u, a.stream_err, a.stream_spin_limit); if (seen_lo == ASDR_STREAM_FAIL) break; }
       v4f key;
       asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(key) : "v"(lo_rd) : "memory");
       lo_kp = __float_as_uint(key[0]); lo_ki = __float_as_uint(key[1]); lo_end = key[2];
@@ -1486,9 +1491,19 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         store8(L + W0 + kA + 64 * h, vq);
       }
     }
-    if (ROLE == 0 && !is_ssb && !is_am && mode != ASDR_SAMmode) {   // unknown mode: the reference re-processes stale audio; we emit silence
-      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      store8(L + W0 + kA, z); store8(L + W0 + kA + 64, z);
+    if (ROLE == 0 && !is_ssb && !is_am && mode != ASDR_SAMmode) {
+      // Unknown mode value: neither demodulator branch runs (AudioSDR.cpp:84, 122), _audioOut still holds what the PREVIOUS block
+      // left in it -- its audio after the audio filter, AGC and ALS -- and those stages now process it again (:149-161).  The row
+      // comes back from HBM (every block stores it, below).  Without the row (asdr_set_exact_unknown_mode(b, 0)): silence.
+      float z[16];
+      DEFINE_ALL_PATHS(z, 16);
+      if (a.audio_prev != nullptr) {
+        const float *ap = row_ptr(a.audio_prev, (uint32_t)ch * 512u + 4u * (uint32_t)kF);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load4(ap + 32 * m, z + 4 * m);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) store4(L + W0 + kF + 32 * m, z + 4 * m);
     }
     WAVE_SYNC();
     TL(10);
@@ -1804,6 +1819,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
       }
     }
+    if (DO3 && valid && a.audio_prev != nullptr) {   // _audioOut as this block leaves it: what an unknown mode value would re-process
+      float *ap = row_ptr(a.audio_prev, (uint32_t)ch * 512u + 4u * (uint32_t)kF);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { float t[4]; load4(L + W0 + kF + 32 * m, t); store4(ap + 32 * m, t); }
+    }
     {
       // ---- output, AudioSDR.cpp:158-161: float product, x 32767.0 in binary64, truncate, wrap to int16 ------
       const float og = P.output_gain;
@@ -1964,6 +1984,7 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
   const bool up = !(inc < 0.0f);
   const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
   const uint32_t flip = up ? 0u : 0x80000000u;
+  bool gave_up = false;
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
     if (blk >= ASDR_LO_RING) {   // every role-2 wave has left the entry this block overwrites
@@ -1974,9 +1995,11 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
         for (int w = lane; w < a.stream_waves; w += 64) { const uint32_t v = __hip_atomic_load(prog + a.stream_waves + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mn = v < mn ? v : mn; }
         if (__all(mn >= need)) break;
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > ASDR_STREAM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (++spins > a.stream_spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); gave_up = true; break; }
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; break; }
       }
       asm volatile("" ::: "memory");
+      if (gave_up) break;
     }
     LoEntry *e = a.lo_ring + (blk % ASDR_LO_RING);
     const float start = phase;
@@ -2026,6 +2049,67 @@ extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
   hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves + 1), dim3(128), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// How many workgroups of the pipeline kernel the device can hold at once (occupancy x compute units): the pipeline's roles wait
+// for each other, so all 3 W + 1 of them must be resident together.  -1 = the runtime could not tell.
+extern "C" int asdr_stream_capacity(int device, int *compute_units) {
+  int per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, asdr_stream_kernel, 128, 0) != hipSuccess) return -1;
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return per_cu * prop.multiProcessorCount;
+}
+
+// ---- the pipeline as a transaction ---------------------------------------------------------------------------------------
+// A pipeline call advances its channels' state block by block across three roles; if a role's bounded wait ever fires (the
+// roles were not co-resident: a shared GPU, masked CUs) the state is left part-way.  So the host brackets the launch:
+//   asdr_stream_snapshot_kernel   copies the rows the call will advance (ASDR_SNAP_BYTES per channel) aside
+//   asdr_stream_kernel            the pipeline; on a timeout it sets stream_err[0] and every wave leaves
+//   asdr_stream_restore_kernel    stream_err[0] != 0: copies the rows back
+//   asdr_update_kernel (run_if)   stream_err[0] != 0: the same call on the in-kernel block loop (no inter-workgroup waits)
+//   asdr_stream_ack_kernel        stream_err[0] != 0: counts the recovery in stream_err[1], clears stream_err[0]
+// all on the caller's stream, so that whatever the caller enqueues next sees exact results either way.
+// One workgroup per group of 8 schedule slots; snap = [slot][ASDR_SNAP_BYTES / 16] uint4.
+template <bool RESTORE>
+__device__ __forceinline__ void stream_snapshot_body(const UpdateArgs &a, uint4 *snap) {
+  if (RESTORE && *a.stream_err == 0u) return;
+  const int t = threadIdx.x;   // 256 threads
+  for (int j = 0; j < 8; ++j) {
+    const int slot = (int)blockIdx.x * 8 + j;
+    if (slot >= a.n_sched) return;
+    const int ch = (a.direct_ch0 >= 0) ? a.direct_ch0 + slot : a.sched[slot].ch;
+    if (ch >= a.n_channels) continue;
+    uint4 *dst = snap + (size_t)slot * (ASDR_SNAP_BYTES / 16);
+    // piece p of the channel's snapshot row: which array, which 16-byte piece of the channel's row in it
+    for (int p = t; p < ASDR_SNAP_BYTES / 16; p += 256) {
+      uint4 *row; int q = p;
+      if (q < 28) row = reinterpret_cast<uint4 *>(a.small + ch);
+      else if ((q -= 28) < 96) row = reinterpret_cast<uint4 *>(a.nb_hist + (size_t)ch * 768);
+      else if ((q -= 96) < ASDR_NB_MASK_ROW / 16) row = reinterpret_cast<uint4 *>(a.nb_mask + (size_t)ch * ASDR_NB_MASK_ROW);
+      else if ((q -= ASDR_NB_MASK_ROW / 16) < 64) row = reinterpret_cast<uint4 *>(a.hil_q + (size_t)ch * 256);
+      else if ((q -= 64) < 64) row = reinterpret_cast<uint4 *>(a.hil_i + (size_t)ch * 256);
+      else { q -= 64; row = a.audio_prev ? reinterpret_cast<uint4 *>(a.audio_prev + (size_t)ch * 128) : nullptr; }
+      if (row == nullptr) continue;
+      if (RESTORE) row[q] = dst[p]; else dst[p] = row[q];
+    }
+  }
+}
+extern "C" __global__ __launch_bounds__(256) void asdr_stream_snapshot_kernel(UpdateArgs a, uint4 *snap) { stream_snapshot_body<false>(a, snap); }
+extern "C" __global__ __launch_bounds__(256) void asdr_stream_restore_kernel(UpdateArgs a, uint4 *snap) { stream_snapshot_body<true>(a, snap); }
+extern "C" __global__ void asdr_stream_ack_kernel(uint32_t *err) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && err[0] != 0u) { err[1] += 1u; err[0] = 0u; }
+}
+extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int restore, hipStream_t stream) {
+  const int groups = a->n_sched / 8;
+  if (groups <= 0) return 0;
+  if (restore) hipLaunchKernelGGL(asdr_stream_restore_kernel, dim3(groups), dim3(256), 0, stream, *a, reinterpret_cast<uint4 *>(snap));
+  else hipLaunchKernelGGL(asdr_stream_snapshot_kernel, dim3(groups), dim3(256), 0, stream, *a, reinterpret_cast<uint4 *>(snap));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream) {
+  hipLaunchKernelGGL(asdr_stream_ack_kernel, dim3(1), dim3(64), 0, stream, err);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 // ---- state (re-)initialisation kernel: applies ChanParams.reset bits, one thread per (channel, word) ------
 extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset_bits, int first_row, int n_rows) {
@@ -2041,6 +2125,7 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
     for (int i = t; i < (int)(sizeof(ChanSmall) / 4); i += 128) w[i] = 0u;
     a.hil_i[(size_t)ch * 256 + t] = 0.0f; a.hil_i[(size_t)ch * 256 + 128 + t] = 0.0f;
     a.hil_q[(size_t)ch * 256 + t] = 0.0f; a.hil_q[(size_t)ch * 256 + 128 + t] = 0.0f;
+    if (a.audio_prev != nullptr) a.audio_prev[(size_t)ch * 128 + t] = 0.0f;   // _audioOut: static storage, zero before the first block
   }
   __syncthreads();
   if (all && t == 0) { S->nb_avg = 10.0f; S->status = ASDR_S_AGC_ACTIVE; }   // AudioSDR.h:242, :230

@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s through the full SSB demod chain, batched 128-sample blocks (BASELINE.json).
 
-Workload at every N (weak scaling; channels shard embarrassingly, no collective):
+Default workload (`--config c2`, weak scaling: channels shard embarrassingly, no collective):
   SURVEY.md 8d config C2 per GPU: 65,536 independent channels x one 128-sample block per step,
   USB demodulation, noise blanker on (default threshold 1.2), IF band-pass, complex mixer,
   257-tap Hilbert, audio IIR filter enabled (bw2700), AGC default, ALS off.
   int16 I/Q rows and the int16 audio rows are resident in HBM before the timed region.
 A "step" is one asdr_update_device() call = one pass of the hot path over the whole batch.
+
+The other two BASELINE configs that need more than one GPU are selectable, so that the driver's one command covers them
+(strong scaling: the job is fixed, --gpus N ranks each take 1/N of its channels):
+  --config c4   1,048,576 channels in all, mode = channel mod 7 (LSB, USB, CW_LSB, CW_USB, AM, SAM, WSPR), ALS notch on,
+                blanker at 10 dB; one block per step
+  --config c5   4,096 WSPR receivers in all (EXTRAS/BareBonesWSPR/BareBonesWSPR.ino:87-102 settings); one step = one
+                646-block call (1/64 of a 2-minute slot) appended to the capture sink
 
 Launching:
   python bench.py --gpus N ...            N > 1 without a distributed launcher: this process starts
@@ -16,11 +23,16 @@ Launching:
   A launcher whose WORLD_SIZE differs from --gpus is an error (exit 2), never a silently mislabelled line.
   --dry-run: no GPU and no HIP library: gloo backend, the timed loop is empty; checks the launch / reduce / JSON plumbing.
 
+Warm-up: the GPU's clocks need ~0.2 s of work to settle after idle (the first ~500 launches of C2 run ~3 % slower, a 20-step
+run right after start-up ~10 %).  `--settle S` (default 1500 for c2 / c4, 4 for c5) asks for at least S untimed steps in front of
+the timed region whatever `--warmup` says; the JSON's `warmup` is the number of untimed steps that REALLY preceded the timed
+region, `config.warmup_requested` what the command line asked for.  `--settle 0` honours `--warmup` to the letter.
+
 Prints ONE JSON line (rank 0).  `value` = samples processed by all ranks / max-over-ranks wall time.
-`roofline` is for the single kernel of the path (asdr_update_kernel): algorithmic bytes per launch
-(10,520 B per channel-block: SURVEY.md 8d) / its mean duration from HIP events recorded on the launch
-stream around every launch of the timed region.  `cpu_baseline` is the CPU oracle (a port, the reference
-is unbuildable here) timed on this host on a bounded sample of the same workload.
+`roofline` is for the dominant kernel of the config: algorithmic bytes per step / the mean duration of a step
+from ONE HIP-event pair recorded on the launch stream around the timed region.  `robustness` (c2, N = 1): the same 65,536-channel
+chain on adverse inputs / settings that defeat its data-dependent fast paths, measured the same way after the headline region.
+`cpu_baseline` is the CPU oracle (a port, the reference is unbuildable here) timed on this host on a bounded sample of C2.
 """
 import argparse
 import json
@@ -33,13 +45,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CHANNELS_PER_GPU = 65536
 BLOCK = 128
-ALGO_BYTES_PER_BLOCK = 10520          # 768 I/O + 96 params + 2 x 4828 carried state (C2)
-ALGO_READ_BYTES_PER_BLOCK = 5436      # HBM-read share of the above
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_INPUT_BLOCKS = 4                    # distinct resident input blocks cycled through by the steps
 PMC_FILE = os.path.join("profiles", "pmc_latest.json")
+
+# ---- algorithmic bytes per channel-block, SURVEY.md 8d (minimal carried state read AND written once per block at T = 1) ----
+B_IO, B_PARAMS = 768, 96
+ST_NB, ST_IF, ST_PHASE, ST_HILBERT, ST_IMG, ST_PLL, ST_AF, ST_AGC, ST_ALS = 3076, 128, 4, 1536, 128 + 4 + 4, 40, 64, 20, 450
+C2_STATE = ST_NB + ST_IF + ST_PHASE + ST_HILBERT + ST_AF + ST_AGC                         # 4828
+ALGO_BYTES_PER_BLOCK = B_IO + B_PARAMS + 2 * C2_STATE                                    # 10,520
+ALGO_READ_BYTES_PER_BLOCK = 512 + B_PARAMS + C2_STATE                                    # 5,436: the HBM-read share
+_C4_SSB = ST_NB + ST_IF + ST_PHASE + ST_HILBERT + ST_AGC + ST_ALS                        # 5 of 7 channels
+_C4_AM = ST_NB + ST_IF + ST_IMG + ST_AGC + ST_ALS
+_C4_SAM = ST_NB + ST_IF + ST_PLL + ST_IMG + ST_AGC + ST_ALS
+C4_ALGO_BYTES_PER_BLOCK = B_IO + B_PARAMS + 2.0 * (5 * _C4_SSB + _C4_AM + _C4_SAM) / 7.0  # 10,501.1 on average
+C5_T = 646                                                                               # blocks per call: 64 calls = one 2-minute slot
+C5_STATE = ST_IF + ST_PHASE + ST_HILBERT + ST_AGC                                        # 1688 (blanker, audio filter off)
+C5_ALGO_BYTES_PER_BLOCK = (B_IO * C5_T + B_PARAMS + 2.0 * C5_STATE) / C5_T                # 773.4
+
+CONFIGS = {
+    # name: (channels of the whole job or per GPU, scaling, blocks per step, default settle steps)
+    "c2": dict(channels=65536, per_gpu=True, scaling="weak", blocks=1, settle=1500, algo=ALGO_BYTES_PER_BLOCK,
+               kernel="asdr_update_kernel"),
+    "c4": dict(channels=1048576, per_gpu=False, scaling="strong", blocks=1, settle=300, algo=C4_ALGO_BYTES_PER_BLOCK,
+               kernel="asdr_update_kernel_als_small (+ the SAM pre | PLL | post launches and the remainders' launch beside it)"),
+    "c5": dict(channels=4096, per_gpu=False, scaling="strong", blocks=C5_T, settle=4, algo=C5_ALGO_BYTES_PER_BLOCK,
+               kernel="asdr_stream_kernel"),
+}
+CHANNELS_PER_GPU = CONFIGS["c2"]["channels"]
 
 
 def configure_c2(sdr):
@@ -47,7 +81,56 @@ def configure_c2(sdr):
     sdr.enableAudioFilter()    # bw2700 from init(); NB + AGC are on by default
 
 
-SETTLE_LAUNCHES = 1500    # untimed launches in front of the timed region (>= --warmup): clocks settled, see main()
+def configure_c4(sdr, lib=None, channel0=0):
+    """mode = (global channel index) mod 7, ALS notch (defaults M 55 / lambda 0.5 / delay 3), blanker threshold 10 dB."""
+    n = sdr.n_channels
+    if lib is not None:
+        for c in range(n):
+            lib.asdr_setDemodMode(sdr._h, c, (channel0 + c) % 7)
+    else:
+        for c in range(n):
+            sdr.setDemodMode((channel0 + c) % 7, ch=c)
+    sdr.enableALSfilter(); sdr.setNoiseBlankerThresholdDb(10.0)
+
+
+def configure_c5(sdr):   # BareBonesWSPR.ino:87-102,129
+    sdr.enableAGC(); sdr.setAGCmode(2); sdr.disableALSfilter(); sdr.disableNoiseBlanker(); sdr.setNoiseBlankerThresholdDb(10.0)
+    sdr.setInputGain(1.0); sdr.setOutputGain(0.5); sdr.setIQgainBalance(1.020); sdr.setAudioFilter(2); sdr.setDemodMode(6); sdr.setMute(0)
+
+
+# ---- the adverse cases of the `robustness` object (each defeats one of the C2 kernel's data- / settings-dependent fast paths) ----
+ROBUSTNESS_CASES = {
+    "divergent_mixer_phases": dict(phases=True, agc=False, impulses=False,
+        what="every wave holds 8 channels with 8 DIFFERENT mixer phases (channel c switched LSB -> USB after c mod 8 blocks): the "
+             "local-oscillator cache and the wave-uniform mixer both miss; every lane runs its own 2 x 16 sin/cos lookups"),
+    "agc_general_form": dict(phases=False, agc=True, impulses=False,
+        what="AGC hang time 0 and noise-like audio (tone 0.05 under noise 0.2): the envelope releases between peaks and attacks "
+             "again, every 8-sample chunk takes the AGC's general per-sample form (no hanging-chunk / attack-only fast form)"),
+    "impulse_every_block": dict(phases=False, agc=False, impulses=True,
+        what="an impulse in every block of every channel: the blanker's general path (counts, mask decode / zero / ramp / encode)"),
+    "all_three": dict(phases=True, agc=True, impulses=True, what="the three together"),
+}
+
+
+def stagger_divergent_phases(batch, step_one_block, lib=None, oracles=None):
+    """Leaves the batch in USB mode with 8 different mixer phases in every wave: all channels start in LSB; before block j
+    (j = 0..7) the channels with c mod 8 == j switch to USB (AudioSDR.cpp:187-222: the mixer phase is kept, the increment
+    changes), so channel c has accumulated (c mod 8) blocks of the LSB increment.  `step_one_block(j)` runs block j."""
+    n = batch.n_channels
+    batch.setDemodMode(0)
+    for o in (oracles or []):
+        o.setDemodMode(0)
+    for j in range(8):
+        if lib is not None:
+            for c in range(j, n, 8):
+                lib.asdr_setDemodMode(batch._h, c, 1)
+        else:
+            for c in range(j, n, 8):
+                batch.setDemodMode(1, ch=c)
+        for c, o in enumerate(oracles or []):
+            if c % 8 == j:
+                o.setDemodMode(1)
+        step_one_block(j)
 
 
 def cpu_info():
@@ -132,15 +215,92 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def tiled_input(np, torch, dev, n_ch, n_blocks, uniq, channel0=0, per_block=True, **sig):
+    """`uniq` distinct channels generated (audiosdr_amd/synth.py) and tiled over n_ch; resident tensors, one [n_ch][128] pair per
+    block (per_block) or one [n_ch][n_blocks][128] pair."""
+    from audiosdr_amd.synth import make_iq
+    uniq = max(8, min(uniq, n_ch))
+    I, Q = make_iq(uniq, n_blocks, channel0=channel0, **sig)
+    reps = (n_ch + uniq - 1) // uniq
+    if per_block:
+        dI = [torch.from_numpy(np.ascontiguousarray(I[:, b])).to(dev).repeat(reps, 1)[:n_ch].contiguous() for b in range(n_blocks)]
+        dQ = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).to(dev).repeat(reps, 1)[:n_ch].contiguous() for b in range(n_blocks)]
+        return dI, dQ
+    dI = torch.from_numpy(I).to(dev).repeat(reps, 1, 1)[:n_ch].contiguous()
+    dQ = torch.from_numpy(Q).to(dev).repeat(reps, 1, 1)[:n_ch].contiguous()
+    return dI, dQ
+
+
+def measure_region(batch, step, stream, warm, timed):
+    """`warm` untimed steps, then ONE HIP-event pair (recorded by the library on the launch stream) around `timed` steps.
+    Returns milliseconds per step."""
+    import torch
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    batch.region_timing_begin(stream)
+    for i in range(timed):
+        step(i)
+    ms, calls = batch.region_timing_end()
+    return ms / max(1, calls)
+
+
+def robustness(np, torch, dev, local_rank, n_ch, stream, timed):
+    """The C2 chain (65,536 channels, USB + blanker + audio filter + AGC) on the adverse cases of ROBUSTNESS_CASES: same kernel,
+    same event-pair method as the headline region, >= 200 timed launches each after the case's own warm-up."""
+    import audiosdr_amd as A
+    L = A.load_library()
+    out = {}
+    dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
+    for name, c in ROBUSTNESS_CASES.items():
+        sig = dict(fc=6290.0, A=0.25)
+        if c["agc"]:
+            sig.update(A=0.05, noise=0.2)
+        if c["impulses"]:
+            sig.update(impulse_every=128)     # sample 64 of every block
+        dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, **sig)
+        batch = A.AudioSDRBatch(n_ch, device=local_rank)
+
+        def step(i, batch=batch, dI=dI, dQ=dQ):
+            b = i % N_INPUT_BLOCKS
+            batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, stream)
+
+        if c["phases"]:
+            stagger_divergent_phases(batch, step, lib=L)
+        configure_c2(batch)
+        if c["agc"]:
+            batch.setAGChangTime(0.0)
+        ms = measure_region(batch, step, stream, 120, timed)   # 120 blocks: the blanker's average and the AGC have settled
+        st = batch.read_status()
+        ach = ALGO_BYTES_PER_BLOCK * n_ch / (ms * 1e-3) / 1e9
+        out[name] = {"kernel_ms": round(ms, 5), "frac": round(ach / HBM_PEAK_GBS, 4), "Msamples_per_s": round(n_ch * BLOCK / ms / 1e3, 1),
+                     "launches_timed": timed, "channels_with_blanker_detection": int(st["nb_detected"].sum()), "what": c["what"]}
+        batch.close()
+        del dI, dQ
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)   # 2000 x ~0.14 ms: long enough for the clocks to settle (the first ~500 launches after idle run ~3 % slower)
-    ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--channels", type=int, default=CHANNELS_PER_GPU, help="channels per GPU (default = C2)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 2000; c5: 16 calls of 646 blocks)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front of the timed region (default = --settle)")
+    ap.add_argument("--settle", type=int, default=None,
+                    help="at least this many untimed steps precede the timed region whatever --warmup says (clock settling; "
+                         "default 1500 for c2, 300 for c4, 4 for c5); 0 = honour --warmup to the letter")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-robustness", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo, empty timed loop (tests the launch plumbing)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 16 if args.config == "c5" else 2000
+    settle_min = cfg["settle"] if args.settle is None else args.settle
+    warm_req = args.warmup
+    if args.warmup is None:
+        args.warmup = settle_min
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not launched and args.gpus > 1:
@@ -168,28 +328,47 @@ def main():
     elif not args.dry_run:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
-    n_ch = args.channels
+
+    # this rank's shard of the job: a contiguous channel range (audiosdr_amd/sharding.py), no data-path collective
+    from audiosdr_amd.sharding import shard_range
+    if args.channels is not None:
+        n_ch, ch0, total_ch = args.channels, rank * args.channels, world * args.channels
+    elif cfg["per_gpu"]:
+        n_ch, ch0, total_ch = cfg["channels"], rank * cfg["channels"], world * cfg["channels"]
+    else:
+        lo, hi = shard_range(cfg["channels"], rank, world)
+        n_ch, ch0, total_ch = hi - lo, lo, cfg["channels"]
+    T = cfg["blocks"]
 
     batch = None
+    stream = None
     if not args.dry_run:
         import audiosdr_amd as A
-        from audiosdr_amd.synth import make_iq
-        # this rank's shard of the job: channels [rank*n_ch, (rank+1)*n_ch); a quarter is generated and tiled
-        uniq = max(8, n_ch // 4)
-        I, Q = make_iq(uniq, N_INPUT_BLOCKS, fc=6290.0, A=0.25, channel0=rank * n_ch)
-        reps = (n_ch + uniq - 1) // uniq
-        I = np.tile(I, (reps, 1, 1))[:n_ch]
-        Q = np.tile(Q, (reps, 1, 1))[:n_ch]
-        # resident layout per step: [channel][1 block][128]
-        dI = [torch.from_numpy(np.ascontiguousarray(I[:, b])).to(dev) for b in range(N_INPUT_BLOCKS)]
-        dQ = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).to(dev) for b in range(N_INPUT_BLOCKS)]
-        dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
-        batch = A.AudioSDRBatch(n_ch, device=local_rank)
-        configure_c2(batch)
         stream = torch.cuda.current_stream().cuda_stream
+        batch = A.AudioSDRBatch(n_ch, device=local_rank)
+        if args.config == "c2":
+            dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, channel0=ch0, fc=6290.0, A=0.25)
+            configure_c2(batch)
+        elif args.config == "c4":
+            # 3584 distinct input channels tiled over the shard (the input does not depend on the mode; the mode is (global channel) mod 7)
+            dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, 3584, channel0=ch0 % 3584, fc=6890.0 - 300, A=0.3, m=0.4,
+                                 f2=7500.0, a2=0.15)
+            configure_c4(batch, lib=A.load_library(), channel0=ch0)
+        else:
+            dI, dQ = tiled_input(np, torch, dev, n_ch, T, n_ch, channel0=ch0, per_block=False, fc=6890.0, A=0.02, noise=0.05)
+            configure_c5(batch)
+            batch.capture_open(T * 4)         # the sink is rewound every 4 calls: the bench keeps 4 calls' worth, not a whole slot
+        if args.config != "c5":
+            dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
 
     def step(i):
-        if batch is not None:
+        if batch is None:
+            return
+        if args.config == "c5":
+            if batch.capture_position + T > batch.capture_capacity:
+                batch.capture_rewind()
+            batch.capture_update_device(dI.data_ptr(), dQ.data_ptr(), T, None, stream)
+        else:
             b = i % N_INPUT_BLOCKS
             batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, stream)
 
@@ -201,17 +380,13 @@ def main():
         if not args.dry_run:
             torch.cuda.synchronize()
 
-    # The GPU's clocks need ~0.2 s of work to settle after idle (the first ~500 launches run ~3 % slower, a 20-step run right
-    # after start-up ~10 %): whatever --warmup says, at least SETTLE_LAUNCHES untimed launches precede the timed region.  The
-    # timed region is exactly --steps launches.
-    settle = max(0, SETTLE_LAUNCHES - args.warmup) if batch is not None else 0
-    for i in range(settle):
-        step(i)
-    for i in range(args.warmup):
+    # untimed steps: what --warmup asks for, topped up to --settle (see the module docstring); reported as `warmup`
+    untimed = max(args.warmup, settle_min) if batch is not None else args.warmup
+    for i in range(untimed):
         step(i)
     fence()
-    # Kernel time: ONE HIP-event pair, recorded by the library on the launch stream, around the K launches of the timed region;
-    # kernel_ms = elapsed / K = the average time per back-to-back launch, gaps between the kernels included.  (A pair around
+    # Kernel time: ONE HIP-event pair, recorded by the library on the launch stream, around the K steps of the timed region;
+    # kernel_ms = elapsed / K = the average time per back-to-back step, gaps between the kernels included.  (A pair around
     # every launch puts two more packets between consecutive kernels: it slows the job by ~5 % and measures its own overhead;
     # that per-launch figure is taken AFTER the timed region, from 40 further launches, and reported beside it.)
     fence()
@@ -225,9 +400,9 @@ def main():
     fence()
     t1 = time.perf_counter()
     wall = t1 - t0
-    kernel_ms = [region_ms / max(1, region_calls)] if batch is not None else [0.0]
+    k_ms = region_ms / max(1, region_calls) if batch is not None else 0.0
     pair_ms = None
-    if batch is not None:
+    if batch is not None and args.config == "c2":
         batch.kernel_timing_begin(40)
         for i in range(40):
             step(i)
@@ -236,18 +411,19 @@ def main():
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
+    pipeline_calls = batch.stream_pipeline_launches() if batch is not None else None
 
     if rank == 0:
-        samples = float(world) * n_ch * BLOCK * args.steps
-        k_ms = float(np.mean(kernel_ms))
-        ach = ALGO_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        samples = float(total_ch) * T * BLOCK * args.steps
+        algo = cfg["algo"] * n_ch * T                      # this rank's algorithmic bytes per step
+        ach = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM bytes per launch: NOT measured in this run -- copied from the committed rocprofv3 PMC passes of this same command
-        # (tools/prof_pmc.sh); dropped when that file was taken from a different build of the library
+        # (tools/prof_pmc2.sh); dropped when that file was taken from a different build of the library
         traffic, traffic_source = None, None
         try:
             with open(os.path.join(ROOT, PMC_FILE)) as f:
                 pj = json.load(f)
-            if n_ch == CHANNELS_PER_GPU and not args.dry_run:
+            if args.config == "c2" and n_ch == CHANNELS_PER_GPU and not args.dry_run:
                 import audiosdr_amd as A
                 from audiosdr_amd import build as _build
                 same_binary = pj.get("library_sha256") == A.library_sha256()
@@ -260,27 +436,52 @@ def main():
                     traffic_source = "%s is from another build of the library: dropped" % PMC_FILE
         except Exception:
             pass
+        workload = {
+            "c2": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
+            "c4": "C4: mixed modes (channel mod 7: LSB, USB, CW_LSB, CW_USB, AM, SAM, WSPR) + ALS notch + blanker at 10 dB, %d channels "
+                  "in all over %d GPU(s) = %d on this one, 1 block/step" % (total_ch, world, n_ch),
+            "c5": "C5: WSPR receivers (BareBonesWSPR.ino settings), %d in all over %d GPU(s) = %d on this one, one step = a %d-block "
+                  "call (1/64 of a 2-minute slot) into the capture sink" % (total_ch, world, n_ch, T),
+        }[args.config]
+        inputs = {
+            "c2": "tone + LCG noise per channel, no impulses, all channels configured together (one mixer phase: every wave hits the "
+                  "local-oscillator cache), steady tone (the AGC hangs between envelope peaks): the best case of four data-dependent "
+                  "fast paths -- `robustness` holds the same chain with each of them defeated",
+            "c4": "carrier + 40 % AM + a second tone 610 Hz away at -6 dB (the notch has work) + LCG noise",
+            "c5": "weak tone (0.02) under noise (0.05); the same resident 646-block period is streamed",
+        }[args.config]
         out = {
             "metric": "Msamples/s through full SSB demod chain, batched 128-sample blocks",
             "value": round(samples / wall / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
-                       "untimed_launches_before_the_timed_region": settle + args.warmup,
-                       "channels_per_gpu": n_ch, "block": BLOCK, "sharding": "channels, no collective",
-                       "input": "tone + LCG noise per channel, no impulses: the blanker runs (envelope, average, threshold) but detects "
-                                "nothing, so its mask stays all ones; with an impulse in every block of every channel the same chain "
-                                "is ~9 % slower (tools/bench_configs.py c2)"},
-            "roofline": {"bound": "hbm", "kernel": "asdr_update_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "warmup": untimed, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "name": args.config,
+                       "warmup_requested": warm_req, "settle_steps_minimum": settle_min,
+                       "untimed_launches_before_the_timed_region": untimed,
+                       "channels_per_gpu": n_ch, "channels_total": total_ch, "blocks_per_step": T, "block": BLOCK,
+                       "sharding": "channels, no collective", "input": inputs},
+            "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 5),
-                         "kernel_ms_method": "one HIP-event pair on the launch stream around the %d timed launches / %d" % (args.steps, args.steps),
+                         "kernel_ms_method": "one HIP-event pair on the launch stream around the %d timed steps / %d" % (args.steps, args.steps),
                          "kernel_ms_event_pair_per_launch": None if pair_ms is None else round(pair_ms, 5),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BLOCK * n_ch,
-                         "hbm_read_share_frac": round(ALGO_READ_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0},
+                         "algorithmic_bytes_per_channel_block": round(cfg["algo"], 1),
+                         "algorithmic_bytes_per_launch": int(round(algo))},
         }
+        if args.config == "c2":
+            out["roofline"]["hbm_read_share_frac"] = round(ALGO_READ_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0
+        if args.config == "c5":
+            out["roofline"]["regime"] = "latency-bound (64 waves of dependent work per GPU share); the HBM fraction is reported as SURVEY 8d asks"
+            out["config"]["calls_run_as_block_pipeline"] = pipeline_calls
+            if k_ms > 0:
+                out["config"]["times_real_time"] = round(T * BLOCK / 44100.0 / (k_ms * 1e-3), 1)
         if args.dry_run:
             out["dry_run"] = True
+        if world == 1 and args.config == "c2" and not args.no_robustness and not args.dry_run:
+            if batch is not None:
+                batch.close(); batch = None
+            del dI, dQ
+            out["robustness"] = robustness(np, torch, dev, local_rank, n_ch, stream, 300)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

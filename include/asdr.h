@@ -204,11 +204,39 @@ int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]);
  * beta_freq, f_conv, lock_freq_low, lock_freq_high, twoPI, halfPI, twoPI/AUDIO_SAMPLE_RATE_EXACT, 1 - nb alpha; returns the
  * AGC hang count (samples) of channel `ch` (0 for a bad channel). */
 unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]);
+/* Mode values outside 0..6 (reachable through setDemodMode, AudioSDR.cpp:188).  The reference then runs neither demodulator
+ * (AudioSDR.cpp:84, 122) and its audio filter / AGC / ALS / output stage process the member _audioOut AGAIN, i.e. the audio the
+ * previous block left there (:149-161).  To reproduce that, every block of every channel stores its post-ALS float audio row
+ * (512 B per channel-block written; the kernel cannot know which block is a channel's last with a known mode).  This is the
+ * DEFAULT (on = 1): results equal the reference's for every mode value.  on = 0 drops the row: unknown mode values then process
+ * a silent block (everything else unchanged) and the 512 B per channel-block are saved -- for callers that never set one.
+ * Switching it back on starts from silent rows. */
+int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on);
+int asdr_get_exact_unknown_mode(asdr_batch_t *b);
 /* How many calls so far ran as the streaming block pipeline (a multi-block call on a small batch of SSB-class channels:
  * three role-specialised waves per group of 8 channels -- blanker + IF | mixer + Hilbert | audio filter + AGC + output -- work
  * on consecutive blocks at the same time).  Results are bit-identical to the block-by-block path; the counter
  * exists so that tests and benchmarks can tell which path ran. */
 long asdr_stream_pipeline_launches(asdr_batch_t *b);
+/* The pipeline is a transaction.  Its roles wait for each other with BOUNDED waits, so all 3 w + 1 workgroups must be resident at
+ * the same time; asdr_create() asks the runtime how many the device holds (occupancy x compute units, at most one per compute
+ * unit) and batches with more channel groups than asdr_stream_pipeline_max_groups() never take the pipeline.  Should a wait still
+ * run out (the GPU shared with another long kernel, masked compute units), every wave of the launch leaves, and the launches
+ * enqueued behind it on the same stream put the channels' state back from a snapshot taken in front of the pipeline and run the
+ * call again on the in-kernel block loop: the caller's next operation on that stream sees exact results and exact state either
+ * way, without any host synchronisation.  asdr_stream_pipeline_recoveries() = how many calls went that way (synchronises).
+ * asdr_set_stream_pipeline(b, 0) opts a batch out of the pipeline altogether (default on; environment ASDR_NO_STREAM_PIPELINE=1
+ * at asdr_create time = default off). */
+long asdr_stream_pipeline_recoveries(asdr_batch_t *b);
+int asdr_stream_pipeline_max_groups(asdr_batch_t *b);
+int asdr_set_stream_pipeline(asdr_batch_t *b, int on);
+/* How a batch launches its SAM channels (bit-identical results): fused = 1 -> the fused 4-wave kernel always; otherwise the three
+ * launches pre | PLL | post from split_min_channels SAM channels on (<= 0: the default, 512).  Defaults at asdr_create time from
+ * the environment (ASDR_SAM_FUSED, ASDR_SAM_SPLIT_MIN): comparison switches of the measurement tools. */
+int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels);
+/* Test hook: the number of polls after which a pipeline wait gives up (0 = the default, 2^18).  A tiny value injects timeouts, so
+ * that the recovery path can be tested on an idle GPU. */
+int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls);
 /* The wave schedule as the last flush built it (the next update's launches; a control-plane-only batch: after
  * asdr_control_plane_flush), in schedule slots (8 per wave): out[0..4] = the sub-ranges of whole waves of one settings group by
  * kernel kind -- 0 plain, 1 SAM, 2 ALS on the long rows, 3 ALS on the compact rows (taps <= 64, delay + taps <= 65, not SAM),

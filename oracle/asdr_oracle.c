@@ -84,7 +84,9 @@ struct asdr_oracle {
   int pll_locked;
   float pll_y_re, pll_y_im, pll_prev_filt, pll_err, pll_filt;
   /* --- test aid */
-  int unknown_mode_silence; /* model the PRODUCT's documented choice for unknown mode values (default 0 = the reference) */
+  int unknown_mode_silence; /* model the PRODUCT's opt-out for unknown mode values (default 0 = the reference) */
+  int pll_wrap_bound;       /* model the PRODUCT's bounded PLL phase wrap (default 0 = the reference's unbounded loops) */
+  int pll_stalled;          /* default mode: a wrap loop of .cpp:735-736 could never have ended (the reference would hang) */
   int taps_on;
   float taps[AO_N_TAPS][N];
 };
@@ -315,10 +317,24 @@ static void sam_demod(asdr_oracle_t *o) {
     /* .cpp:732: `phase_est += (a + b)/2.0` : float sum, double halve, double add, float store */
     o->pll_phase_est = (float)((double)o->pll_phase_est + (double)(o->pll_filt + o->pll_prev_filt) / 2.0);
     o->pll_prev_filt = o->pll_filt;
-    { /* .cpp:735-736 are two unbounded loops (compare vs double PI) that never end once phase_est -+ twoPI == phase_est
-       * (an infinite estimate): a Teensy instance would stall.  The product bounds them (ASDR_PLL_WRAP_MAX turns per sample, then
-       * phase_est = 0: DESIGN.md 4, defined differences) and the oracle mirrors that bound so the two stay comparable; a
-       * physical loop-filter step is below pi, i.e. at most one turn, so the bound never acts on a finite signal. */
+    if (!o->pll_wrap_bound) {
+      /* DEFAULT = the reference, .cpp:735-736: two unbounded loops (compare vs double PI).  They never end once
+       * phase_est -+ twoPI == phase_est (an infinite or huge estimate): a Teensy instance would hang there.  The oracle cannot
+       * hang the test process, so it notes the fact (ao_pll_stalled) and leaves the loop; everything else is the reference's. */
+      while (o->pll_phase_est >= AO_PI) {
+        float nxt = o->pll_phase_est - two_pi;
+        if (nxt == o->pll_phase_est) { o->pll_stalled = 1; break; }
+        o->pll_phase_est = nxt;
+      }
+      while (o->pll_phase_est < -AO_PI) {
+        float nxt = o->pll_phase_est + two_pi;
+        if (nxt == o->pll_phase_est) { o->pll_stalled = 1; break; }
+        o->pll_phase_est = nxt;
+      }
+    } else {
+      /* ao_set_pll_wrap_bound(o, 1): the PRODUCT's defined difference -- at most ASDR_PLL_WRAP_MAX turns per sample,
+       * then phase_est = 0 (a wave must not hang the GPU).  A physical loop-filter step is below pi, i.e. at most one turn, so
+       * the bound never acts on a finite signal; the GPU tests switch it on so that the two stay comparable on any input. */
       int turns = 0;
       while (o->pll_phase_est >= AO_PI && turns < AO_PLL_WRAP_MAX) { o->pll_phase_est -= two_pi; turns++; }
       while (o->pll_phase_est < -AO_PI && turns < AO_PLL_WRAP_MAX) { o->pll_phase_est += two_pi; turns++; }
@@ -465,7 +481,7 @@ void ao_update(asdr_oracle_t *o, const int16_t *bi, const int16_t *bq, int16_t *
       for (int i = 0; i < N; i++) o->audio[i] = o->Q[i];
     }
     if (o->mode == AO_AM || (o->mode == AO_SAM && !o->pll_locked)) am_envelope(o);
-  } else if (o->unknown_mode_silence) { /* the product's defined difference: silence instead of stale audio */
+  } else if (o->unknown_mode_silence) { /* the product with asdr_set_exact_unknown_mode(b, 0): silence instead of stale audio */
     memset(o->audio, 0, sizeof o->audio);
   } /* any other mode value: _audioOut keeps last block's (already post-processed) samples (.cpp:84,122,149-161) */
   TAP(AO_TAP_MIX_I, o->I); TAP(AO_TAP_MIX_Q, o->Q);
@@ -524,6 +540,10 @@ asdr_oracle_t *ao_create(void) {
 void ao_destroy(asdr_oracle_t *o) { free(o); }
 void ao_enable_taps(asdr_oracle_t *o, int on) { o->taps_on = on; }
 void ao_set_unknown_mode_silence(asdr_oracle_t *o, int on) { o->unknown_mode_silence = on; }
+void ao_set_pll_wrap_bound(asdr_oracle_t *o, int on) { o->pll_wrap_bound = on; }
+int ao_pll_stalled(const asdr_oracle_t *o) { return o->pll_stalled; }
+void ao_test_set_pll_phase(asdr_oracle_t *o, float phase_est) { o->pll_phase_est = phase_est; }
+float ao_test_get_pll_phase(const asdr_oracle_t *o) { return o->pll_phase_est; }
 const float *ao_tap(const asdr_oracle_t *o, int tap) { return o->taps[tap]; }
 
 void ao_init(asdr_oracle_t *o) { /* .cpp:174-185 */

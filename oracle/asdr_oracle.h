@@ -165,10 +165,17 @@ double ao_bench_run(int config, int n_channels, int n_blocks, const int16_t *I, 
 #endif
 /* Unknown demodulation-mode values (anything but 0..6; reachable through setDemodMode, AudioSDR.cpp:188): the reference
  * leaves _audioOut untouched, so the audio filter / AGC / ALS / output stage re-process the PREVIOUS block's already
- * processed audio (AudioSDR.cpp:84,122,149-161).  That is the oracle's default.  The HIP product deliberately outputs
- * the post-processing of a silent block instead (reproducing the stale row would cost a 512-byte store per channel and
- * block for every channel); on = 1 makes the oracle model that documented choice so the GPU tests can pin it. */
+ * processed audio (AudioSDR.cpp:84,122,149-161).  That is the oracle's default -- and the HIP product's (it keeps every block's
+ * post-ALS row in HBM).  on = 1 models the product's OPT-OUT, asdr_set_exact_unknown_mode(b, 0): the post-processing of a silent block. */
 void ao_set_unknown_mode_silence(asdr_oracle_t *o, int on);
+/* SAM PLL phase wrap (AudioSDR.cpp:735-736: two unbounded loops).  Default 0 = the reference's loops, run to their end; where they
+ * could never end (phase_est -+ twoPI == phase_est) the oracle leaves them and sets the flag ao_pll_stalled() reports (the
+ * reference would hang there).  on = 1 models the HIP product's defined difference: at most 64 turns per sample, then the estimate
+ * restarts at 0.  The GPU parity tests switch it on (tests/conftest.py); it never acts on a finite loop-filter step. */
+void ao_set_pll_wrap_bound(asdr_oracle_t *o, int on);
+int ao_pll_stalled(const asdr_oracle_t *o);
+void ao_test_set_pll_phase(asdr_oracle_t *o, float phase_est);   /* test hooks: the PLL's phase estimate */
+float ao_test_get_pll_phase(const asdr_oracle_t *o);
 
 /* same 12 derived constants as the product's asdr_get_chain_constants (include/asdr.h) */
 void ao_get_chain_constants(const asdr_oracle_t *o, float out[12]);

@@ -60,6 +60,10 @@ def lib():
     L.ao_destroy.argtypes = [vp]
     L.ao_enable_taps.argtypes = [vp, i32]
     L.ao_set_unknown_mode_silence.argtypes = [vp, i32]
+    L.ao_set_pll_wrap_bound.argtypes = [vp, i32]
+    L.ao_pll_stalled.argtypes = [vp]; L.ao_pll_stalled.restype = i32
+    L.ao_test_set_pll_phase.argtypes = [vp, f32]
+    L.ao_test_get_pll_phase.argtypes = [vp]; L.ao_test_get_pll_phase.restype = f32
     L.ao_get_chain_constants.argtypes = [vp, fp]
     L.ao_tap.argtypes = [vp, i32]
     L.ao_tap.restype = fp
@@ -150,14 +154,22 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+# The oracle's default is the reference's behaviour everywhere.  The GPU parity tests compare with the HIP product, whose SAM PLL
+# bounds the reference's two unbounded phase-wrap loops (defined differences): tests/conftest.py sets this for tests
+# marked `gpu`, so that every OracleSDR they create models that bound (ao_set_pll_wrap_bound).
+PRODUCT_PLL_BOUND = False
+
+
 class OracleSDR:
     """One reference-equivalent AudioSDR instance on the host CPU."""
 
-    def __init__(self, taps=False):
+    def __init__(self, taps=False, pll_wrap_bound=None):
         self._L = lib()
         self._h = self._L.ao_create()
         if taps:
             self._L.ao_enable_taps(self._h, 1)
+        if PRODUCT_PLL_BOUND if pll_wrap_bound is None else pll_wrap_bound:
+            self._L.ao_set_pll_wrap_bound(self._h, 1)
 
     def chain_constants(self):
         out = np.zeros(12, dtype=np.float32)

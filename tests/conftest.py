@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _oracle_models_the_products_pll_bound(request):
+    """The oracle's default is the reference's behaviour.  Tests marked `gpu` compare with the HIP product, whose SAM PLL bounds the
+    reference's unbounded phase-wrap loops (AudioSDR.cpp:735-736): their oracles model that bound."""
+    from oracle import asdr_oracle
+    asdr_oracle.PRODUCT_PLL_BOUND = request.node.get_closest_marker("gpu") is not None
+    yield
+    asdr_oracle.PRODUCT_PLL_BOUND = False
+
+
 @pytest.fixture(scope="session")
 def ao():
     """The CPU oracle binding (built on demand with gcc)."""

@@ -28,6 +28,42 @@ def test_gpus_2_self_launches_two_ranks_dry_run():
     assert abs(j["value"] - 2 * 65536 * 128 * 3 / (j["ms_per_step"] * 3e-3) / 1e6) / j["value"] < 0.01
 
 
+def test_config_c4_and_c5_shard_the_fixed_job_over_the_ranks():
+    """--config c4 / c5 (BASELINE configs 4 and 5): the job is fixed (1,048,576 channels / 4,096 receivers), N ranks take 1/N each
+    (strong scaling), `value` counts the whole job's samples, `config.workload` names the config."""
+    for cfg, total, blocks in (("c4", 1048576, 1), ("c5", 4096, 646)):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--config", cfg, "--dry-run", "--steps", "2", "--warmup", "1"],
+                           capture_output=True, text=True, env=_env(), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["name"] == cfg and j["config"]["workload"].startswith(cfg.upper())
+        assert j["config"]["channels_per_gpu"] == total // 2 and j["config"]["channels_total"] == total and j["config"]["blocks_per_step"] == blocks
+        assert abs(j["value"] - total * blocks * 128 * 2 / (j["ms_per_step"] * 2e-3) / 1e6) / j["value"] < 0.01
+        assert j["roofline"]["algorithmic_bytes_per_launch"] == int(round(j["roofline"]["algorithmic_bytes_per_channel_block"] * (total // 2) * blocks)) or \
+            abs(j["roofline"]["algorithmic_bytes_per_launch"] / (total // 2 * blocks) - j["roofline"]["algorithmic_bytes_per_channel_block"]) < 0.1
+
+
+def test_algorithmic_bytes_follow_survey_8d():
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.ALGO_BYTES_PER_BLOCK == 10520 and bench.ALGO_READ_BYTES_PER_BLOCK == 5436      # SURVEY.md 8d, C2
+    assert abs(bench.C4_ALGO_BYTES_PER_BLOCK - 10501.14) < 0.01                                 # per-mode sums + ALS, averaged over c mod 7
+    assert abs(bench.C5_ALGO_BYTES_PER_BLOCK - (768 * 646 + 96 + 2 * 1688) / 646.0) < 1e-9
+
+
+def test_warmup_field_is_the_effective_number_of_untimed_steps():
+    """`warmup` in the JSON line = the untimed steps that really preceded the timed region; what the command line asked for is
+    config.warmup_requested.  (On a GPU run the settle minimum tops --warmup up; the dry run has no device to settle.)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "3"],
+                       capture_output=True, text=True, env=_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["warmup"] == 3 and j["config"]["warmup_requested"] == 3 and j["config"]["settle_steps_minimum"] == 1500
+
+
 def test_gpus_1_dry_run_is_a_single_process_line():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0"],
                        capture_output=True, text=True, env=_env(), timeout=300)

@@ -114,3 +114,67 @@ def test_c5_share(gpu, ao):
         want = o.update(np.tile(I[c], (launches, 1)), np.tile(Q[c], (launches, 1)))
         assert np.array_equal(batch.capture_read(c).reshape(-1), want.reshape(-1)), "C5 receiver %d" % c
     batch.close()
+
+
+@pytest.mark.parametrize("adverse", ["divergent_mixer_phases", "all_three"])
+def test_full_size_c2_divergent_phases(gpu, ao, adverse):
+    """BASELINE config 2 at full size on the adverse cases bench.py's `robustness` object times (bench.ROBUSTNESS_CASES): every wave
+    holds 8 channels with 8 different mixer phases (channel c switched LSB -> USB after c mod 8 blocks, AudioSDR.cpp:187-222: the
+    local-oscillator cache and the wave-uniform mixer both miss, AudioSDR.h:508-526); `all_three` adds an impulse in every block
+    (the blanker's general path, AudioSDR.cpp:606-650) and AGC hang time 0 on noise-like audio (the AGC's general form in every
+    chunk, AudioSDR.cpp:404-436).  Sampled channels -- all 8 lanes' worth of two waves, the last wave -- bit-for-bit against the
+    oracle driven through the same setter sequence; the tiled-duplicate property for every channel."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from audiosdr_amd.synth import make_iq
+    case = bench.ROBUSTNESS_CASES[adverse]
+    n_ch, uniq, n_blk = 65536, 2048, 14
+    sig = dict(fc=6290.0, A=0.25)
+    if case["agc"]:
+        sig.update(A=0.05, noise=0.2)
+    if case["impulses"]:
+        sig.update(impulse_every=128)
+    I, Q = make_iq(uniq, n_blk, **sig)
+    dI, dQ = _device_tiles(torch, I, Q, n_ch)
+    batch = gpu.AudioSDRBatch(n_ch)
+    dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device="cuda")
+    sample = list(range(0, 16)) + [777, 2040, 2047]
+    orcs = {c: ao.OracleSDR() for c in sample}
+    got = {c: [] for c in sample}
+    want = {c: [] for c in sample}
+
+    def step(b):
+        batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, 0)
+        batch.synchronize()
+        _assert_tiled(torch, dOut, uniq, "%s block %d" % (adverse, b))
+        for c in sample:
+            got[c].append(dOut[c + uniq * 31].cpu().numpy().copy())
+            want[c].append(orcs[c].update(I[c, b], Q[c, b]))
+
+    # the stagger of bench.stagger_divergent_phases, with the sampled oracles switched at the same blocks
+    batch.setDemodMode(0)
+    for o in orcs.values():
+        o.setDemodMode(0)
+    L = gpu.load_library()
+    for j in range(8):
+        for c in range(j, n_ch, 8):
+            L.asdr_setDemodMode(batch._h, c, 1)
+        for c, o in orcs.items():
+            if c % 8 == j:
+                o.setDemodMode(1)
+        step(j)
+    for s in [batch] + list(orcs.values()):
+        bench.configure_c2(s)
+        if case["agc"]:
+            s.setAGChangTime(0.0)
+    for b in range(8, n_blk):
+        step(b)
+    for c in sample:
+        assert np.array_equal(np.stack(got[c]), np.stack(want[c])), "%s channel %d" % (adverse, c)
+    st = batch.read_status()
+    if case["impulses"]:
+        assert int(st["nb_detected"].sum()) > n_ch // 2
+    batch.close()

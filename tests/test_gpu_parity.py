@@ -147,31 +147,67 @@ def test_mixer_uniform_and_divergent_phases_in_one_wave(gpu, ao):
 
 
 @pytest.mark.parametrize("mode", [7, -1, 65535, 9])
-def test_unknown_mode_values(gpu, ao, mode):
-    """setDemodMode with a value outside 0..6 (AudioSDR.cpp:188: only _mode changes).  Defined difference: the
-    reference re-processes the previous block's stale audio (.cpp:84,122,149-161); the product runs the enabled post stages
-    on a SILENT block.  The oracle models that choice with ao_set_unknown_mode_silence; its default (the reference's behaviour)
-    is pinned by tests/test_oracle_known_answers.py.  Everything else -- blanker, IF filter state, the stages after the
-    demodulator, the return to a known mode -- must stay bit-exact."""
+@pytest.mark.parametrize("als", [False, True])
+def test_unknown_mode_values(gpu, ao, mode, als):
+    """setDemodMode with a value outside 0..6 (AudioSDR.cpp:188: only _mode changes).  Neither demodulator branch runs
+    (.cpp:84, 122), _audioOut keeps what the previous block left in it and the audio filter / AGC / ALS / output stage process
+    it AGAIN (.cpp:149-161) -- block after block while the mode stays unknown.  The product keeps every block's post-ALS row in
+    HBM for this (asdr_device.h audio_prev); the oracle is the DEFAULT one (the reference's behaviour, no product-modelling
+    switch).  Audio filter + AGC on, with and without the ALS filter (its kernel kinds), per-channel and whole-batch switches,
+    a multi-block call inside the unknown stretch, returns to known modes; int16 audio, six stage taps, status."""
     from audiosdr_amd.synth import make_iq
-    n_ch, n_blk = 11, 12
+    n_ch, n_blk = 19, 16
+    I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.25, impulse_every=700, f2=7100.0, a2=0.1)
+    pre = [S("setDemodMode", 1), S("enableAudioFilter")] + ([S("enableALSfilter")] if als else [])
+    batch, orcs = _mk(gpu, ao, n_ch, pre, taps=True)
+    script = {3: [S("setDemodMode", mode, sel=lambda c: c % 2 == 0)], 6: [S("setDemodMode", 4, sel=lambda c: c % 4 == 0)],
+              8: [S("setDemodMode", mode)], 13: [S("setDemodMode", 0)], 14: [S("setDemodMode", mode, sel=lambda c: c < 9), S("setMute", 1, sel=lambda c: c == 2)]}
+    calls = [1] * 9 + [3] + [1] * 4      # blocks per update(): blocks 9..11 in ONE call (the in-kernel block loop keeps re-processing)
+    b = 0
+    for nb in calls:
+        if b in script:
+            apply_setters(batch, orcs, script[b])
+        got = batch.update(I[:, b:b + nb], Q[:, b:b + nb])
+        taps = batch.read_taps()
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b:b + nb], Q[c, b:b + nb]).reshape(nb, 128)
+            for t in ("NB_I", "IF_I", "IF_Q", "DEMOD", "AUDIO_FILT", "AGC", "ALS"):
+                assert np.array_equal(f32_bits(taps[t][c]), f32_bits(orcs[c].tap(t))), "mode %d block %d ch %d tap %s" % (mode, b, c, t)
+            assert np.array_equal(got[c], want), "mode %d block %d ch %d" % (mode, b, c)
+            assert batch.getDemodMode(ch=c) == orcs[c].getDemodMode()
+        b += nb
+    assert b == n_blk
+    compare_status(gpu, batch, orcs)
+    batch.close()
+
+
+def test_unknown_mode_values_without_the_kept_row(gpu, ao):
+    """asdr_set_exact_unknown_mode(b, 0): the post-ALS row is not kept (512 B per channel-block less written) and an unknown mode value
+    processes a SILENT block -- the oracle's ao_set_unknown_mode_silence models that opt-out; everything else stays bit-exact.
+    Switching the row back on starts from silence and is exact again from the first block with a known mode."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, n_blk = 11, 14
     I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.25, impulse_every=700)
     batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")], taps=True)
+    batch.set_exact_unknown_mode(False)
     for o in orcs:
         o.set_unknown_mode_silence()
-    script = {3: [S("setDemodMode", mode, sel=lambda c: c % 2 == 0)], 6: [S("setDemodMode", 4, sel=lambda c: c % 4 == 0)],
-              8: [S("setDemodMode", mode)], 10: [S("setDemodMode", 0)]}
+    script = {3: [S("setDemodMode", 7, sel=lambda c: c % 2 == 0)], 6: [S("setDemodMode", 4, sel=lambda c: c % 4 == 0)],
+              8: [S("setDemodMode", -1)], 10: [S("setDemodMode", 0)], 12: [S("setDemodMode", 9, sel=lambda c: c % 3 == 0)]}
     for b in range(n_blk):
         if b in script:
             apply_setters(batch, orcs, script[b])
+        if b == 10:   # known modes again: keep the row from here on
+            batch.set_exact_unknown_mode(True)
+            for o in orcs:
+                o.set_unknown_mode_silence(False)
         got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
         taps = batch.read_taps()
         for c in range(n_ch):
             want = orcs[c].update(I[c, b], Q[c, b])
             for t in ("NB_I", "IF_I", "IF_Q", "DEMOD", "AUDIO_FILT", "AGC"):
-                assert np.array_equal(f32_bits(taps[t][c]), f32_bits(orcs[c].tap(t))), "mode %d block %d ch %d tap %s" % (mode, b, c, t)
-            assert np.array_equal(got[c], want), "mode %d block %d ch %d" % (mode, b, c)
-            assert batch.getDemodMode(ch=c) == orcs[c].getDemodMode()
+                assert np.array_equal(f32_bits(taps[t][c]), f32_bits(orcs[c].tap(t))), "block %d ch %d tap %s" % (b, c, t)
+            assert np.array_equal(got[c], want), "block %d ch %d" % (b, c)
     compare_status(gpu, batch, orcs)
     batch.close()
 

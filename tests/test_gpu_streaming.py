@@ -205,3 +205,70 @@ def test_block_pipeline_sizes(gpu, ao, n_ch, T, pipelined):
             assert np.array_equal(got[c], want), "call %d ch %d" % (call, c)
     assert batch.stream_pipeline_launches() == (2 if pipelined else 0)
     hip.free_all(); batch.close()
+
+
+@pytest.mark.parametrize("limit", [1, 40])
+def test_block_pipeline_timeout_is_recovered_in_stream(gpu, ao, limit):
+    """The pipeline as a transaction (asdr.h, asdr_kernels.hip): with the poll limit of the bounded waits shrunk to `limit` the
+    roles give up at once (1) or somewhere inside the call (40) -- as they would if the GPU were shared and the 3 w + 1 workgroups
+    not co-resident.  The launches enqueued behind the pipeline restore the channels' state from the snapshot and run the call
+    on the in-kernel block loop, all on the caller's stream and with no host synchronisation in between: three calls back to back
+    (pipeline with injected timeouts, a one-block call, pipeline again), every block of every channel against the oracle, state
+    (status getters) included; then the limit goes back to its default and the pipeline completes on its own."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 64, (24, 1, 17, 20)
+    total = sum(plan)
+    I, Q = make_iq(n_ch, total, fc=6290.0, A=0.25, noise=0.02, impulse_every=777)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0)])
+    assert batch.stream_pipeline_max_groups() >= 8
+    batch.debug_set_stream_spin_limit(limit)
+    hip = Hip()
+    outs, pos = [], 0
+    for k, T in enumerate(plan):
+        if k == 3:
+            batch.synchronize()
+            assert batch.stream_pipeline_recoveries() >= 1          # the injected timeouts were seen and recovered ...
+            rec = batch.stream_pipeline_recoveries()
+            batch.debug_set_stream_spin_limit(0)                    # ... and with the default limit the pipeline runs through
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        hip.fill(dO, 0x11, n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)                          # no synchronisation between the calls
+        outs.append((dO, pos, T))
+        pos += T
+    batch.synchronize()
+    assert batch.stream_pipeline_recoveries() == rec
+    assert batch.stream_pipeline_launches() == 3
+    for dO, p0, T in outs:
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            if p0 == 0:
+                want = orcs[c].update(I[c, :total], Q[c, :total]).reshape(total, 128)
+                orcs[c]._want = want
+            assert np.array_equal(got[c], orcs[c]._want[p0:p0 + T]), "call at block %d (%d blocks), ch %d" % (p0, T, c)
+    _compare_status(batch, orcs)
+    hip.free_all(); batch.close()
+
+
+def test_launch_form_switches_per_batch(gpu, ao):
+    """asdr_set_stream_pipeline / asdr_set_sam_launch_form: the launch forms are properties of a batch (their defaults come from
+    the environment when the batch is created), so two batches of one process can differ -- and every form is bit-exact."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, T = 64, 12
+    fc = 6890.0 + (np.arange(n_ch) % 5 - 2) * 40.0
+    I, Q = make_iq(n_ch, T, fc=fc, A=0.3, m=0.4, noise=0.02)
+    for mode, kw in ((1, dict(pipeline=True)), (1, dict(pipeline=False)), (5, dict(fused=True)), (5, dict(fused=False, split_min=1))):
+        b = gpu.AudioSDRBatch(n_ch)
+        b.setDemodMode(mode); b.enableAudioFilter()
+        if "pipeline" in kw:
+            b.set_stream_pipeline(kw["pipeline"])
+        else:
+            b.set_sam_launch_form(kw["fused"], kw.get("split_min", 0))
+        got = b.update(I, Q)
+        assert b.stream_pipeline_launches() == (1 if kw.get("pipeline") else 0)
+        if mode == 5:
+            assert b.schedule_layout()["sam_three_launches"] == (not kw["fused"])
+        for c in range(0, n_ch, 5):
+            o = ao.OracleSDR(); o.setDemodMode(mode); o.enableAudioFilter()
+            assert np.array_equal(got[c], o.update(I[c], Q[c]).reshape(T, 128)), (mode, kw, c)
+        b.close()
