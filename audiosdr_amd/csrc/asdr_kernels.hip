@@ -136,6 +136,31 @@ template <bool BELOW_TWO_PI = false>
 __device__ __forceinline__ float cos_f32(const float *sine, float phase, float two_pi, double inv_two_pi, double half_pi_d) {
   return sin_f32<BELOW_TWO_PI>(sine, (float)((double)phase + half_pi_d), two_pi, inv_two_pi);
 }
+// cos_f32 / sin_f32 of NP phases (the mixer, AudioSDR.h:519-520): all 2 NP table phases first, then the 2 NP gathers TOGETHER, then the
+// interpolations.  Written lookup by lookup the compiler waits for every gather right behind its issue -- one exposed L1 round
+// trip per lookup.  Same operations per value as sin_f32 / cos_f32 above.
+template <int NP>
+__device__ __forceinline__ void sincos_batch(const float *sine, const float *ph, float *cc, float *sn, float two_pi, double inv_two_pi, double half_pi_d) {
+  uint32_t ipc[NP], ips[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    ipc[j] = sin_index((float)((double)ph[j] + half_pi_d), two_pi, inv_two_pi);   // cos_f32: sin_f32(phase + PI/2.0)
+    ips[j] = sin_index(ph[j], two_pi, inv_two_pi);
+  }
+  float c1[NP], c2[NP], s1[NP], s2[NP];
+  const float *tab = sine ? sine : c_sine;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const float *tc = tab + (ipc[j] >> 8), *ts = tab + (ips[j] >> 8);
+    c1[j] = tc[0]; c2[j] = tc[1]; s1[j] = ts[0]; s2[j] = ts[1];
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (every request is out before the first value is waited for)
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    cc[j] = c1[j] + ((c2[j] - c1[j]) * (float)(ipc[j] & 0xFFu)) * (1.0f / 256.0f);   // sin_lut
+    sn[j] = s1[j] + ((s2[j] - s1[j]) * (float)(ips[j] & 0xFFu)) * (1.0f / 256.0f);
+  }
+}
 // AudioSDR.h:384-408
 __device__ __forceinline__ float approx_atan(float z) {
   const float n1 = 0.97239411f, n2 = -0.19194795f;
@@ -290,6 +315,30 @@ __device__ __forceinline__ void load4(const float *p, float *v) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
 }
 __device__ __forceinline__ void store4(float *p, const float *v) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+// the same as a non-temporal (streaming) store: `global_store_dwordx4 ... nt`
+__device__ __forceinline__ void store4_nt(float *p, const float *v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v tv = {v[0], v[1], v[2], v[3]};
+  __builtin_nontemporal_store(tv, reinterpret_cast<f4v *>(p));
+}
+#ifndef ASDR_NT_LOADS
+#define ASDR_NT_LOADS 2   /* non-temporal loads for rows a launch reads once and nobody reads again: 1 = input rows, 2 = + the blanker ring's oldest block (-1.5 % on C2), 3 = + the Hilbert ring's oldest block (no further gain) */
+#endif
+__device__ __forceinline__ int4 load_int4_nt(const int4 *p) {
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(p));
+  return make_int4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void load4_nt(const float *p, float *v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ void store_int4_nt(int4 *p, int4 v) {
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  const i4v tv = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(tv, reinterpret_cast<i4v *>(p));
+}
 __device__ __forceinline__ void store8(float *p, const float *v) {
   float4 *q = reinterpret_cast<float4 *>(p);
   q[0] = make_float4(v[0], v[1], v[2], v[3]); q[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -779,8 +828,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
       nb_avg0 = S->nb_avg;
       const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + kA), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + kA);
+#if ASDR_NT_LOADS >= 2
+      rmi[0].v = mid4[0]; rmi[1].v = mid4[8]; rmq[0].v = mid4[16]; rmq[1].v = mid4[24];   // (the middle block comes back once more: temporal)
+      roi[0].v = load_int4_nt(old4); roi[1].v = load_int4_nt(old4 + 8); roq[0].v = load_int4_nt(old4 + 16); roq[1].v = load_int4_nt(old4 + 24);
+#else
       rmi[0].v = mid4[0]; rmi[1].v = mid4[8]; rmq[0].v = mid4[16]; rmq[1].v = mid4[24];   // Q row starts 128 samples = 16 int4 later
       roi[0].v = old4[0]; roi[1].v = old4[8]; roq[0].v = old4[16]; roq[1].v = old4[24];
+#endif
 #pragma unroll
       for (int r = 0; r < 5; ++r) mkc[r] = mrow[8 * r];   // codes of the carried mask[128..265]
     }
@@ -789,7 +843,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (DO1 && valid) {
       const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
       const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
+#if ASDR_NT_LOADS >= 1
+      ri[0].v = load_int4_nt(pi); ri[1].v = load_int4_nt(pi + 8); rq[0].v = load_int4_nt(pq); rq[1].v = load_int4_nt(pq + 8);
+#else
       ri[0].v = pi[0]; ri[1].v = pi[8]; rq[0].v = pq[0]; rq[1].v = pq[8];   // int4 #8 = 64 samples on
+#endif
     }
     // mixer increment (AudioSDR.h:508-512) and the local-oscillator cache test (asdr_device.h LoEntry): hit = every channel of the
     // wave starts this block with exactly the cached phase and increment -> no recurrence, no table lookups, the pairs are read
@@ -864,7 +922,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       if (nb_en) {   // newest block -> third ring slot, with its gains (blanker-off channels pass their own input: see above)
         int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + kA);
+#ifndef ASDR_TEMPORAL_RINGS
+        store_int4_nt(ni, ri[0].v); store_int4_nt(ni + 8, ri[1].v); store_int4_nt(ni + 16, rq[0].v); store_int4_nt(ni + 24, rq[1].v);
+#else
         ni[0] = ri[0].v; ni[8] = ri[1].v; ni[16] = rq[0].v; ni[24] = rq[1].v;
+#endif
         if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
       }
       if (tap_on) {
@@ -1139,7 +1201,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (RING_PREFETCH && is_ssb) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+#if ASDR_NT_LOADS >= 3
+        load4_nt(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m);          // the oldest block: overwritten below, never read again
+#else
         load4(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m);
+#endif
         load4(hq_ring + (hs ^ 1u) * 128 + 32 * m, hq_m + 4 * m);
       }
     }
@@ -1308,10 +1374,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     TL(6);
     if (ABL_ON(ABL_MIX) && mix_uni && !lo_hit) {   // sin/cos of the wave's 128 phases, two per lane
       const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane);
-      const float c0 = cos_f32(sine, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d), s0 = sin_f32(sine, p2.x, two_pi, K.inv_two_pi_d);
-      const float c1 = cos_f32(sine, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d), s1 = sin_f32(sine, p2.y, two_pi, K.inv_two_pi_d);
-      *reinterpret_cast<float2 *>(lds + STRIDE + PH + 2 * lane) = make_float2(c0, c1);
-      *reinterpret_cast<float2 *>(lds + 2 * STRIDE + PH + 2 * lane) = make_float2(s0, s1);
+      const float ph2[2] = {p2.x, p2.y};
+      float c2[2], s2[2];
+      sincos_batch<2>(sine, ph2, c2, s2, two_pi, K.inv_two_pi_d, K.half_pi_d);
+      *reinterpret_cast<float2 *>(lds + STRIDE + PH + 2 * lane) = make_float2(c2[0], c2[1]);
+      *reinterpret_cast<float2 *>(lds + 2 * STRIDE + PH + 2 * lane) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
     }
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
@@ -1329,13 +1396,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         } else if (mix_uni) {
           load4(lds + STRIDE + PH + kF + 32 * m, cc); load4(lds + 2 * STRIDE + PH + kF + 32 * m, sn);
         } else {
+          // per-channel phases (the wave's channels carry different mixer phases): 4 x (cos, sin) lookups per piece, gathers batched
           float ph[4];
           load4(L + PH + kF + 32 * m, ph);
+#ifndef ASDR_MIX_SERIAL_LOOKUPS
+          sincos_batch<4>(sine, ph, cc, sn, two_pi, K.inv_two_pi_d, K.half_pi_d);
+#else
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             cc[j] = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d, K.half_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
             if ((j & 1) == 1) SCHED_FENCE();
           }
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1343,7 +1415,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           mq[j] = vq[j] * cc[j] + vi[j] * sn[j];
         }
         store4(L + W0 + kF + 32 * m, mi); store4(L + W1 + kF + 32 * m, mq);
+#ifndef ASDR_TEMPORAL_RINGS
+        if (is_ssb) store4_nt(hi_ring + hs * 128 + 32 * m, mi);
+#else
         if (is_ssb) store4(hi_ring + hs * 128 + 32 * m, mi);
+#endif
       }
     }
 
@@ -1398,7 +1474,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) L[XP + 255 + kF + 32 * m + j] = qn[4 * m + j];
+#ifndef ASDR_TEMPORAL_RINGS
+          store4_nt(hq_ring + hs * 128 + 32 * m, qn + 4 * m);
+#else
           store4(hq_ring + hs * 128 + 32 * m, qn + 4 * m);   // newest replaces oldest (loaded before the IF pipeline)
+#endif
         }
         if (lead) S->hil_slot = hs ^ 1u;
         carry_hs = hs ^ 1u;
@@ -1822,7 +1902,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (DO3 && valid && a.audio_prev != nullptr) {   // _audioOut as this block leaves it: what an unknown mode value would re-process
       float *ap = row_ptr(a.audio_prev, (uint32_t)ch * 512u + 4u * (uint32_t)kF);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { float t[4]; load4(L + W0 + kF + 32 * m, t); store4(ap + 32 * m, t); }
+      for (int m = 0; m < 4; ++m) {
+        float t[4]; load4(L + W0 + kF + 32 * m, t);
+#ifndef ASDR_PREV_TEMPORAL
+        store4_nt(ap + 32 * m, t);   // written every block, read (if ever) a launch later: streaming store, keeps L2 for the rows that come back
+#else
+        store4(ap + 32 * m, t);
+#endif
+      }
     }
     {
       // ---- output, AudioSDR.cpp:158-161: float product, x 32767.0 in binary64, truncate, wrap to int16 ------
@@ -1842,7 +1929,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       if (DO3 && valid) {
         int4 *po = reinterpret_cast<int4 *>(a.out + io_out);
+#ifndef ASDR_TEMPORAL_OUT
+        store_int4_nt(po, ro[0].v); store_int4_nt(po + 8, ro[1].v);
+#else
         po[0] = ro[0].v; po[8] = ro[1].v;
+#endif
       }
     }
     if (!STREAM) { if (lead) S->status = status; }
@@ -1873,10 +1964,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane_i);
-      const float c0 = cos_f32(sine, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d), s0 = sin_f32(sine, p2.x, two_pi, K.inv_two_pi_d);
-      const float c1 = cos_f32(sine, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d), s1 = sin_f32(sine, p2.y, two_pi, K.inv_two_pi_d);
-      *reinterpret_cast<float2 *>(lo_wr->c + 2 * lane_i) = make_float2(c0, c1);
-      *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s0, s1);
+      const float ph2[2] = {p2.x, p2.y};
+      float c2[2], s2[2];
+      sincos_batch<2>(sine, ph2, c2, s2, two_pi, K.inv_two_pi_d, K.half_pi_d);
+      *reinterpret_cast<float2 *>(lo_wr->c + 2 * lane_i) = make_float2(c2[0], c2[1]);
+      *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
     }
     TL(15);
@@ -2020,8 +2112,12 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
     WAVE_SYNC();
     const float2 p2 = *reinterpret_cast<const float2 *>(lds + 2 * lane);
     v2f c2, s2;
-    c2[0] = cos_f32(nullptr, p2.x, two_pi, K.inv_two_pi_d, K.half_pi_d); s2[0] = sin_f32(nullptr, p2.x, two_pi, K.inv_two_pi_d);
-    c2[1] = cos_f32(nullptr, p2.y, two_pi, K.inv_two_pi_d, K.half_pi_d); s2[1] = sin_f32(nullptr, p2.y, two_pi, K.inv_two_pi_d);
+    {
+      const float ph2[2] = {p2.x, p2.y};
+      float cb[2], sb[2];
+      sincos_batch<2>(nullptr, ph2, cb, sb, two_pi, K.inv_two_pi_d, K.half_pi_d);
+      c2[0] = cb[0]; c2[1] = cb[1]; s2[0] = sb[0]; s2[1] = sb[1];
+    }
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_nop 1"
                  :: "v"(e->c + 2 * lane), "v"(c2), "v"(e->s + 2 * lane), "v"(s2) : "memory");
     if (lane == 0) {

@@ -104,8 +104,8 @@ ROBUSTNESS_CASES = {
         what="every wave holds 8 channels with 8 DIFFERENT mixer phases (channel c switched LSB -> USB after c mod 8 blocks): the "
              "local-oscillator cache and the wave-uniform mixer both miss; every lane runs its own 2 x 16 sin/cos lookups"),
     "agc_general_form": dict(phases=False, agc=True, impulses=False,
-        what="AGC hang time 0 and noise-like audio (tone 0.05 under noise 0.2): the envelope releases between peaks and attacks "
-             "again, every 8-sample chunk takes the AGC's general per-sample form (no hanging-chunk / attack-only fast form)"),
+        what="AGC hang time 0 (setAGChangTime(0)): the envelope releases between the audio's peaks and attacks again at each of them, "
+             "so every 8-sample chunk takes the AGC's general per-sample form (no hanging-chunk / attack-only fast form); input as C2"),
     "impulse_every_block": dict(phases=False, agc=False, impulses=True,
         what="an impulse in every block of every channel: the blanker's general path (counts, mask decode / zero / ramp / encode)"),
     "all_three": dict(phases=True, agc=True, impulses=True, what="the three together"),
@@ -254,8 +254,6 @@ def robustness(np, torch, dev, local_rank, n_ch, stream, timed):
     dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
     for name, c in ROBUSTNESS_CASES.items():
         sig = dict(fc=6290.0, A=0.25)
-        if c["agc"]:
-            sig.update(A=0.05, noise=0.2)
         if c["impulses"]:
             sig.update(impulse_every=128)     # sample 64 of every block
         dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, **sig)

@@ -121,7 +121,7 @@ def test_full_size_c2_divergent_phases(gpu, ao, adverse):
     """BASELINE config 2 at full size on the adverse cases bench.py's `robustness` object times (bench.ROBUSTNESS_CASES): every wave
     holds 8 channels with 8 different mixer phases (channel c switched LSB -> USB after c mod 8 blocks, AudioSDR.cpp:187-222: the
     local-oscillator cache and the wave-uniform mixer both miss, AudioSDR.h:508-526); `all_three` adds an impulse in every block
-    (the blanker's general path, AudioSDR.cpp:606-650) and AGC hang time 0 on noise-like audio (the AGC's general form in every
+    (the blanker's general path, AudioSDR.cpp:606-650) and AGC hang time 0 (the AGC's general form in every
     chunk, AudioSDR.cpp:404-436).  Sampled channels -- all 8 lanes' worth of two waves, the last wave -- bit-for-bit against the
     oracle driven through the same setter sequence; the tiled-duplicate property for every channel."""
     import os
@@ -133,8 +133,6 @@ def test_full_size_c2_divergent_phases(gpu, ao, adverse):
     case = bench.ROBUSTNESS_CASES[adverse]
     n_ch, uniq, n_blk = 65536, 2048, 14
     sig = dict(fc=6290.0, A=0.25)
-    if case["agc"]:
-        sig.update(A=0.05, noise=0.2)
     if case["impulses"]:
         sig.update(impulse_every=128)
     I, Q = make_iq(uniq, n_blk, **sig)
