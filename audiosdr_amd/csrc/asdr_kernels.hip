@@ -40,9 +40,9 @@
 #define NB_B 2     // [2,180): beta*mag[t] of detection indices 78..255 (t = 0..177) from the envelope pass, overwritten in place by
                    // avg[t] (the running average BEFORE sample t) by the sequential pass; dead once the detection flags are in
                    // registers.  (Offset 2: the lanes' pieces t = 50 + 8 s8 + 64h and t = 8 s8 - 14 fall on 16-byte slots; words 0, 1 are padding.)
-#define NB_MSK 0   // general path only: mask[0..265(..271)], overlays the dead B row
-#define NB_CB 272  // general path only: 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count
-                   // after detection index t (0..177), CB[202..222] = final count (overlays the PH row: phases are recomputed)
+#define NB_MSKB 0  // general path only: 272 BYTE codes of mask[0..265(..271)] = 68 words, overlays the dead B row
+#define NB_CB 68   // general path only: 56 words = 224 bytes of padded running detection counts: CB[3..23] = 0, CB[24+t] = count
+                   // after detection index t (0..177), CB[202..222] = final count (also inside the dead B row: the PH row survives)
 // AGC overlay
 #define AGC_GV 128   // per sample: the envelope value whose compressor gain applies (-1 = gain carried in)
 #define AGC_TAB 256  // this channel's gain table (row of 132 floats)
@@ -110,10 +110,12 @@ __device__ __forceinline__ double div_by_const(double x, double c, double r) {
 // sin_f32's phase -> uint16 table phase (AudioSDR.h:362-364): index logic, evaluated in binary64.
 // BELOW_TWO_PI: the caller guarantees phase < twoPI (the PLL: |phase_est| < pi after its wrap, so phase_est and
 // phase_est + pi/2 are below 4.72), which makes the first test dead -- three instructions less on the PLL's dependent chain.
-template <bool BELOW_TWO_PI = false>
+// NONNEG: the caller guarantees phase >= 0 (the mixer: its phase stays in [0, twoPI], AudioSDR.h:514-517, and so does phase + pi/2),
+// which makes the second test dead.
+template <bool BELOW_TWO_PI = false, bool NONNEG = false>
 __device__ __forceinline__ uint32_t sin_index(float phase, float two_pi, double inv_two_pi) {
   if (!BELOW_TWO_PI && phase >= two_pi) phase -= two_pi;
-  if (phase < 0.0f) phase += two_pi;
+  if (!NONNEG && phase < 0.0f) phase += two_pi;
   const double q = div_by_const((double)phase * 65535.0, (double)two_pi, inv_two_pi);
   return (uint32_t)(int)q & 0xFFFFu;
 }
@@ -144,8 +146,8 @@ __device__ __forceinline__ void sincos_batch(const float *sine, const float *ph,
   uint32_t ipc[NP], ips[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    ipc[j] = sin_index((float)((double)ph[j] + half_pi_d), two_pi, inv_two_pi);   // cos_f32: sin_f32(phase + PI/2.0)
-    ips[j] = sin_index(ph[j], two_pi, inv_two_pi);
+    ipc[j] = sin_index<false, true>((float)((double)ph[j] + half_pi_d), two_pi, inv_two_pi);   // cos_f32: sin_f32(phase + PI/2.0)
+    ips[j] = sin_index<false, true>(ph[j], two_pi, inv_two_pi);   // (mixer phases are in [0, twoPI]: never negative)
   }
   float c1[NP], c2[NP], s1[NP], s2[NP];
   const float *tab = sine ? sine : c_sine;
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           }
         }
         if (nb_en) S->nb_avg = avg;
-        if (mix_early && !lo_hit) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
+        if (mix_early && !lo_hit && c_tail != 0) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
         mphase_end = phase;
       }
       ph_ready = mix_early && !lo_hit;
@@ -1059,11 +1061,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const bool nb_slow = __any(!nb_quiet);
 #endif
       if (nb_slow) {
-        float mk[16];
-        DEFINE_ALL_PATHS(mk, 16);
+        // General path, on the mask's BYTE CODES (0..6 <-> {0, 1, .933, .75, .5, .25, .067}: the only values the mask ever holds,
+        // AudioSDR.cpp:608, 623, 630): the carried codes go to LDS as they came from HBM, zeroing and the trailing ramp write code
+        // bytes, the carry-out is copied back as it is -- no float mask row, no encode / decode round trip (round 2 kept the mask
+        // as floats in LDS: 85 decode + ~110 encode instructions per lane and block).  Only this lane's 16 output samples are
+        // decoded, for the multiply.  Both arrays live in the dead B row, so the phase sequence in the PH row survives.
         const float mask_tab = c_mask_val[lane_i & 7];   // code -> value, one entry per lane (mask_decode_byte)
         const uint32_t group4 = (uint32_t)(lane_i & 56) << 2;
-        ph_ready = false;          // the count bytes below overlay the PH row: the phase sequence is recomputed after the blanker
+        uint8_t *const mb = reinterpret_cast<uint8_t *>(Li + NB_MSKB);   // mb[m] = code of mask[m], m = 0..271
         WAVE_SYNC();               // every lane has read its averages: the B row is dead
         if (nb_en) {
           // running detection counts as bytes: CB[0..23] = 0, CB[24 + t] = detections up to and including index t (t = 0..177),
@@ -1100,22 +1105,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
             for (int z = 51; z < 56; ++z) Li[NB_CB + z] = (int)fin;                                      // bytes 204..223
           }
-          // mask: carried part = previous mask[128..265] (row of 144, 138 used); then the rest of the (new) newest
-          // block is 1.0 (:621-623) -- written AFTER the row so that it wins on entries 138..143
-          // lane s8 decodes mask entries 32r + 4 s8 .. + 3 of its five code words (entries >= 138 are padding)
+          // mask codes: carried part = the previous call's mask[128..265], as it came from HBM (lane s8 holds entries 32r + 4 s8 .. + 3
+          // of its five code words; entries >= 138 of the row are padding with code 1 = 1.0), then the rest of the (new) newest
+          // block is 1.0 (:621-623): code words 40..67 (entries 160..271)
 #pragma unroll
-          for (int r = 0; r < 5; ++r) {
-            const int e = 32 * r + 4 * s8;
-            const float4 dv = make_float4(mask_decode_byte(mask_tab, group4, mkc[r], 0), mask_decode_byte(mask_tab, group4, mkc[r], 1),
-                                          mask_decode_byte(mask_tab, group4, mkc[r], 2), mask_decode_byte(mask_tab, group4, mkc[r], 3));   // (all 8 lanes)
-            if (e < ASDR_NB_MASK_USED + 2) *reinterpret_cast<float4 *>(L + NB_MSK + e) = dv;
-          }
-          float one = 1.0f; asm volatile("" : "+v"(one));   // materialised here, not parked in a VGPR at kernel entry
+          for (int r = 0; r < 5; ++r) Li[NB_MSKB + 8 * r + s8] = (int)mkc[r];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) L[NB_MSK + ASDR_NB_MASK_USED + k0 + j] = one;   /* any partition of 138..265 */
+          for (int k = 0; k < 4; ++k) { const int w = 40 + s8 + 8 * k; if (w < 68) Li[NB_MSKB + w] = 0x01010101; }
         }
         WAVE_SYNC();
-        if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are 0.0, so order-free:
+        if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are code 0, so order-free:
                        // mask[m] is hit iff a detection index lies in [m-10, m+10] iff CB[m-44] - CB[m-65] > 0
           const uint8_t *cb = reinterpret_cast<const uint8_t *>(Li + NB_CB);
           const int m0 = 68 + s8 * 25;
@@ -1125,50 +1124,52 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
             for (int r = 0; r < 5; ++r) { hi[r] = cb[m0 - 44 + g5 + r]; lo[r] = cb[m0 - 65 + g5 + r]; }
 #pragma unroll
-            for (int r = 0; r < 5; ++r) if (m0 + g5 + r <= 265 && hi[r] - lo[r] > 0) L[NB_MSK + m0 + g5 + r] = 0.0f;
+            for (int r = 0; r < 5; ++r) if (m0 + g5 + r <= 265 && hi[r] - lo[r] > 0) mb[m0 + g5 + r] = (uint8_t)0;
             SCHED_FENCE();
           }
         }
         WAVE_SYNC();
-        float ev[17];
-        DEFINE_ALL_PATHS(ev, 17);
         if (nb_en) {   // trailing-edge ramp (:637-644; only the first branch is reachable).  An edge at i
                        // writes mask[i-7..i-1] only, which later iterations never read: read all, then write.
+                       // codes of mask[124 + k0 .. 143 + k0] (five aligned words); entry 127 + k0 + j is byte 3 + j of them
+          uint32_t evw[5];
 #pragma unroll
-          for (int j = 0; j < 17; ++j) ev[j] = L[NB_MSK + 127 + k0 + j];
-        }
-        WAVE_SYNC();
-        if (nb_en) {
-          // {.933, .750, .500, .250, .067, 0, 0} (:608) read from the code table: as literals the compiler parks them in VGPRs
-          // for the whole kernel
-          float trans_dn[7];
-#pragma unroll
-          for (int q = 0; q < 5; ++q) trans_dn[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mask_tab), 2 + q));
-          trans_dn[5] = 0.0f; trans_dn[6] = 0.0f;
+          for (int z = 0; z < 5; ++z) evw[z] = (uint32_t)Li[NB_MSKB + 31 + 4 * s8 + z];
+          WAVE_SYNC();   // (every lane's reads are issued before any lane's writes: one wave, LDS in order)
+          // {.933, .750, .500, .250, .067, 0, 0} (:608) = codes 2, 3, 4, 5, 6, 0, 0
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            if (ev[j + 1] == 1.0f && ev[j] == 0.0f) {
-              const int i = 128 + k0 + j;
-#pragma unroll
-              for (int q = 0; q < 7; ++q) L[NB_MSK + i - 7 + q] = trans_dn[q];
+            const uint32_t c_prev = (evw[(3 + j) >> 2] >> (8 * ((3 + j) & 3))) & 0xFFu, c_here = (evw[(4 + j) >> 2] >> (8 * ((4 + j) & 3))) & 0xFFu;
+            if (c_here == 1u && c_prev == 0u) {
+              uint8_t *w = mb + 128 + k0 + j - 7;
+              // (the seven code bytes out of two registers materialised HERE: as seven literals the compiler parks them in VGPRs
+              // for the whole kernel)
+              uint32_t lo4 = 0x05040302u, hi4 = 0x00000006u;
+              asm volatile("" : "+v"(lo4), "+v"(hi4));
+              w[0] = (uint8_t)lo4; w[1] = (uint8_t)(lo4 >> 8); w[2] = (uint8_t)(lo4 >> 16); w[3] = (uint8_t)(lo4 >> 24);
+              w[4] = (uint8_t)hi4; w[5] = (uint8_t)(hi4 >> 8); w[6] = (uint8_t)(hi4 >> 16);
             }
           }
         }
         WAVE_SYNC();
-        {   // read this lane's mask values and carry mask[128..265(..271)] to the next call, before the rows are reused
-          load8(L + NB_MSK + kA, mk); load8(L + NB_MSK + kA + 64, mk + 8);
+        {   // this lane's 16 output samples' codes (entries kA .. kA + 7 and 64 + kA ..), and mask[128..265(..271)] carried to the next call
+          uint32_t own[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
           if (nb_en) {
+            const int2 a2 = *reinterpret_cast<const int2 *>(Li + NB_MSKB + 2 * s8), b2 = *reinterpret_cast<const int2 *>(Li + NB_MSKB + 16 + 2 * s8);
+            own[0] = (uint32_t)a2.x; own[1] = (uint32_t)a2.y; own[2] = (uint32_t)b2.x; own[3] = (uint32_t)b2.y;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-              const int e = 32 * r + 4 * s8;   // entries >= 138 are padding: store code 1
-              const float4 mv = (e < ASDR_NB_MASK_USED + 2) ? *reinterpret_cast<const float4 *>(L + NB_MSK + 128 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-              mrow[8 * r] = mask_encode4(mv);
+              const int e = 32 * r + 4 * s8;   // entries >= 138 (+ 2) are padding: store code 1
+              mrow[8 * r] = (e < ASDR_NB_MASK_USED + 2) ? (uint32_t)Li[NB_MSKB + 32 + 8 * r + s8] : 0x01010101u;
             }
           }
-        }
-        // output = mask x oldest block (:646-649)
+          // output = mask x oldest block (:646-649); blanker-off channels of the wave pass their samples (code 1 = 1.0)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { const float mv = nb_en ? mk[j] : 1.0f; vio[j] = mv * vio[j]; vqo[j] = mv * vqo[j]; }
+          for (int j = 0; j < 16; ++j) {
+            const float mv = mask_decode_byte(mask_tab, group4, own[j >> 2], j & 3);   // (all 8 lanes of the group)
+            vio[j] = mv * vio[j]; vqo[j] = mv * vqo[j];
+          }
+        }
       }   // nb_slow
       WAVE_SYNC();   // the B row / mask row is dead: the IF filter rows may overwrite it
       store8(L + W0 + kA, vio); store8(L + W0 + kA + 64, vio + 8); store8(L + W1 + kA, vqo); store8(L + W1 + kA + 64, vqo + 8);
@@ -1197,7 +1198,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Hilbert ring (two previous blocks of mixed Q) is requested before the pipeline: 32 registers that the
     // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer.  (Not in the SAM-only
     // instantiation: its only SSB channels are the padding slots, and it has no registers to spare at 3 waves/SIMD.)
-    constexpr bool RING_PREFETCH = !HAS_SAM;
+    constexpr bool RING_PREFETCH = !HAS_SAM && !(HAS_ALS && !UNIFORM && STRIDE == ASDR_STRIDE);   // (nor in the compact ALS rows' general form -- a few remainder waves: it spills with them)
     if (RING_PREFETCH && is_ssb) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
