@@ -163,6 +163,19 @@ __device__ __forceinline__ void sincos_batch(const float *sine, const float *ph,
     sn[j] = s1[j] + ((s2[j] - s1[j]) * (float)(ips[j] & 0xFFu)) * (1.0f / 256.0f);
   }
 }
+// The PLL's y = (cos_f32, sin_f32)(phase_est) (AudioSDR.cpp:737-738) from the wave's LDS copy of the table, |phase| < pi.  `sine` is
+// named as an LDS pointer: through the generic `sine ? sine : c_sine` form of sin_lut the compiler emits FLAT loads, which count
+// against the vector-memory counter as well -- every lookup then waited for the PLL kernel's outstanding global sample loads too.
+// Both table phases first, both reads together, then the interpolations (same operations per value as sin_f32 / cos_f32).
+typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;
+__device__ __forceinline__ void sincos_pll(const float *sine, float phase, float &c, float &s, float two_pi, double inv_two_pi, double half_pi_d) {
+  const uint32_t ipc = sin_index<true>((float)((double)phase + half_pi_d), two_pi, inv_two_pi);
+  const uint32_t ips = sin_index<true>(phase, two_pi, inv_two_pi);
+  lds_cfloat_ptr tab = (lds_cfloat_ptr)sine;
+  const float c1 = tab[ipc >> 8], c2 = tab[(ipc >> 8) + 1], s1 = tab[ips >> 8], s2 = tab[(ips >> 8) + 1];
+  c = c1 + ((c2 - c1) * (float)(ipc & 0xFFu)) * (1.0f / 256.0f);
+  s = s1 + ((s2 - s1) * (float)(ips & 0xFFu)) * (1.0f / 256.0f);
+}
 // AudioSDR.h:384-408
 __device__ __forceinline__ float approx_atan(float z) {
   const float n1 = 0.97239411f, n2 = -0.19194795f;
@@ -563,15 +576,25 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // read / write the four IF samples i .. i + 3 of the channel (its LDS rows in the fused kernels, its exchange tile in the
 // stand-alone PLL kernel); Sc = the channel's state row.  Returns the lock flag after the block.
 // CH = samples per loop trip (4 from LDS; 16 in the PLL kernel, whose accessor requests the next trip's samples from HBM first).
-template <bool TWO_SUMS, int CH, typename LD, typename ST>
+// PF: the accessor reads HBM (the stand-alone PLL kernel): the NEXT trip's samples are requested before this trip's arithmetic, so
+// that the chain never waits for memory.
+template <bool TWO_SUMS, int CH, bool PF = false, typename LD, typename ST>
 __device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, const float *sine, float two_pi, LD ld, ST st) {
     float y_re = Sc->pll_y_re, y_im = Sc->pll_y_im, prev_filt = Sc->pll_prev_filt;
     float d0 = Sc->pll_d0, d1 = Sc->pll_d1, phase_est = Sc->pll_phase_est, pfreq = Sc->pll_freq;
     bool locked = false;
+    float nr[CH], ni[CH];
+    if (PF) ld(0, nr, ni);
 #pragma unroll 1
     for (int i = 0; i < ASDR_N; i += CH) {
       float xr[CH], xi[CH];
-      ld(i, xr, xi);
+      if (PF) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { xr[u] = nr[u]; xi[u] = ni[u]; }
+        ld((i + CH < ASDR_N) ? i + CH : i, nr, ni);   // (the last trip re-reads its own samples: no branch)
+      } else {
+        ld(i, xr, xi);
+      }
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const float x_re = xr[u], x_im = xi[u];
@@ -603,8 +626,12 @@ __device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, co
             while (phase_est <= -pi_up && turns < ASDR_PLL_WRAP_MAX) { phase_est += two_pi; ++turns; }
             if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f;
           } }
+#ifndef ASDR_PLL_FLAT_LOOKUPS
+        sincos_pll(sine, phase_est, y_re, y_im, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
+#else
         y_re = cos_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
         y_im = sin_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d);
+#endif
         pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
         locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
         const float o_re = x_re * y_re + x_im * y_im, o_im = -x_re * y_im + x_im * y_re;
@@ -2049,7 +2076,11 @@ extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs 
   // (The kernel is bound by its instruction count -- ~120 per sample and lane, 61 k wave instructions per SIMD for C3, as many as
   // the whole C2 chain -- not by these 32-byte accesses: 16-sample trips with the next trip's values requested ahead, and without
   // the stores altogether, changed its 0.18 ms by less than 0.01 / 0.04 ms.)
+#ifndef ASDR_PLL_NO_PREFETCH
+  const bool lk = pll_loop<false, 4, true>(Sc, a.k, sine, a.k.two_pi_f,
+#else
   const bool lk = pll_loop<false, 4>(Sc, a.k, sine, a.k.two_pi_f,
+#endif
     [&](int i, float *xr, float *xi) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const float *e = xt + (size_t)(i + u) * 16; xr[u] = e[0]; xi[u] = e[8]; } },
