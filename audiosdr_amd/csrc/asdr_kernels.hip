@@ -1142,39 +1142,61 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         WAVE_SYNC();
         if (nb_en) {   // zero mask[i-10 .. i+10] around every detection (:630); all writes are code 0, so order-free:
-                       // mask[m] is hit iff a detection index lies in [m-10, m+10] iff CB[m-44] - CB[m-65] > 0
-          const uint8_t *cb = reinterpret_cast<const uint8_t *>(Li + NB_CB);
-          const int m0 = 68 + s8 * 25;
+                       // mask[m] is hit iff a detection index lies in [m-10, m+10] iff CB[m-44] - CB[m-65] > 0.
+          // Four entries per operation (bytes of a word): lane s8 owns the code words 17 + 7 s8 .. + 6 (entries 68 + 28 s8 ..; words
+          // from 67 on lie behind the last entry a detection can reach: for them the two counts are the block's total and their
+          // difference 0).  The counts at m - 44 start on a word of CB, the counts at m - 65 three bytes into one (v_alignbyte).
+          const int wz = 17 + 7 * s8;
+          const uint32_t *cbw32 = reinterpret_cast<const uint32_t *>(Li + NB_CB);
+          uint32_t hi[7], lo[8], old[7];
 #pragma unroll
-          for (int g5 = 0; g5 < 25; g5 += 5) {
-            int hi[5], lo[5];
+          for (int z = 0; z < 7; ++z) { hi[z] = cbw32[wz + z - 11]; old[z] = (uint32_t)Li[NB_MSKB + wz + z]; }
 #pragma unroll
-            for (int r = 0; r < 5; ++r) { hi[r] = cb[m0 - 44 + g5 + r]; lo[r] = cb[m0 - 65 + g5 + r]; }
+          for (int z = 0; z < 8; ++z) lo[z] = cbw32[wz + z - 17];
 #pragma unroll
-            for (int r = 0; r < 5; ++r) if (m0 + g5 + r <= 265 && hi[r] - lo[r] > 0) mb[m0 + g5 + r] = (uint8_t)0;
-            SCHED_FENCE();
+          for (int z = 0; z < 7; ++z) {
+            const uint32_t lo3 = __builtin_amdgcn_alignbyte(lo[z + 1], lo[z], 3);   // counts at m - 65 for the word's four entries
+            const uint32_t d = hi[z] - lo3;                                           // bytewise: the counts only grow and differ by <= 21
+            const uint32_t nz = (d + 0x7F7F7F7Fu) & 0x80808080u;                      // bit 7 of every non-zero byte
+            const uint32_t ff = nz | (nz - (nz >> 7));                                // ... spread over the byte
+            if (wz + z <= 66) Li[NB_MSKB + wz + z] = (int)(old[z] & ~ff);             // code 0 where a detection reaches
           }
         }
         WAVE_SYNC();
         if (nb_en) {   // trailing-edge ramp (:637-644; only the first branch is reachable).  An edge at i
                        // writes mask[i-7..i-1] only, which later iterations never read: read all, then write.
-                       // codes of mask[124 + k0 .. 143 + k0] (five aligned words); entry 127 + k0 + j is byte 3 + j of them
+                       // codes of mask[124 + k0 .. 143 + k0] (five aligned words); entry 124 + k0 + p is byte p of them
           uint32_t evw[5];
 #pragma unroll
           for (int z = 0; z < 5; ++z) evw[z] = (uint32_t)Li[NB_MSKB + 31 + 4 * s8 + z];
           WAVE_SYNC();   // (every lane's reads are issued before any lane's writes: one wave, LDS in order)
-          // {.933, .750, .500, .250, .067, 0, 0} (:608) = codes 2, 3, 4, 5, 6, 0, 0
+          // edge at i = 124 + k0 + p  <=>  code[p] == 1 and code[p - 1] == 0, p = 4..19: bit 7 of byte p of the words below (exact
+          // bytewise tests: a byte is zero iff neither its low seven bits nor its top bit are set)
+          uint32_t zb[5], ob[5];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const uint32_t c_prev = (evw[(3 + j) >> 2] >> (8 * ((3 + j) & 3))) & 0xFFu, c_here = (evw[(4 + j) >> 2] >> (8 * ((4 + j) & 3))) & 0xFFu;
-            if (c_here == 1u && c_prev == 0u) {
-              uint8_t *w = mb + 128 + k0 + j - 7;
-              // (the seven code bytes out of two registers materialised HERE: as seven literals the compiler parks them in VGPRs
-              // for the whole kernel)
-              uint32_t lo4 = 0x05040302u, hi4 = 0x00000006u;
-              asm volatile("" : "+v"(lo4), "+v"(hi4));
-              w[0] = (uint8_t)lo4; w[1] = (uint8_t)(lo4 >> 8); w[2] = (uint8_t)(lo4 >> 16); w[3] = (uint8_t)(lo4 >> 24);
-              w[4] = (uint8_t)hi4; w[5] = (uint8_t)(hi4 >> 8); w[6] = (uint8_t)(hi4 >> 16);
+          for (int z = 0; z < 5; ++z) {
+            const uint32_t w = evw[z], x = w ^ 0x01010101u;
+            zb[z] = ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+            ob[z] = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+          }
+          uint32_t ed[4];
+#pragma unroll
+          for (int z = 1; z < 5; ++z) ed[z - 1] = ob[z] & __builtin_amdgcn_alignbit(zb[z], zb[z - 1], 24);   // zero flags moved up one byte
+          if ((ed[0] | ed[1] | ed[2] | ed[3]) != 0u) {   // (rare: at most a few edges per channel and block)
+            // {.933, .750, .500, .250, .067, 0, 0} (:608) = codes 2, 3, 4, 5, 6, 0, 0 out of two registers materialised HERE (as seven
+            // literals the compiler parks them in VGPRs for the whole kernel)
+            uint32_t lo4 = 0x05040302u, hi4 = 0x00000006u;
+            asm volatile("" : "+v"(lo4), "+v"(hi4));
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+              uint32_t e = ed[z];
+              while (e != 0u) {
+                const int p = 4 * (z + 1) + (__builtin_ctz(e) >> 3);
+                e &= e - 1u;
+                uint8_t *w = mb + 124 + k0 + p - 7;
+                w[0] = (uint8_t)lo4; w[1] = (uint8_t)(lo4 >> 8); w[2] = (uint8_t)(lo4 >> 16); w[3] = (uint8_t)(lo4 >> 24);
+                w[4] = (uint8_t)hi4; w[5] = (uint8_t)(hi4 >> 8); w[6] = (uint8_t)(hi4 >> 16);
+              }
             }
           }
         }
@@ -1530,7 +1552,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       TL(9);
       if (!IDL_EARLY && is_ssb) {   // delayed I = previous block's mixed I (:111); requested here: the FIR has no registers to spare for it
 #pragma unroll
-        for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
+        for (int m = 0; m < 4; ++m) {
+#if ASDR_NT_LOADS >= 4
+          load4_nt(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
+#else
+          load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
+#endif
+        }
       }
       if (is_ssb) {   // the FIR owns 16 contiguous outputs per lane; the combine works on the float-row pieces: hand over through W1
 #pragma unroll
