@@ -456,7 +456,7 @@ __device__ __forceinline__ void als_group_load(AlsGroup &G, const float *wh, con
   G.x0 = xh[-8 * g]; G.x1 = xh[-8 * g - 2]; G.x2 = xh[-8 * g - 4]; G.x3 = xh[-8 * g - 6];
 }
 __device__ __forceinline__ float als_group_sum(float y, const AlsGroup &G) {
-  const float p0 = G.w.x * G.x0, p1 = G.w.y * G.x1, p2 = G.w.z * G.x2, p3 = G.w.w * G.x3;
+  const float p0 = G.w.x * G.x0, p1 = G.w.y * G.x1, p2 = G.w.z * G.x2, p3 = G.w.w * G.x3;   // (as two v_pk_mul_f32: no gain, profiles/README.md)
   y += p0; y += dpp_row_shl4(p0); y += p1; y += dpp_row_shl4(p1);
   y += p2; y += dpp_row_shl4(p2); y += p3; y += dpp_row_shl4(p3);
   return y;
@@ -2089,13 +2089,17 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pos
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, true, false, true, 1, 5>(a, lds);
 }
+#ifndef ASDR_PLL_LANES
+#define ASDR_PLL_LANES 64   /* channels per wave of the PLL kernel (experiments: 32 = twice the waves, each half empty) */
+#endif
 // One LANE per channel: lane l of workgroup w runs the PLL of schedule slot 64 w + l on the rows the pre kernel left in its tile.
 extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs a) {
   __shared__ float sine[ASDR_SINE_TABLE_LEN];
   const int lane = threadIdx.x;
   for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
   __syncthreads();
-  const int s = (int)blockIdx.x * 64 + lane;
+  if (lane >= ASDR_PLL_LANES) return;
+  const int s = (int)blockIdx.x * ASDR_PLL_LANES + lane;
   if (s >= a.n_sched) return;
   const int4 sl = *reinterpret_cast<const int4 *>(a.sched + s);   // {channel, mode, flags, -}
   if (sl.x >= a.n_channels || (uint32_t)sl.y != ASDR_SAMmode) return;
@@ -2308,7 +2312,7 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   else if ((variant == ASDR_KERNEL_SAM || variant == ASDR_KERNEL_SAM_ALS) && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
     if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + 63) / 64), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
     if (variant == ASDR_KERNEL_SAM_ALS) {
       if (uniform) hipLaunchKernelGGL(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
       else hipLaunchKernelGGL(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);

@@ -1,26 +1,35 @@
 #!/bin/bash
 # One GPU-box call that produces everything profiles/ needs for the current build (copy the results from gpurun_out/<tag>/):
-#   bench.json            python bench.py (default flags: the driver's N=1 command)
-#   kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command (default flags, CPU baseline leg skipped; kernel rows only)
-#   pmc.json              rocprofv3 --pmc passes of the same command (tools/prof_pmc2.sh; HBM traffic = 2*FETCH_SIZE + WRITE_SIZE)
-#   configs_1gpu.jsonl    tools/bench_configs.py: BASELINE configs 1-5 on one GPU with their parity checks
-#   c3_kernel_stats.csv, c4_kernel_stats.csv   rocprofv3 --kernel-trace --stats of tools/bench_configs.py c3 / c4 (which launches, how long)
+#   bench.json              python bench.py (default flags: the driver's N=1 command; headline + robustness + cpu_baseline)
+#   bench_driver.json       python bench.py --gpus 1 --steps 20 --warmup 5 (the driver's exact command line)
+#   kernel_stats.csv        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-robustness` (headline launches only)
+#   pmc.json                rocprofv3 --pmc passes of the C2 command (tools/prof_pmc2.sh; HBM traffic = 2*FETCH_SIZE + WRITE_SIZE)
+#   pmc_c3.json, pmc_c4.json   the same passes of tools/bench_configs.py c3 / c4, per kernel
+#   configs_1gpu.jsonl      tools/bench_configs.py: BASELINE configs 1-5 on one GPU with their parity checks
+#   bench_c4.json, bench_c5.json   python bench.py --config c4 / c5 (N = 1: the whole job on one GPU)
+#   c3_kernel_stats.csv, c4_kernel_stats.csv   rocprofv3 --kernel-trace --stats of tools/bench_configs.py c3 / c4
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/stats.log" 2>&1 )
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-robustness > "$OUT/stats.log" 2>&1 )
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
 bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc" > "$OUT/pmc.log" 2>&1
-cp "$OUT/pmc.json" "$OUT/pmc_final.json" 2>/dev/null
+bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c3" "tools/bench_configs.py c3: SAM, 262144 channels x 1 block per launch" python3 $ROOT/tools/bench_configs.py c3 > "$OUT/pmc_c3.log" 2>&1
+bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c4" "tools/bench_configs.py c4: mixed modes + ALS, 131072 channels x 1 block per launch" python3 $ROOT/tools/bench_configs.py c4 > "$OUT/pmc_c4.log" 2>&1
 python3 tools/bench_configs.py c1 c2 c2s c3 c4 c5 > "$OUT/configs_1gpu.jsonl" 2> "$OUT/configs.err"
+python3 bench.py --config c4 --no-cpu-baseline --steps 300 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config c5 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
+python3 bench.py --config c5 --channels 512 --no-cpu-baseline --steps 64 > "$OUT/bench_c5_share.json" 2> "$OUT/bench_c5_share.err"
 for c in c3 c4; do
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$c" -- python3 "$ROOT/tools/bench_configs.py" $c > "$OUT/stats_$c.log" 2>&1 )
   f=$(find "$OUT/stats_$c" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${c}_kernel_stats.csv"
 done
-cat "$OUT/bench.json"; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/configs_1gpu.jsonl"
+rm -rf "$OUT/stats" "$OUT/stats_c3" "$OUT/stats_c4" "$OUT"/pmc/*/ "$OUT"/pmc_c3/*/ "$OUT"/pmc_c4/*/
+cat "$OUT/bench.json"; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/configs_1gpu.jsonl"; cat "$OUT/bench_c4.json" "$OUT/bench_c5.json" "$OUT/bench_c5_share.json"
