@@ -28,7 +28,7 @@
 // group (asdr_stream_kernel): all 3 x waves workgroups must be resident at once, hence the cap; shorter calls are not worth the
 // pipeline's fill and drain.
 #ifndef ASDR_STREAM_MAX_WAVES
-#define ASDR_STREAM_MAX_WAVES 84   /* 3 x 84 + 1 = 253 workgroups: one per CU, the condition the fence-free hand-off is measured for */
+#define ASDR_STREAM_MAX_WAVES 1024   /* upper bound on what the occupancy query may allow (asdr_create) */
 #endif
 #ifndef ASDR_STREAM_MIN_BLOCKS
 #define ASDR_STREAM_MIN_BLOCKS 8
@@ -603,12 +603,13 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     }
     if (ok && asdr_kernels_upload_tables() != 0) ok = false;
     if (ok) {
-      // The pipeline's hand-off is measured for one workgroup per compute unit, and its roles wait for each other: 3 w + 1 workgroups
-      // must fit the device at once (occupancy query, not an assumption about the part) and stay within one per compute unit.
+      // The pipeline's roles wait for each other: its 3 w workgroups must fit the device at once -- an occupancy query, not an
+      // assumption about the part (MI355X: 6 workgroups of this kernel per compute unit x 256 = 1,536 -> 512 channel groups).
+      // Measured with several workgroups per compute unit (tools/stream_sizes.py): 6.9 us per block up to 84 groups, 7.3 at 128,
+      // 8.4 at 256, 11.0 at 512 -- against 18.9-20.2 us for the in-kernel block loop at every one of those sizes.
       int cus = 0;
       const int cap = asdr_stream_capacity(device, &cus);
-      const int wg = cap < cus ? cap : cus;
-      b->stream_max_waves = wg >= 4 ? (wg - 1) / 3 : 0;
+      b->stream_max_waves = cap >= 3 ? cap / 3 : 0;
       if (b->stream_max_waves > ASDR_STREAM_MAX_WAVES) b->stream_max_waves = ASDR_STREAM_MAX_WAVES;
     }
     if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
@@ -752,7 +753,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
                 hipMalloc(&xb, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)) == hipSuccess &&
                 hipMalloc(&prog, n_prog * sizeof(uint32_t)) == hipSuccess &&
                 hipMalloc(&ring, ASDR_LO_RING * sizeof(LoEntry)) == hipSuccess &&
-                hipMalloc(&snap, (size_t)ASDR_STREAM_MAX_WAVES * 8 * ASDR_SNAP_BYTES) == hipSuccess &&
+                hipMalloc(&snap, (size_t)(((b->n + 7) / 8) * 8) * ASDR_SNAP_BYTES) == hipSuccess &&
                 hipMemsetAsync(prog, 0, n_prog * sizeof(uint32_t), stream) == hipSuccess;
       if (!ok) {
         for (void *p : {(void *)xa, (void *)xb, (void *)prog, (void *)ring, snap}) if (p) hipFree(p);
@@ -1171,6 +1172,12 @@ int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels)
   b->sam_fused = fused != 0;
   b->sam_split_min = split_min_channels > 0 ? split_min_channels : ASDR_SAM_SPLIT_MIN_CHANNELS;
   b->sched_dirty = true;
+  return 0;
+}
+int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups) {   // experiments: more than one pipeline workgroup per compute unit
+  if (!b) return fail("null batch");
+  if (groups < 0 || groups > 1024) return fail("bad group count");
+  b->stream_max_waves = groups;
   return 0;
 }
 int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls) {

@@ -2123,7 +2123,7 @@ extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs 
   Sc->status = (st & ~ASDR_S_PLL_LOCKED) | (lk ? ASDR_S_PLL_LOCKED : 0u);
 }
 
-// Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves),
+// Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves; the oscillator role is workgroup 0's second wave),
 // workgroup 3W the oscillator role; all 3W + 1 workgroups must be resident together (the host launches it only for small batches).  Uniform-key SSB waves only.
 // The pipeline's oscillator role (one wave): for every block of the call, the 128 phases that start where the previous block
 // ended -- the recurrence of AudioSDR.h:513-518 from the first channel's carried phase -- and their cos / sin pairs, left in
@@ -2196,17 +2196,23 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
 
 extern "C" __global__ __launch_bounds__(128, ASDR_WAVES_PER_EU) void asdr_stream_kernel(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  __shared__ __attribute__((aligned(16))) float lo_scratch[ASDR_N];   // the oscillator role's phase row (workgroup 0's second wave)
   const int role = (int)blockIdx.x / a.stream_waves;   // workgroup-uniform
-  // two waves per workgroup: the second one only exists for role 2, whose Hilbert FIR it shares (every other role: gone at once)
-  if (threadIdx.x >= 64) { if (role == 1) asdr_stream_fir_helper<ASDR_STRIDE>(a, lds); return; }
-  if (role == 3) asdr_stream_lo_role(a, lds);
-  else if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
+  // Two waves per workgroup.  The second one shares the Hilbert FIR in a role-2 workgroup, is the launch's oscillator role in
+  // workgroup 0 (so that the pipeline is exactly 3 W workgroups: 512 channel groups = 4,096 receivers fill an MI355X's 1,536
+  // resident workgroups of this kernel) and is gone at once everywhere else.
+  if (threadIdx.x >= 64) {
+    if (role == 1) asdr_stream_fir_helper<ASDR_STRIDE>(a, lds);
+    else if (blockIdx.x == 0) asdr_stream_lo_role(a, lo_scratch);
+    return;
+  }
+  if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
   else if (role == 1) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 2>(a, lds);
   else asdr_update_body<ASDR_STRIDE, false, false, true, 1, 3>(a, lds);
 }
 extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
   if (a->stream_waves <= 0) return 0;
-  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves + 1), dim3(128), 0, stream, *a);
+  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(128), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // How many workgroups of the pipeline kernel the device can hold at once (occupancy x compute units): the pipeline's roles wait

@@ -237,6 +237,10 @@ int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels)
 /* Test hook: the number of polls after which a pipeline wait gives up (0 = the default, 2^18).  A tiny value injects timeouts, so
  * that the recovery path can be tested on an idle GPU. */
 int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls);
+/* Test / experiment hook: overrides the largest number of channel groups the pipeline takes (asdr_stream_pipeline_max_groups();
+ * default from the occupancy query: one workgroup per compute unit).  Larger values put several pipeline workgroups on a compute
+ * unit; results stay exact (a wait that runs out is recovered as described above). */
+int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups);
 /* The wave schedule as the last flush built it (the next update's launches; a control-plane-only batch: after
  * asdr_control_plane_flush), in schedule slots (8 per wave): out[0..4] = the sub-ranges of whole waves of one settings group by
  * kernel kind -- 0 plain, 1 SAM, 2 ALS on the long rows, 3 ALS on the compact rows (taps <= 64, delay + taps <= 65, not SAM),

@@ -182,10 +182,11 @@ def test_block_pipeline_is_not_used_where_it_does_not_apply(gpu, ao):
         hip.free_all(); batch.close()
 
 
-@pytest.mark.parametrize("n_ch,T,pipelined", [(8, 9, True), (672, 11, True), (680, 9, False)])
+@pytest.mark.parametrize("n_ch,T,pipelined", [(8, 9, True), (672, 11, True), (680, 9, True), (4096, 9, True), (4104, 8, False)])
 def test_block_pipeline_sizes(gpu, ao, n_ch, T, pipelined):
-    """One channel group (a single wave per role), the largest batch the pipeline takes (84 groups: 3 x 84 + 1 workgroups), and
-    one group more (block-by-block path).  A mode change between two calls resets filter state through the usual path."""
+    """One channel group (a single wave per role), 84 groups (one pipeline workgroup per compute unit), 85, the largest batch the
+    pipeline takes on an MI355X (512 groups = 4,096 receivers: 3 x 512 workgroups, the occupancy query's limit) and one group more
+    (in-kernel block loop).  A mode change between two calls resets filter state through the usual path."""
     from audiosdr_amd.synth import make_iq
     I, Q = make_iq(n_ch, 2 * T, fc=6290.0, A=0.25, noise=0.02)
     batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter")])
@@ -204,6 +205,7 @@ def test_block_pipeline_sizes(gpu, ao, n_ch, T, pipelined):
             want = orcs[c].update(I[c, sl], Q[c, sl]).reshape(T, 128)
             assert np.array_equal(got[c], want), "call %d ch %d" % (call, c)
     assert batch.stream_pipeline_launches() == (2 if pipelined else 0)
+    assert batch.stream_pipeline_recoveries() == 0
     hip.free_all(); batch.close()
 
 
