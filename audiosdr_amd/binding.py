@@ -53,7 +53,7 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 # every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
-            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_set_exact_unknown_mode", "asdr_get_exact_unknown_mode", "asdr_stream_pipeline_recoveries", "asdr_stream_pipeline_max_groups", "asdr_set_stream_pipeline", "asdr_set_sam_launch_form", "asdr_debug_set_stream_spin_limit", "asdr_debug_set_stream_max_groups", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
+            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_set_exact_unknown_mode", "asdr_get_exact_unknown_mode", "asdr_stream_pipeline_recoveries", "asdr_stream_pipeline_max_groups", "asdr_set_stream_pipeline", "asdr_set_sam_launch_form", "asdr_set_als_launch_form", "asdr_debug_set_stream_spin_limit", "asdr_debug_set_stream_max_groups", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
             "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_set_launch_timing", "asdr_region_timing_begin", "asdr_region_timing_end", "asdr_update_device_strided", "asdr_capture_open",
             "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read"] +
@@ -121,6 +121,8 @@ def load_library(path=None):
         L.asdr_stream_pipeline_max_groups.argtypes = [vp]; L.asdr_stream_pipeline_max_groups.restype = _i
         L.asdr_set_stream_pipeline.argtypes = [vp, _i]; L.asdr_set_stream_pipeline.restype = _i
         L.asdr_set_sam_launch_form.argtypes = [vp, _i, _i]; L.asdr_set_sam_launch_form.restype = _i
+        if hasattr(L, "asdr_set_als_launch_form"):
+            L.asdr_set_als_launch_form.argtypes = [vp, _i]; L.asdr_set_als_launch_form.restype = _i
         L.asdr_debug_set_stream_spin_limit.argtypes = [vp, _u]; L.asdr_debug_set_stream_spin_limit.restype = _i
         L.asdr_debug_set_stream_max_groups.argtypes = [vp, _i]; L.asdr_debug_set_stream_max_groups.restype = _i
     if path is None or hasattr(L, "asdr_set_exact_unknown_mode"):
@@ -258,6 +260,9 @@ class AudioSDRBatch:
     def set_sam_launch_form(self, fused=False, split_min_channels=0):
         self._chk(self._L.asdr_set_sam_launch_form(self._h, 1 if fused else 0, int(split_min_channels)))
 
+    def set_als_launch_form(self, split_min_channels=0):
+        self._chk(self._L.asdr_set_als_launch_form(self._h, int(split_min_channels)))
+
     def debug_set_stream_max_groups(self, groups):
         self._chk(self._L.asdr_debug_set_stream_max_groups(self._h, int(groups)))
 
@@ -270,7 +275,7 @@ class AudioSDRBatch:
         self._chk(self._L.asdr_schedule_layout(self._h, out))
         v = list(out)
         return {"plain": v[0], "sam": v[1], "als_long": v[2], "als_compact": v[3], "sam_als": v[4], "remainders": v[5],
-                "remainder_kind": v[6], "sam_three_launches": bool(v[7])}
+                "remainder_kind": v[6], "sam_three_launches": bool(v[7] & 1), "als_two_launches": bool(v[7] & 2)}
 
     def set_launch_timing(self, on):
         self._chk(self._L.asdr_set_launch_timing(self._h, 1 if on else 0))

@@ -12,7 +12,7 @@
  *   nb_mask  uint8       [C+1][160]        160 B  mask codes of (middle block + 10 look-ahead), 138 used
  *   hil_q    float       [C+1][2][128]     1 KiB  Hilbert Q history ring (2 previous shifted blocks)
  *   hil_i    float       [C+1][2][128]     1 KiB  ring of mixed I blocks (this block, previous = the 128-sample delay)
- *   als_x    float       [C+1][128]        512 B  previous ALS input block
+ *   als_x    float       [C+1][2][128]     1 KiB  ring of ALS input blocks (this block, previous block); position = UpdateArgs.als_phase
  *   als_w    float       [C+1][128]        512 B  ALS coefficients
  *   audio_prev float     [C+1][128]        512 B  _audioOut as the block left it (after the audio filter / AGC / ALS): what an
  *                                                 unknown mode value re-processes (AudioSDR.cpp:84,122,149-161)
@@ -139,6 +139,9 @@ typedef struct {
   int16_t *out;
   int32_t n_blocks;       /* blocks per channel processed by this call */
   uint32_t nb_phase;      /* blocks processed by the batch so far, mod 3: oldest slot of every channel's blanker ring */
+  uint32_t als_phase;     /* blocks processed by the batch so far, mod 2: the slot of the ALS input ring (als_x) THIS block's input goes to;
+                             the other slot holds the previous block's (enableALSfilter zeroes both, AudioSDR.cpp:384-391, so a channel
+                             whose filter was off meanwhile never sees a stale position) */
   LoEntry *lo_cache;      /* [2] */
   uint32_t lo_parity;     /* entry this launch reads; wave 0 of the launch with lo_write set fills the other one */
   uint32_t lo_write;

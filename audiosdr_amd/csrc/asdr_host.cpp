@@ -194,6 +194,9 @@ struct asdr_batch {
   void *d_stream_snap = nullptr;    // snapshot of the state a pipeline call advances (asdr_kernels.hip "the pipeline as a transaction")
   long stat_stream_recoveries = 0;  // pipeline calls that gave up and were re-run on the in-kernel block loop (read back at synchronisation points)
   bool sam_split = false;           // decided when the schedule is built (enough SAM channels, not sam_fused)
+  int als_split_min = 0x7fffffff;   // channels with a short ALS filter (not SAM) run as chain | filter launches from this many on (default: never --
+                                    // measured: 2 % faster for C4's 131,072-channel share, 6 % slower at 1,048,576 channels, 3 % slower all-ALS)
+  bool als_split = false;           // decided when the schedule is built
   float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
   size_t xch_sam_slots = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
@@ -201,6 +204,7 @@ struct asdr_batch {
   long stat_stream_launches = 0;
   uint32_t lo_parity = 0;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
+  uint32_t als_phase = 0;        // blocks processed so far, mod 2 (position of every channel's ALS input ring)
   ChainConsts k{};
 };
 
@@ -388,6 +392,12 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     int n_sam = 0;
     for (int i = 0; i < b->n; i++) { const int k = (int)(order[i].first >> 60); n_sam += (k == ASDR_KERNEL_SAM || k == ASDR_KERNEL_SAM_ALS); }
     b->sam_split = !b->sam_fused && n_sam >= b->sam_split_min;
+    {   // short ALS filters on channels that are not SAM: the chain up to the AGC as the plain instantiation, then the filter as a
+        // launch of its own (asdr_als_kernel: small LDS rows, 18 waves per CU) -- when there are enough of them to fill it
+      int n_als_small = 0;
+      for (int i = 0; i < b->n; i++) n_als_small += ((int)(order[i].first >> 60) == ASDR_KERNEL_ALS_SMALL);
+      b->als_split = n_als_small >= b->als_split_min;
+    }
     const bool sam_general_only = !b->sam_split;
     // The remainders (< 8 channels) of all key groups share ONE sub-range behind the kinds' whole waves, run by one launch of a
     // general instantiation: as a launch per kind they were up to five more streams of a handful of long-lived waves each, and
@@ -494,7 +504,7 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
   a.audio_prev = b->exact_unknown_mode ? b->d_audio_prev : nullptr;
   a.sched = b->d_sched; a.n_sched = 0; a.n_channels = b->n;   // the launcher sets the sub-range
   a.taps = b->taps_on ? b->d_taps : nullptr;
-  a.nb_phase = b->nb_phase;
+  a.nb_phase = b->nb_phase; a.als_phase = b->als_phase;
   a.lo_cache = b->d_lo; a.lo_parity = b->lo_parity; a.lo_write = 0;
   a.k = b->k;
 }
@@ -568,6 +578,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   b->sam_fused = getenv("ASDR_SAM_FUSED") != nullptr;
   b->sam_split_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;
   b->stream_pipeline = getenv("ASDR_NO_STREAM_PIPELINE") == nullptr;
+  b->als_split_min = getenv("ASDR_ALS_SPLIT_MIN") ? atoi(getenv("ASDR_ALS_SPLIT_MIN")) : 0x7fffffff;
   const size_t rows = (size_t)n_channels + 1;
   if (device != ASDR_NO_DEVICE) {
     int ndev = 0;
@@ -582,7 +593,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_nb_mask, rows * ASDR_NB_MASK_ROW * sizeof(uint8_t));
     alloc((void **)&b->d_hil_q, rows * 256 * sizeof(float));
     alloc((void **)&b->d_hil_i, rows * 256 * sizeof(float));
-    alloc((void **)&b->d_als_x, rows * 128 * sizeof(float));
+    alloc((void **)&b->d_als_x, rows * 256 * sizeof(float));
     alloc((void **)&b->d_als_w, rows * 128 * sizeof(float));
     alloc((void **)&b->d_audio_prev, rows * 128 * sizeof(float));
     if (ok && hipMemset(b->d_audio_prev, 0, rows * 128 * sizeof(float)) != hipSuccess) ok = false;
@@ -738,7 +749,10 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     b->d_xch_sam = grown; b->xch_sam_slots = (size_t)sam_slots;
   }
   a.xch_sam = sam_split ? b->d_xch_sam : nullptr;
-  const bool per_block = n_blocks > 1 && (sam_split || total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES);
+  // ... and channels with a short ALS filter as two: the chain up to the AGC | the filter and the output stage (stage taps off: the taps
+  // of the last two stages are the fused kernel's)
+  const bool als_split = b->als_split && !b->taps_on && b->kind_uniform_slots[ASDR_KERNEL_ALS_SMALL] > 0;
+  const bool per_block = n_blocks > 1 && (sam_split || als_split || total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES);
   // Small batch, many blocks, one sub-range of uniform SSB-class waves, no taps: the block pipeline -- as a transaction: a snapshot of
   // the state in front of it, and behind it the launches that put the state back and run the call on the in-kernel block loop if a
   // role's bounded wait fired (asdr_kernels.hip).  3 w + 1 workgroups must be co-resident: w <= stream_max_waves (occupancy query at
@@ -785,6 +799,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (b->region_calls >= 0) b->region_calls++;
     b->last_stream = stream;
     b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
+    b->als_phase = (b->als_phase + (uint32_t)n_blocks) & 1u;
     b->lo_parity ^= 1u;
     return 0;
   }
@@ -800,6 +815,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (per_block) {
       a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
       a.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
+      a.als_phase = (b->als_phase + (uint32_t)lb) & 1u;
       a.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
       a.taps = (lb == n_launch - 1) ? taps : nullptr;   // the taps are those of the call's last block
     }
@@ -818,7 +834,8 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
         a.xch_sam = b->d_xch_sam + (size_t)(subs[i].first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM_ALS)   // ... behind those of the SAM kind
         a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + subs[i].first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
-      if (asdr_launch_update(&a, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
+      const int form = (als_split && subs[i].kind == ASDR_KERNEL_ALS_SMALL && subs[i].uniform) ? 2 : subs[i].uniform;
+      if (asdr_launch_update(&a, subs[i].kind, form, s) != 0) return fail("update kernel launch failed");
       if (i != main_sub) HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
     }
     for (int j = 0; j + 1 < n_sub; j++) HIPCHK(hipStreamWaitEvent(stream, b->ev_join[j], 0));   // behind the caller's stream's own launch
@@ -829,6 +846,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   if (b->region_calls >= 0) b->region_calls++;
   b->last_stream = stream;
   b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
+  b->als_phase = (b->als_phase + (uint32_t)n_blocks) & 1u;
   b->lo_parity ^= (uint32_t)(n_launch & 1);
   return 0;
 }
@@ -1167,6 +1185,12 @@ long asdr_stream_pipeline_recoveries(asdr_batch_t *b) {
 }
 int asdr_stream_pipeline_max_groups(asdr_batch_t *b) { return b ? b->stream_max_waves : -1; }
 int asdr_set_stream_pipeline(asdr_batch_t *b, int on) { if (!b) return fail("null batch"); b->stream_pipeline = on != 0; return 0; }
+int asdr_set_als_launch_form(asdr_batch_t *b, int split_min_channels) {
+  if (!b) return fail("null batch");
+  b->als_split_min = split_min_channels > 0 ? split_min_channels : 0x7fffffff;
+  b->sched_dirty = true;
+  return 0;
+}
 int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels) {
   if (!b) return fail("null batch");
   b->sam_fused = fused != 0;
@@ -1202,7 +1226,7 @@ int asdr_get_exact_unknown_mode(asdr_batch_t *b) { return b ? (b->exact_unknown_
 int asdr_schedule_layout(asdr_batch_t *b, int out[8]) {
   if (!b || !out) return fail("null argument");
   for (int k = 0; k < ASDR_KERNEL_KINDS; k++) out[k] = b->kind_slots[k];
-  out[5] = b->left_slots; out[6] = b->left_slots ? b->left_kind : -1; out[7] = b->sam_split ? 1 : 0;
+  out[5] = b->left_slots; out[6] = b->left_slots ? b->left_kind : -1; out[7] = (b->sam_split ? 1 : 0) | (b->als_split ? 2 : 0);
   return 0;
 }
 

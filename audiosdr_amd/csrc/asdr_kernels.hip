@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 
 #include "asdr_device.h"
 #include "asdr_tables.h"
@@ -712,13 +713,183 @@ __device__ __forceinline__ void xch_load4x4(const float *p, v4f &v0, v4f &v1, v4
                : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p) : "memory");
 }
 
+// The ALS filter of one block (AudioSDR.cpp:329-351) on a channel's LDS rows: L[XB + idx] = sample idx of the reference's 256-sample
+// buffer (idx >= 128 - history kept), taps de-interleaved at L[AW ..] (ALS_TAP, WH per half), error broadcast word L[SCR], output sample
+// n at L[OUT + n].  OUT may overlay the history at buffer index i - 65 (the stand-alone ALS kernel): a sample's sums read no index
+// below i - 64, the four samples of a tap set are summed before any of them is written, and the tap update behind them reads from
+// i + 3 - 64 upwards.  Called by all lanes of the wave (wave-uniform branches inside).
+template <bool COMPACT, int XB, int AW, int WH, int SCR, int OUT>
+__device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive, bool notch, int M, int D, float lam, int s8, int k0) {
+    constexpr int AH = 2 * WH;
+    // every history index i - D - q (i = 128..255, q < M) is inside the kept window iff D >= 0 and D + M <= AH + 1: true for
+    // the reference's defaults (M 55, D 3) and checked per wave.  (The host sends a channel to a compact instantiation only
+    // if it is: the checked forms are compiled for the 516-float rows alone.)
+    const bool als_safe = COMPACT || __all(!als_en || (D >= 0 && D + M <= AH + 1));
+    const int M_u = __builtin_amdgcn_readfirstlane(M);
+    const bool als_m_uniform = __all(als_en && adaptive && M == M_u);   // the usual case: one filter length in the wave
+    const bool als_m_default = als_m_uniform && als_safe && M_u == ALS_M_DEFAULT;   // ... and the reference's default one
+    if (__any(als_en && !adaptive)) {   // static taps: every lane computes its 16 outputs, all results written after all reads
+      float yo[16];                     // (the output row may overlay the history: OUT != a row of its own in the stand-alone kernel)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) yo[j] = 0.0f;
+      if (als_en && !adaptive) {
+        for (int j = 0; j < 16; ++j) {
+          const int i = 128 + k0 + j;
+          float y;
+          if constexpr (COMPACT) y = als_dot<false, WH>(L + AW, L + XB, i - D, M);
+          else y = als_safe ? als_dot<false, WH>(L + AW, L + XB, i - D, M) : als_dot<true, WH>(L + AW, L + XB, i - D, M);
+          const float e = L[XB + i] - y;
+          yo[j] = notch ? e : y;
+        }
+      }
+      WAVE_SYNC();
+      if (als_en && !adaptive) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) L[OUT + k0 + j] = yo[j];
+      }
+    }
+#ifndef ASDR_ALS_TAPS_IN_LDS
+    if (als_m_default) {
+      // The reference's default length (55 taps, adaptive) in the whole wave: THE TAPS LIVE IN REGISTERS for the block.  Each half
+      // of a channel's eight lanes holds its 28 taps (even / odd) in every one of its four lanes, so a tap set costs no LDS reads,
+      // and the tap update w[q] += lambda * (e * x[iu - D - q]) (AudioSDR.cpp:341-343) needs none either: x[iu - D - q] for a lane's
+      // own taps is exactly the operand set the lane of the updating sample iu (lane 3 of the quad; lane 0 for the very first
+      // sample) has just used for its sum -- it arrives as a DPP quad broadcast folded into the multiply.  Same products, same
+      // sums, same order.  Per tap set: 14 two-sample LDS reads instead of 7 b128 + 28 + 21 accesses (the filter was bound by LDS
+      // bandwidth: asdr_als_kernel 0.237 ms for 131,072 channels, the LDS pipe ~65 % busy).
+      const int h = s8 >> 2;
+      float wr[7][4];
+#pragma unroll
+      for (int g = 0; g < 7; ++g) { const float4 t4 = *reinterpret_cast<const float4 *>(L + AW + WH * h + 4 * g); wr[g][0] = t4.x; wr[g][1] = t4.y; wr[g][2] = t4.z; wr[g][3] = t4.w; }
+      auto epoch = [&](auto first_tag, int ep) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int base = FIRST ? 0 : 4 * ep + 1;
+        const int cntn = FIRST ? 1 : ((ep == 31) ? 3 : 4);
+        const int n = base + (s8 & 3), i = 128 + n;
+        const bool mine = (s8 < cntn);
+        const float *xh = L + XB + (i - D - h);
+        float xs[7][4];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) { xs[g][0] = xh[-8 * g]; xs[g][1] = xh[-8 * g - 2]; xs[g][2] = xh[-8 * g - 4]; xs[g][3] = xh[-8 * g - 6]; }
+        float y = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float p = wr[g][t] * xs[g][t];
+            if (g == 6 && t == 3) p = (h == 0) ? p : 0.0f;   // tap 55 does not exist (the running sum starts at +0.0: adding +0.0 leaves it)
+            y += p; y += dpp_row_shl4(p);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from forming all 28 products -- and 28 moved copies -- up front: registers)
+        }
+        if (mine) {
+          const float e = L[XB + i] - y;
+          L[OUT + n] = notch ? e : y;
+          if ((n & 3) == 0) L[SCR] = e;
+        }
+        WAVE_SYNC();
+        const int nu = FIRST ? 0 : 4 * ep + 4;   // the updating sample of this epoch: lane 0's in the first one, lane 3's afterwards
+        if (nu < ASDR_N) {
+          const float e = L[SCR];
+#pragma unroll
+          for (int g = 0; g < 7; ++g) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float xu = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xs[g][t]), FIRST ? 0x00 : 0xFF, 0xF, 0xF, true));   // quad_perm:[k,k,k,k]
+              const float gq = e * xu; const float dq = lam * gq; const float wn = wr[g][t] + dq;
+              wr[g][t] = (g == 6 && t == 3 && h != 0) ? wr[g][t] : wn;
+            }
+          }
+        }
+        WAVE_SYNC();
+      };
+      epoch(std::true_type{}, -1);
+#pragma unroll 1
+      for (int ep = 0; ep < 32; ++ep) epoch(std::false_type{}, ep);
+      // the taps back to their LDS rows (one lane of each half: they all hold the same values)
+      if ((s8 & 3) == 0) {
+#pragma unroll
+        for (int g = 0; g < 7; ++g) *reinterpret_cast<float4 *>(L + AW + WH * h + 4 * g) = make_float4(wr[g][0], wr[g][1], wr[g][2], wr[g][3]);
+      }
+      WAVE_SYNC();
+    } else
+#endif
+    if (__any(als_en && adaptive)) {
+      // taps change only after samples n = 0, 4, 8, ...; samples sharing one tap set run on lanes s8 = 0..3
+#pragma unroll 1
+      for (int ep = -1; ep < 32; ++ep) {
+        const int base = (ep < 0) ? 0 : 4 * ep + 1;
+        const int cntn = (ep < 0) ? 1 : ((ep == 31) ? 3 : 4);
+        const int n = base + (s8 & 3);
+        const bool mine = als_en && adaptive && (s8 < cntn);
+        if (als_safe) {   // all eight lanes of the channel share the sum (als_dot_split); lanes 0-3 keep the results
+          const int i = 128 + n, h = s8 >> 2;
+          float y = 0.0f;
+          if (als_m_default) y = als_dot_split_const<ALS_M_DEFAULT>(L + AW + WH * h, L + XB + (i - D - h), h);
+          else if (als_m_uniform) y = als_dot_split_uniform(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
+          else if (als_en && adaptive) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M, h);
+          if (mine) {
+            const float e = L[XB + i] - y;
+            L[OUT + n] = notch ? e : y;
+            if ((n & 3) == 0) L[SCR] = e;
+          }
+        } else if (mine) {
+          if constexpr (!COMPACT) {
+            const int i = 128 + n;
+            const float y = als_dot<true, WH>(L + AW, L + XB, i - D, M);
+            const float e = L[XB + i] - y;
+            L[OUT + n] = notch ? e : y;
+            if ((n & 3) == 0) L[SCR] = e;
+          }
+        }
+        WAVE_SYNC();
+        const int nu = (ep < 0) ? 0 : 4 * ep + 4;   // the updating sample of this epoch
+        if (als_en && adaptive && nu < ASDR_N) {
+          const float e = L[SCR];
+          const int iu = 128 + nu;
+          if (als_m_default) {
+            als_tap_update_const<ALS_M_DEFAULT>(L + XB + iu - D - s8, L + AW + ALS_TAP(s8, WH), e, lam, s8);
+          } else if (als_m_uniform && als_safe) {
+            // lane s8 owns taps s8 + 8k (k < nk).  Eight of them per step, all operands requested together and all results
+            // written together: one LDS round trip per step instead of one per tap.  Steps run to a multiple of 8 taps per
+            // lane: the surplus ones (still inside the tap rows: M <= 64 -> k <= 7, M <= 128 -> k <= 15) are written back unchanged.
+            const float *xq = L + XB + iu - D - s8;
+            float *wq = L + AW + ALS_TAP(s8, WH);
+            const int nk = (M_u - s8 + 7) >> 3, nk_max = (M_u + 7) >> 3;
+#pragma unroll 1
+            for (int k0 = 0; k0 < nk_max; k0 += 8) {
+              float xv[8], wv[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { xv[j] = xq[-8 * (k0 + j)]; wv[j] = wq[4 * (k0 + j)]; }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { const float gq = e * xv[j]; const float dq = lam * gq; const float wn = wv[j] + dq; wv[j] = (k0 + j < nk) ? wn : wv[j]; }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) wq[4 * (k0 + j)] = wv[j];
+            }
+          } else if (als_safe) {
+#pragma unroll 2
+            for (int q = s8; q < M; q += 8) { const float gq = e * L[XB + iu - D - q]; const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
+          } else {
+            if constexpr (!COMPACT) {
+              for (int q = s8; q < M; q += 8) { const float gq = e * (((iu - D - q) >= 0 && (iu - D - q) < 256) ? L[XB + (iu - D - q)] : 0.0f); const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
+            }
+          }
+        }
+        WAVE_SYNC();
+      }
+    }
+}
 template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds_wg) {
   // ROLE 4 / 5: the SAM sub-range as three launches -- 4 = everything in front of the PLL (scale, blanker, IF filter), then the
   // stand-alone PLL kernel (asdr_sam_pll_kernel: one LANE per channel, 64 channels per wave -- the PLL is a 128-step dependent chain
   // per channel, and as one phase of a fused kernel it kept a whole workgroup waiting for ~58 k cycles per block), 5 = everything
   // behind it.  The IF rows cross in xch_sam; the lock flag in the status word.
-  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5), DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5);
+  // ROLE 6: the whole chain up to and including the AGC for channels whose (short) ALS filter runs as a launch of its own
+  // (asdr_als_kernel): the post-AGC row goes to the ALS input ring instead of through the filter and the output stage.
+  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4 || ROLE == 6), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5 || ROLE == 6),
+                 DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6);
+  constexpr bool TO_ALS = (ROLE == 6);
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
   if (ROLE == 0 && a.run_if != nullptr && *a.run_if == 0u) return;   // the pipeline's fallback launch: nothing to do unless the pipeline gave up
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
@@ -1627,7 +1798,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         store8(L + W0 + kA + 64 * h, vq);
       }
     }
-    if (ROLE == 0 && !is_ssb && !is_am && mode != ASDR_SAMmode) {
+    if ((ROLE == 0 || ROLE == 6) && !is_ssb && !is_am && mode != ASDR_SAMmode) {
       // Unknown mode value: neither demodulator branch runs (AudioSDR.cpp:84, 122), _audioOut still holds what the PREVIOUS block
       // left in it -- its audio after the audio filter, AGC and ALS -- and those stages now process it again (:149-161).  The row
       // comes back from HBM (every block stores it, below).  Without the row (asdr_set_exact_unknown_mode(b, 0)): silence.
@@ -1838,12 +2009,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const int M = P.als_m, D = P.als_delay;
         const float lam = P.als_lambda;   // (requested once, not in every tap-update epoch)
         const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
-        float *gx = a.als_x + (size_t)ch * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
+        const uint32_t as = (a.als_phase + (uint32_t)blk) & 1u;   // ring slot of this block's input; the other one holds the previous block's
+        float *gx = a.als_x + (size_t)ch * (2 * ASDR_N) + as * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
+        const float *gx_prev = a.als_x + (size_t)ch * (2 * ASDR_N) + (as ^ 1u) * ASDR_N + kF;
         if (als_en) {
           float tx[16], tw[16], tn[16];   // all row loads in flight together
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            if (m >= M0) load4(gx + 32 * m, tx + 4 * m);
+            if (m >= M0) load4(gx_prev + 32 * m, tx + 4 * m);
             if (m < NW) load4(gw + 32 * m, tw + 4 * m);
             load4(L + W0 + kF + 32 * m, tn + 4 * m);
           }
@@ -1859,90 +2032,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           }
         }
         WAVE_SYNC();
-#define ALS_HIST(idx) (((idx) >= 0 && (idx) < 256) ? L[XB + (idx)] : 0.0f)
-        // every history index i - D - q (i = 128..255, q < M) is inside the kept window iff D >= 0 and D + M <= AH + 1: true for
-        // the reference's defaults (M 55, D 3) and checked per wave.  (The host sends a channel to a compact instantiation only
-        // if it is: the checked forms are compiled for the 516-float rows alone.)
-        const bool als_safe = COMPACT || __all(!als_en || (D >= 0 && D + M <= AH + 1));
-        const int M_u = __builtin_amdgcn_readfirstlane(M);
-        const bool als_m_uniform = __all(als_en && adaptive && M == M_u);   // the usual case: one filter length in the wave
-        const bool als_m_default = als_m_uniform && als_safe && M_u == ALS_M_DEFAULT;   // ... and the reference's default one
-        if (__any(als_en && !adaptive)) {
-          if (als_en && !adaptive) {
-            for (int j = 0; j < 16; ++j) {
-              const int i = 128 + k0 + j;
-              float y;
-              if constexpr (COMPACT) y = als_dot<false, WH>(L + AW, L + XB, i - D, M);
-              else y = als_safe ? als_dot<false, WH>(L + AW, L + XB, i - D, M) : als_dot<true, WH>(L + AW, L + XB, i - D, M);
-              const float e = L[XB + i] - y;
-              L[ALS_OUT + k0 + j] = notch ? e : y;
-            }
-          }
-        }
-        if (__any(als_en && adaptive)) {
-          // taps change only after samples n = 0, 4, 8, ...; samples sharing one tap set run on lanes s8 = 0..3
-#pragma unroll 1
-          for (int ep = -1; ep < 32; ++ep) {
-            const int base = (ep < 0) ? 0 : 4 * ep + 1;
-            const int cntn = (ep < 0) ? 1 : ((ep == 31) ? 3 : 4);
-            const int n = base + (s8 & 3);
-            const bool mine = als_en && adaptive && (s8 < cntn);
-            if (als_safe) {   // all eight lanes of the channel share the sum (als_dot_split); lanes 0-3 keep the results
-              const int i = 128 + n, h = s8 >> 2;
-              float y = 0.0f;
-              if (als_m_default) y = als_dot_split_const<ALS_M_DEFAULT>(L + AW + WH * h, L + XB + (i - D - h), h);
-              else if (als_m_uniform) y = als_dot_split_uniform(L + AW + WH * h, L + XB + (i - D - h), M_u, h);   // scalar loop count
-              else if (als_en && adaptive) y = als_dot_split(L + AW + WH * h, L + XB + (i - D - h), M, h);
-              if (mine) {
-                const float e = L[XB + i] - y;
-                L[ALS_OUT + n] = notch ? e : y;
-                if ((n & 3) == 0) L[SCR] = e;
-              }
-            } else if (mine) {
-              if constexpr (!COMPACT) {
-                const int i = 128 + n;
-                const float y = als_dot<true, WH>(L + AW, L + XB, i - D, M);
-                const float e = L[XB + i] - y;
-                L[ALS_OUT + n] = notch ? e : y;
-                if ((n & 3) == 0) L[SCR] = e;
-              }
-            }
-            WAVE_SYNC();
-            const int nu = (ep < 0) ? 0 : 4 * ep + 4;   // the updating sample of this epoch
-            if (als_en && adaptive && nu < ASDR_N) {
-              const float e = L[SCR];
-              const int iu = 128 + nu;
-              if (als_m_default) {
-                als_tap_update_const<ALS_M_DEFAULT>(L + XB + iu - D - s8, L + AW + ALS_TAP(s8, WH), e, lam, s8);
-              } else if (als_m_uniform && als_safe) {
-                // lane s8 owns taps s8 + 8k (k < nk).  Eight of them per step, all operands requested together and all results
-                // written together: one LDS round trip per step instead of one per tap.  Steps run to a multiple of 8 taps per
-                // lane: the surplus ones (still inside the tap rows: M <= 64 -> k <= 7, M <= 128 -> k <= 15) are written back unchanged.
-                const float *xq = L + XB + iu - D - s8;
-                float *wq = L + AW + ALS_TAP(s8, WH);
-                const int nk = (M_u - s8 + 7) >> 3, nk_max = (M_u + 7) >> 3;
-#pragma unroll 1
-                for (int k0 = 0; k0 < nk_max; k0 += 8) {
-                  float xv[8], wv[8];
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) { xv[j] = xq[-8 * (k0 + j)]; wv[j] = wq[4 * (k0 + j)]; }
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) { const float gq = e * xv[j]; const float dq = lam * gq; const float wn = wv[j] + dq; wv[j] = (k0 + j < nk) ? wn : wv[j]; }
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) wq[4 * (k0 + j)] = wv[j];
-                }
-              } else if (als_safe) {
-#pragma unroll 2
-                for (int q = s8; q < M; q += 8) { const float gq = e * L[XB + iu - D - q]; const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
-              } else {
-                if constexpr (!COMPACT) {
-                  for (int q = s8; q < M; q += 8) { const float gq = e * ALS_HIST(iu - D - q); const float dq = lam * gq; L[AW + ALS_TAP(q, WH)] += dq; }
-                }
-              }
-            }
-            WAVE_SYNC();
-          }
-        }
+        als_compute<COMPACT, XB, AW, WH, SCR, ALS_OUT>(L, als_en, adaptive, notch, M, D, lam, s8, k0);
         WAVE_SYNC();
         if (als_en) {
 #pragma unroll 1
@@ -1955,7 +2045,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
       }
     }
-    if (DO3 && valid && a.audio_prev != nullptr) {   // _audioOut as this block leaves it: what an unknown mode value would re-process
+    if (TO_ALS && valid) {   // this block's ALS input (AudioSDR.cpp:326-329: _als_in[n_block + i] = buff[i]) -> its ring slot; the filter is the next launch
+      float *gx = a.als_x + (size_t)ch * (2 * ASDR_N) + ((a.als_phase + (uint32_t)blk) & 1u) * ASDR_N + kF;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { float t[4]; load4(L + W0 + kF + 32 * m, t); store4(gx + 32 * m, t); }
+    }
+    if (DO3 && !TO_ALS && valid && a.audio_prev != nullptr) {   // _audioOut as this block leaves it: what an unknown mode value would re-process
       float *ap = row_ptr(a.audio_prev, (uint32_t)ch * 512u + 4u * (uint32_t)kF);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -1983,7 +2078,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         SCHED_FENCE();
       }
-      if (DO3 && valid) {
+      if (DO3 && !TO_ALS && valid) {
         int4 *po = reinterpret_cast<int4 *>(a.out + io_out);
 #ifndef ASDR_TEMPORAL_OUT
         store_int4_nt(po, ro[0].v); store_int4_nt(po + 8, ro[1].v);
@@ -2092,6 +2187,108 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pos
 #ifndef ASDR_PLL_LANES
 #define ASDR_PLL_LANES 64   /* channels per wave of the PLL kernel (experiments: 32 = twice the waves, each half empty) */
 #endif
+// Channels with a short ALS filter (kind ASDR_KERNEL_ALS_SMALL), when there are enough of them: the chain up to the AGC as the PLAIN
+// instantiation (ROLE 6: every optimisation of the plain kernel, which the fused ALS instantiations had to give up for registers),
+// then the filter as a launch of its own on small LDS rows (asdr_als_kernel below).
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_als_pre_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 6>(a, lds);
+}
+// The ALS filter + the output stage of 8 channels per wave, from the ALS input ring (AudioSDR.cpp:324-352, 158-161).  The filter is 33
+// epochs of dependent work per block -- a 55-long chain of additions, then the tap update -- and its throughput follows the resident
+// waves (profiles/README.md: 9 -> 12 waves per CU gave -22 %): alone, it needs 268 floats of LDS per channel instead of the chain's 388
+// -- [out row / kept history (the output sample n overlays buffer index 128 + n - 65, see als_compute) | current block | even taps |
+// odd taps | e] -- and a fraction of the registers: 18 waves per CU by LDS.
+#define ALS_K_STRIDE 268
+#define ALS_K_XB (-63)     /* L[ALS_K_XB + idx] = sample idx of the reference's 256-sample buffer, idx >= 64 (word 1 ..) */
+#define ALS_K_AW 196       /* taps: 32 even | 32 odd */
+#define ALS_K_SCR 261
+#ifndef ASDR_ALS_K_WAVES_PER_EU
+#define ASDR_ALS_K_WAVES_PER_EU 3
+#endif
+extern "C" __global__ __launch_bounds__(64, ASDR_ALS_K_WAVES_PER_EU) void asdr_als_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ALS_K_STRIDE];
+  const int lane = threadIdx.x, c8 = lane >> 3, s8_ = lane & 7;
+  const int wave_g = (int)blockIdx.x;
+  int4 slot;
+  if (a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, 0);
+  else slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
+  const int ch_ = slot.x;
+  const uint32_t pflags = (uint32_t)slot.z;
+  const bool als_en = pflags & ASDR_F_ALS_EN, adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH, muted = pflags & ASDR_F_MUTED;
+#pragma unroll 1
+  for (int blk = 0; blk < a.n_blocks; ++blk) {   // (the host issues one launch per block: the ring holds two)
+    // per-iteration opaque copies of the lane coordinates: stops LICM from hoisting every per-lane LDS address out of this loop
+    int s8 = s8_; asm volatile("" : "+v"(s8));
+    int loff = c8 * ALS_K_STRIDE; asm volatile("" : "+v"(loff));
+    float *L = lds + loff;
+    const int k0 = 16 * s8, kA = 8 * s8, kF = 4 * s8;
+    int ch = ch_; asm volatile("" : "+v"(ch));
+    const ChanParams *Pp = row_ptr(a.params, (uint32_t)ch * (uint32_t)sizeof(ChanParams));
+    const int M = Pp->als_m, D = Pp->als_delay;
+    const float lam = Pp->als_lambda;
+    const uint32_t as = (a.als_phase + (uint32_t)blk) & 1u;
+    const float *gx_cur = a.als_x + (size_t)ch * (2 * ASDR_N) + as * ASDR_N + kF, *gx_prev = a.als_x + (size_t)ch * (2 * ASDR_N) + (as ^ 1u) * ASDR_N + kF;
+    float *gw = a.als_w + (size_t)ch * ASDR_N + kF;
+    {
+      float tx[8], tw[8], tn[16];   // all row loads in flight together
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { load4(gx_prev + 32 * (m + 2), tx + 4 * m); load4(gw + 32 * m, tw + 4 * m); }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) load4(gx_cur + 32 * m, tn + 4 * m);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L[ALS_K_XB + 64 + kF + 32 * m + j] = tx[4 * m + j];   // previous block's samples 64..127 (the rows start one word off a 16-byte boundary)
+        float *we = L + ALS_K_AW + ((kF + 32 * m) >> 1);   // taps de-interleaved (ALS_TAP)
+        *reinterpret_cast<float2 *>(we) = make_float2(tw[4 * m], tw[4 * m + 2]);
+        *reinterpret_cast<float2 *>(we + 32) = make_float2(tw[4 * m + 1], tw[4 * m + 3]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L[ALS_K_XB + 128 + kF + 32 * m + j] = tn[4 * m + j];
+      }
+    }
+    WAVE_SYNC();
+    als_compute<true, ALS_K_XB, ALS_K_AW, 32, ALS_K_SCR, 0>(L, als_en, adaptive, notch, M, D, lam, s8, k0);
+    WAVE_SYNC();
+    // (the rows' addresses are formed again from the channel index here: held across the filter they cost registers it needs)
+    int ch2 = ch; asm volatile("" : "+v"(ch2));
+    {   // taps back in natural order
+      float *gw = a.als_w + (size_t)ch2 * ASDR_N + kF;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float *we = L + ALS_K_AW + ((kF + 32 * m) >> 1);
+        const float2 e2 = *reinterpret_cast<const float2 *>(we), o2 = *reinterpret_cast<const float2 *>(we + 32);
+        const float t[4] = {e2.x, o2.x, e2.y, o2.y};
+        store4(gw + 32 * m, t);
+      }
+    }
+    if (a.audio_prev != nullptr) {   // _audioOut as this block leaves it (asdr_device.h audio_prev)
+      float *ap = row_ptr(a.audio_prev, (uint32_t)ch2 * 512u + 4u * (uint32_t)kF);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { float t[4]; load4(L + kF + 32 * m, t); store4_nt(ap + 32 * m, t); }
+    }
+    {   // output, AudioSDR.cpp:158-161: float product, x 32767.0 in binary64, truncate, wrap to int16
+      const float og = row_ptr(a.params, (uint32_t)ch2 * (uint32_t)sizeof(ChanParams))->output_gain;
+      union { int4 v; int16_t s[8]; } ro[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float au[8];
+        load8(L + kA + 64 * h, au);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int v = (int)((double)(og * au[j]) * 32767.0);
+          ro[h].s[j] = muted ? (int16_t)0 : (int16_t)v;
+        }
+      }
+      int4 *po = reinterpret_cast<int4 *>(a.out + ((size_t)ch2 * a.out_stride + blk) * ASDR_N + kA);
+      store_int4_nt(po, ro[0].v); store_int4_nt(po + 8, ro[1].v);
+    }
+    WAVE_SYNC();
+  }
+}
 // One LANE per channel: lane l of workgroup w runs the PLL of schedule slot 64 w + l on the rows the pre kernel left in its tile.
 extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs a) {
   __shared__ float sine[ASDR_SINE_TABLE_LEN];
@@ -2304,7 +2501,7 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
     if (t < 6) (&S->nb_gain[0][0])[t] = 0.0f;
   }
   if (all || (r & ASDR_R_ALS)) {
-    a.als_x[(size_t)ch * 128 + t] = 0.0f;
+    a.als_x[(size_t)ch * 256 + t] = 0.0f; a.als_x[(size_t)ch * 256 + 128 + t] = 0.0f;
     a.als_w[(size_t)ch * 128 + t] = 0.0f;
   }
 }
@@ -2314,6 +2511,10 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
   if (variant == ASDR_KERNEL_ALS || (variant == ASDR_KERNEL_SAM_ALS && a->xch_sam == nullptr)) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_ALS_SMALL && uniform == 2) {   // chain up to the AGC | the filter + output, two launches (one block per call: the host loops)
+    hipLaunchKernelGGL(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  }
   else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if ((variant == ASDR_KERNEL_SAM || variant == ASDR_KERNEL_SAM_ALS) && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
     if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);

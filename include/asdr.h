@@ -234,6 +234,12 @@ int asdr_set_stream_pipeline(asdr_batch_t *b, int on);
  * launches pre | PLL | post from split_min_channels SAM channels on (<= 0: the default, 512).  Defaults at asdr_create time from
  * the environment (ASDR_SAM_FUSED, ASDR_SAM_SPLIT_MIN): comparison switches of the measurement tools. */
 int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels);
+/* Channels with a short ALS filter (taps <= 64, delay + taps <= 65; not SAM) CAN run as two launches -- the chain up to the AGC as the
+ * plain kernel, then the filter and the output stage on small LDS rows (asdr_als_kernel) -- when the batch has at least
+ * split_min_channels of them.  Default (<= 0, or environment ASDR_ALS_SPLIT_MIN unset at asdr_create time): never -- measured on
+ * MI355X the two-launch form is 2 % faster for 131,072 mixed channels, 6 % slower for 1,048,576 and 3 % slower for an all-ALS batch
+ * (profiles/README.md).  Bit-identical results.  asdr_schedule_layout()'s out[7] carries the choice in bit 1. */
+int asdr_set_als_launch_form(asdr_batch_t *b, int split_min_channels);
 /* Test hook: the number of polls after which a pipeline wait gives up (0 = the default, 2^18).  A tiny value injects timeouts, so
  * that the recovery path can be tested on an idle GPU. */
 int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls);
@@ -246,7 +252,7 @@ int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups);
  * kernel kind -- 0 plain, 1 SAM, 2 ALS on the long rows, 3 ALS on the compact rows (taps <= 64, delay + taps <= 65, not SAM),
  * 4 SAM + such an ALS filter -- (kind 1 also holds the SAM remainders when a batch with fewer than 512 SAM channels runs them in
  * the fused SAM kernel), out[5] = the sub-range of all other remainders (< 8 channels per settings group), out[6] = the kind of the
- * general kernel that runs it (0 or 2; -1 if empty), out[7] = 1 if SAM channels run as pre | PLL | post launches.  For tests and
+ * general kernel that runs it (0 or 2; -1 if empty), out[7] bit 0 = SAM channels run as pre | PLL | post launches, bit 1 = short ALS filters run as chain | filter launches.  For tests and
  * capacity planning; DESIGN.md 3.1. */
 int asdr_schedule_layout(asdr_batch_t *b, int out[8]);
 /* Library / build identification string (contains "gfx950"). */

@@ -525,3 +525,44 @@ def test_als_kernel_kinds(gpu, ao):
         checked.add(kind_of.get(c))
     assert len(checked) == len(variety) + 1
     b.close()
+
+
+def test_als_as_a_launch_of_its_own(gpu, ao):
+    """Channels with a short ALS filter (not SAM) can run as two launches: the chain up to the AGC as the plain kernel, then the filter
+    + output stage on small LDS rows whose output overlays the consumed history (asdr_als_kernel; asdr_set_als_launch_form).  Forced
+    here for a small batch: USB / LSB / CW / AM / WSPR groups of 8 with filter lengths and delays up to the compact layout's limits
+    (M + delay = 65: the deepest reach into the overlaid history), notch / peak, adaptive / static taps, a muted group, an unknown mode
+    (the kept audio row is the post-ALS one); single-block and 3-block calls, a filter parameter change and a disable / enable
+    (taps + history zeroed, AudioSDR.cpp:384-391) mid-stream.  Every block of every channel, and the ALS-stage tap is NOT available
+    in this form (stage taps keep the fused kernel), so int16 audio + status."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 96, (1, 1, 3, 1, 2, 1, 3)
+    total = sum(plan)
+    I, Q = make_iq(n_ch, total, fc=6890.0 + (np.arange(n_ch) % 9 - 4) * 35.0, A=0.3, m=0.4, f2=7600.0, a2=0.12, noise=0.01, impulse_every=500)
+    grp = lambda g: (lambda c: c // 8 == g)
+    variety = [(1, None, False, False), (0, (64, 0.5, 1), False, False), (3, (1, 0.5, 64), True, False), (4, (55, 0.5, 3), False, False),
+               (6, (60, 0.25, 5), False, True), (1, (8, 0.5, 57), True, True), (2, (0, 0.5, 3), False, False), (1, (33, 0.7, 32), False, False),
+               (4, (64, 0.1, 0), True, False), (1, None, False, False), (0, (17, 0.5, 40), False, False), (1, (55, 0.5, 3), False, False)]
+    setters = [S("setNoiseBlankerThresholdDb", 10.0), S("enableALSfilter")]
+    for g, (mode, par, peak, static) in enumerate(variety):
+        setters.append(S("setDemodMode", mode, sel=grp(g)))
+        if par is not None: setters.append(S("setALSfilterParams", *par, sel=grp(g)))
+        if peak: setters.append(S("setALSfilterPeak", sel=grp(g)))
+        if static: setters.append(S("setALSfilterStatic", sel=grp(g)))
+    setters += [S("enableAudioFilter", sel=grp(3)), S("setMute", 1, sel=grp(9))]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    batch.set_als_launch_form(8)
+    script = {2: [S("setALSfilterParams", 40, 0.5, 20.0, sel=grp(0))], 3: [S("setDemodMode", 7, sel=grp(11))],
+              4: [S("disableALSfilter", sel=grp(7))], 5: [S("enableALSfilter", sel=grp(7)), S("setDemodMode", 1, sel=grp(11))]}
+    pos = 0
+    for k, T in enumerate(plan):
+        if k in script:
+            apply_setters(batch, orcs, script[k])
+        got = batch.update(I[:, pos:pos + T], Q[:, pos:pos + T])
+        assert batch.schedule_layout()["als_two_launches"]
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call %d (blocks %d..%d) ch %d (group %d)" % (k, pos, pos + T - 1, c, c // 8)
+        pos += T
+    compare_status(gpu, batch, orcs)
+    batch.close()
