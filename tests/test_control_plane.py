@@ -230,7 +230,7 @@ def test_schedule_layout_kinds_and_remainders(A):
     b.control_plane_flush()
     lay = b.schedule_layout()
     assert lay == {"plain": n, "sam": 0, "als_long": 0, "als_compact": 0, "sam_als": 0, "remainders": 0, "remainder_kind": -1,
-                   "sam_three_launches": False}
+                   "sam_three_launches": False, "als_two_launches": False}
     # channels 0..99: ALS with the default 55 taps / delay 3 -> compact; 96 in whole waves, 4 remainders (+ 4 plain remainders: n - 100 = 8k + 4)
     for c in range(100):
         b.enableALSfilter(ch=c)
