@@ -750,36 +750,46 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
     }
 #ifndef ASDR_ALS_TAPS_IN_LDS
     if (als_m_default) {
-      // The reference's default length (55 taps, adaptive) in the whole wave: THE TAPS LIVE IN REGISTERS for the block.  Each half
-      // of a channel's eight lanes holds its 28 taps (even / odd) in every one of its four lanes, so a tap set costs no LDS reads,
-      // and the tap update w[q] += lambda * (e * x[iu - D - q]) (AudioSDR.cpp:341-343) needs none either: x[iu - D - q] for a lane's
-      // own taps is exactly the operand set the lane of the updating sample iu (lane 3 of the quad; lane 0 for the very first
-      // sample) has just used for its sum -- it arrives as a DPP quad broadcast folded into the multiply.  Same products, same
-      // sums, same order.  Per tap set: 14 two-sample LDS reads instead of 7 b128 + 28 + 21 accesses (the filter was bound by LDS
-      // bandwidth: asdr_als_kernel 0.237 ms for 131,072 channels, the LDS pipe ~65 % busy).
-      const int h = s8 >> 2;
-      float wr[7][4];
+      // The reference's default length (55 taps, adaptive) in the whole wave: THE TAPS LIVE IN REGISTERS for the block, each held
+      // once.  A channel's eight lanes are two quads: the low one works on the even taps, the high one on the odd taps, and lane
+      // t of a quad owns tap t of every group of four (tap q = 8 g + 2 t + h: seven registers).  The products of a sum take their
+      // tap from the owner through a DPP quad broadcast folded into the multiply (v_mul_f32_dpp quad_perm:[t,t,t,t]) -- no LDS
+      // read, no extra instruction -- and the tap update w[q] += lambda * (e * x[iu - D - q]) (AudioSDR.cpp:341-343) is done by the
+      // owner alone: 7 x 3 operations per lane and tap set instead of 28 x 3.  Same products, same sums, same order.  Per tap
+      // set: 18 two-sample LDS reads and ~135 VALU instructions (round 2: 7 b128 + 56 accesses and ~105 + 28 wait states; the
+      // filter was bound by LDS bandwidth -- asdr_als_kernel 0.237 ms for 131,072 channels with the LDS pipe ~65 % busy).
+      const int h = s8 >> 2, tq = s8 & 3;
+      float wr[7];
 #pragma unroll
-      for (int g = 0; g < 7; ++g) { const float4 t4 = *reinterpret_cast<const float4 *>(L + AW + WH * h + 4 * g); wr[g][0] = t4.x; wr[g][1] = t4.y; wr[g][2] = t4.z; wr[g][3] = t4.w; }
+      for (int g = 0; g < 7; ++g) wr[g] = L[AW + WH * h + 4 * g + tq];
+      const bool own_valid6 = !(tq == 3 && h != 0);   // tap 55 does not exist
       auto epoch = [&](auto first_tag, int ep) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const int base = FIRST ? 0 : 4 * ep + 1;
         const int cntn = FIRST ? 1 : ((ep == 31) ? 3 : 4);
-        const int n = base + (s8 & 3), i = 128 + n;
+        const int n = base + tq, i = 128 + n;
         const bool mine = (s8 < cntn);
         const float *xh = L + XB + (i - D - h);
         float xs[7][4];
 #pragma unroll
         for (int g = 0; g < 7; ++g) { xs[g][0] = xh[-8 * g]; xs[g][1] = xh[-8 * g - 2]; xs[g][2] = xh[-8 * g - 4]; xs[g][3] = xh[-8 * g - 6]; }
+        // the operands of this lane's own taps for the update below: x[iu - D - q], q = 8 g + 2 tq + h (requested with the sums' operands)
+        const int nu = FIRST ? 0 : 4 * ep + 4;   // the updating sample of this tap set
+        const float *xu = L + XB + (128 + nu - D - h - 2 * tq);
+        float xo[7];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) xo[g] = xu[-8 * g];
         float y = 0.0f;
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
+          float p[4];
+          p[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wr[g]), 0x00, 0xF, 0xF, true)) * xs[g][0];   // quad_perm:[0,0,0,0]
+          p[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wr[g]), 0x55, 0xF, 0xF, true)) * xs[g][1];   // [1,1,1,1]
+          p[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wr[g]), 0xAA, 0xF, 0xF, true)) * xs[g][2];   // [2,2,2,2]
+          p[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(wr[g]), 0xFF, 0xF, 0xF, true)) * xs[g][3];   // [3,3,3,3]
+          if (g == 6) p[3] = (h == 0) ? p[3] : 0.0f;   // tap 55 does not exist (the running sum starts at +0.0: adding +0.0 leaves it)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            float p = wr[g][t] * xs[g][t];
-            if (g == 6 && t == 3) p = (h == 0) ? p : 0.0f;   // tap 55 does not exist (the running sum starts at +0.0: adding +0.0 leaves it)
-            y += p; y += dpp_row_shl4(p);
-          }
+          for (int t = 0; t < 4; ++t) { y += p[t]; y += dpp_row_shl4(p[t]); }
           __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from forming all 28 products -- and 28 moved copies -- up front: registers)
         }
         if (mine) {
@@ -788,17 +798,12 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
           if ((n & 3) == 0) L[SCR] = e;
         }
         WAVE_SYNC();
-        const int nu = FIRST ? 0 : 4 * ep + 4;   // the updating sample of this epoch: lane 0's in the first one, lane 3's afterwards
         if (nu < ASDR_N) {
           const float e = L[SCR];
 #pragma unroll
           for (int g = 0; g < 7; ++g) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float xu = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xs[g][t]), FIRST ? 0x00 : 0xFF, 0xF, 0xF, true));   // quad_perm:[k,k,k,k]
-              const float gq = e * xu; const float dq = lam * gq; const float wn = wr[g][t] + dq;
-              wr[g][t] = (g == 6 && t == 3 && h != 0) ? wr[g][t] : wn;
-            }
+            const float gq = e * xo[g]; const float dq = lam * gq; const float wn = wr[g] + dq;
+            wr[g] = (g == 6 && !own_valid6) ? wr[g] : wn;
           }
         }
         WAVE_SYNC();
@@ -806,11 +811,9 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
       epoch(std::true_type{}, -1);
 #pragma unroll 1
       for (int ep = 0; ep < 32; ++ep) epoch(std::false_type{}, ep);
-      // the taps back to their LDS rows (one lane of each half: they all hold the same values)
-      if ((s8 & 3) == 0) {
+      // the taps back to their LDS rows
 #pragma unroll
-        for (int g = 0; g < 7; ++g) *reinterpret_cast<float4 *>(L + AW + WH * h + 4 * g) = make_float4(wr[g][0], wr[g][1], wr[g][2], wr[g][3]);
-      }
+      for (int g = 0; g < 7; ++g) L[AW + WH * h + 4 * g + tq] = wr[g];
       WAVE_SYNC();
     } else
 #endif
