@@ -893,6 +893,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4 || ROLE == 6), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5 || ROLE == 6),
                  DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6);
   constexpr bool TO_ALS = (ROLE == 6);
+#ifndef ASDR_ALS_FULL_OPT
+#define ASDR_ALS_FULL_OPT 0
+#endif
+  // The ALS instantiations used to give up two of the plain kernel's orderings for registers (IF rows consumed before the ring
+  // prefetches; the merged average + phase loop): experiments re-enable them for the compact rows with -DASDR_ALS_FULL_OPT=1.
+  constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && (STRIDE == ASDR_STRIDE), ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && (STRIDE == ASDR_STRIDE);
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
   if (ROLE == 0 && a.run_if != nullptr && *a.run_if == 0u) return;   // the pipeline's fallback launch: nothing to do unless the pipeline gave up
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
@@ -1168,7 +1174,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
         // wrap `t < 0 ? t + twoPI : t` is a sign-mask select (v_ashrrev + v_bfi, no compare -> VCC -> select hazard): the phase
         // chain is add, shift, select.  (t = -0.0 cannot occur: the phase is never -0.0 and x + y = -0.0 needs both -0.0.)
-        if (!HAS_ALS && __all(minc < 0.0f)) {   // (the ALS instantiations take the compact loop below: this one costs them spills)
+        if (!(HAS_ALS && !ALS_FULL_OPT2) && __all(minc < 0.0f)) {   // (the ALS instantiations take the compact loop below: this one costs them spills)
 #pragma unroll 1
           for (int c = 0; c < 16; c += 2) {
             float av[8], bn[8], pv[8];
@@ -1410,7 +1416,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
       for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
     };
-    if (DO1 && ABL_ON(ABL_IF) && !HAS_ALS) {   // (the ALS instantiations keep the old order: they spill with this one)
+    if (DO1 && ABL_ON(ABL_IF) && !(HAS_ALS && !ALS_FULL_OPT)) {   // (the ALS instantiations keep the old order: they spill with this one)
       if (!if_pre) load_if_rows();
       asm volatile("" : "+v"(if_s4.x), "+v"(if_s4.y), "+v"(if_s4.z), "+v"(if_s4.w), "+v"(if_cf[0]), "+v"(if_cf[1]), "+v"(if_cf[2]), "+v"(if_cf[3]), "+v"(if_cf[4]));
     }
@@ -1454,7 +1460,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (DO1 && ABL_ON(ABL_IF)) {
       const int iq = s8 >> 2, st = s8 & 3;
       float sv[4];
-      if (HAS_ALS && !if_pre) load_if_rows();
+      if (HAS_ALS && !ALS_FULL_OPT && !if_pre) load_if_rows();
       sv[0] = if_s4.x; sv[1] = if_s4.y; sv[2] = if_s4.z; sv[3] = if_s4.w;
       biquad_pipe(L + (iq ? W1 : W0), true, st, if_cf, sv);
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
