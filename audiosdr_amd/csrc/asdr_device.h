@@ -104,8 +104,12 @@ typedef struct {
 
 typedef struct {
   int32_t ch;
-  uint32_t mode, flags, pad_;
+  uint32_t mode, flags;
+  uint32_t lo;   /* local-oscillator cache: low byte = 1 + the cache entry of the slot's settings group (0 = none), bit 8 = the slot's wave
+                    is the group's first one and leaves the NEXT block's pairs in that entry (ASDR_LO_WRITER) */
 } SlotInfo;
+#define ASDR_LO_ENTRIES 8        /* settings groups with an entry of their own (round 2: one entry, wave 0's group) */
+#define ASDR_LO_WRITER 0x100u
 
 /* Local-oscillator cache: the mixer's phase sequence and its sin/cos pairs depend only on (carried phase, increment).  When all
  * channels of wave 0 share one pair (receivers configured together), that wave also computes the NEXT block's 128 pairs and
@@ -142,9 +146,10 @@ typedef struct {
   uint32_t als_phase;     /* blocks processed by the batch so far, mod 2: the slot of the ALS input ring (als_x) THIS block's input goes to;
                              the other slot holds the previous block's (enableALSfilter zeroes both, AudioSDR.cpp:384-391, so a channel
                              whose filter was off meanwhile never sees a stale position) */
-  LoEntry *lo_cache;      /* [2] */
-  uint32_t lo_parity;     /* entry this launch reads; wave 0 of the launch with lo_write set fills the other one */
-  uint32_t lo_write;
+  LoEntry *lo_cache;      /* [2][ASDR_LO_ENTRIES] */
+  uint32_t lo_parity;     /* half this launch reads; a settings group's first wave (SlotInfo.lo) fills its entry of the other half */
+  uint32_t lo_write;      /* the launch may fill entries (off for the pipeline, whose oscillator role serves its own ring) */
+  uint32_t direct_lo;     /* SlotInfo.lo of a direct_ch0 launch's single settings group (writer = its wave 0) */
   int32_t direct_ch0;     /* >= 0: the launched sub-range is ONE key group of consecutive channels direct_ch0, direct_ch0 + 1, ...:
                              slot i is channel direct_ch0 + i with direct_mode / direct_flags, and no wave has to load its
                              schedule entry first (one HBM round trip less at the start of every wave); -1: read a.sched */

@@ -421,16 +421,23 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     b->sched.assign(pos, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});   // padding = the dummy channel
     int at_u[ASDR_KERNEL_KINDS], at_m[ASDR_KERNEL_KINDS], at_left = b->left_first;
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) { at_u[k] = b->kind_first[k]; at_m[k] = b->kind_first[k] + uni[k]; }
+    // Local-oscillator cache: the settings groups with whole waves get an entry each, largest first come first served (the mixer's
+    // pairs are a function of (phase, increment); receivers of one group that were configured together share them for ever)
+    uint32_t lo_next = 0;
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
       const int k = (int)(order[i].first >> 60), g = j - i;
       const bool fused = (k == ASDR_KERNEL_SAM && sam_general_only);
       const int whole = fused ? 0 : g / 8 * 8;
+      const uint32_t gm = b->hp[order[i].second].mode;
+      const bool mixes_early = (gm == ASDR_USBmode || gm == ASDR_LSBmode || gm == ASDR_CW_USBmode || gm == ASDR_CW_LSBmode || gm == ASDR_WSPRmode || gm == ASDR_AMmode);
+      const uint32_t lo_id = (whole > 0 && mixes_early && lo_next < ASDR_LO_ENTRIES) ? ++lo_next : 0u;   // 1 + entry, 0 = none
       for (int t = 0; t < g; t++) {
         const int c = order[i + t].second;
         int &at = (t < whole) ? at_u[k] : (fused ? at_m[k] : at_left);
-        b->sched[at++] = SlotInfo{c, b->hp[c].mode, b->hp[c].flags, 0u};
+        const uint32_t lo = (t < whole) ? (lo_id | ((t < 8 && lo_id) ? ASDR_LO_WRITER : 0u)) : 0u;
+        b->sched[at++] = SlotInfo{c, b->hp[c].mode, b->hp[c].flags, lo};
       }
       i = j;
     }
@@ -599,8 +606,8 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     if (ok && hipMemset(b->d_audio_prev, 0, rows * 128 * sizeof(float)) != hipSuccess) ok = false;
     alloc((void **)&b->d_sched, (rows + 32) * sizeof(SlotInfo));   // three sub-ranges, each padded to a whole wave
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
-    alloc((void **)&b->d_lo, 2 * sizeof(LoEntry));
-    if (ok && hipMemset(b->d_lo, 0xFF, 2 * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
+    alloc((void **)&b->d_lo, 2 * ASDR_LO_ENTRIES * sizeof(LoEntry));
+    if (ok && hipMemset(b->d_lo, 0xFF, 2 * ASDR_LO_ENTRIES * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
     if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
@@ -778,7 +785,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));   // stream-ordered behind the previous launch
     a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
     a.direct_ch0 = -1;
-    if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; }
+    if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo; }
     a.lo_write = 0u;
     a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_err = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1;
     a.stream_waves = w; a.lo_ring = b->d_lo_ring; a.stream_spin_limit = b->stream_spin_limit;
@@ -827,9 +834,9 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
       a.direct_ch0 = -1;
       if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
         const SlotInfo &s0 = b->sched[subs[i].first];
-        a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags;
+        a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo;
       }
-      a.lo_write = (i == 0) ? 1u : 0u;   // wave 0 of the first launch fills the other local-oscillator cache entry
+      a.lo_write = 1u;   // the first wave of every settings group fills the group's entry of the other half of the local-oscillator cache
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM)   // this sub-range's tiles (1 KB per slot, 8 slots per tile)
         a.xch_sam = b->d_xch_sam + (size_t)(subs[i].first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM_ALS)   // ... behind those of the SAM kind

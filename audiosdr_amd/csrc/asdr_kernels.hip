@@ -910,7 +910,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   int4 slot = make_int4(a.n_channels, 0, 0, 0);
-  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, 0);
+  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, (int)((a.direct_lo & 0xFFu) | (wave_g == 0 ? ASDR_LO_WRITER : 0u)));
   else if (WAVES == 1 || wave_g * 8 < a.n_sched) slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
   else { const ChanParams *pd = a.params + a.n_channels; slot.y = (int)pd->mode; slot.z = (int)pd->flags; }   // padding wave of a multi-wave workgroup: dummy channel
   const int ch_ = slot.x;
@@ -999,7 +999,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const float nb_thr = P.nb_threshold;   // used after the blanker's sequential pass: requested here, not there
     // Oscillator pairs of this block: the launch-to-launch cache entry, or -- pipeline role 2 -- the entry the pipeline's
     // oscillator role has left for block blk (EVERY block of the call can hit; read with `sc1` loads, see stream_wait)
-    const LoEntry *lo_rd = (ROLE == 2) ? a.lo_ring + (blk % ASDR_LO_RING) : a.lo_cache + (a.lo_parity & 1u);
+    // this wave's entry of the local-oscillator cache: one per settings group (the host numbers the groups; waves of mixed slots
+    // and groups beyond ASDR_LO_ENTRIES have none and compute their own pairs)
+    const uint32_t lo_slot = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.w) : 0u;
+    const uint32_t lo_e = (lo_slot & 0xFFu) ? (lo_slot & 0xFFu) - 1u : 0u;
+    const bool lo_has = (ROLE == 2) || ((lo_slot & 0xFFu) != 0u);
+    const LoEntry *lo_rd = (ROLE == 2) ? a.lo_ring + (blk % ASDR_LO_RING) : a.lo_cache + (a.lo_parity & 1u) * ASDR_LO_ENTRIES + lo_e;
     uint32_t lo_kp, lo_ki;
     float lo_end;
     if (ROLE == 2) {
@@ -1064,7 +1069,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (mix_early) minc = (is_ssb ? -fsh_raw : -K.if_center) * K.phase_inc_unit;
     bool ph_ready = false;   // this channel's phase sequence is in its PH row
     bool lo_hit = false;
-    if (blk == 0 || ROLE == 2) lo_hit = __all(mix_early && __float_as_uint(mphase) == lo_kp && __float_as_uint(minc) == lo_ki);
+    if ((blk == 0 || ROLE == 2) && lo_has) lo_hit = __all(mix_early && __float_as_uint(mphase) == lo_kp && __float_as_uint(minc) == lo_ki);
     if (lo_hit && lead) { if (is_ssb) S->phase_ssb = lo_end; else S->phase_am = lo_end; }
 
     // ---- input scale, AudioSDR.cpp:67-70: ((float)s / 32767.0) * gain in binary64, stored float --------
@@ -2099,9 +2104,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (!STREAM) { if (lead) S->status = status; }
     else { store_status_bits(ASDR_S_AGC_ACTIVE); sig_pending = (uint32_t)blk + 1u; }
     WAVE_SYNC();
-    // Wave 0 of the designated launch leaves the NEXT block's local-oscillator pairs in the other cache entry (LoEntry).
-    if (a.lo_write && wave_g == 0 && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
-      LoEntry *lo_wr = a.lo_cache + ((a.lo_parity & 1u) ^ 1u);
+    // The first wave of every settings group leaves the NEXT block's local-oscillator pairs in the group's entry of the other half (LoEntry).
+    if (a.lo_write && ROLE != 2 && (lo_slot & ASDR_LO_WRITER) && (lo_slot & 0xFFu) != 0u && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
+      LoEntry *lo_wr = a.lo_cache + ((a.lo_parity & 1u) ^ 1u) * ASDR_LO_ENTRIES + lo_e;
       const float start = lo_hit ? lo_end : __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mphase_end)));
       const float inc = __uint_as_float(inc_first);
       if (lane == 0) {
