@@ -921,6 +921,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
   const uint32_t mode = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.y) : (uint32_t)slot.y;
   const uint32_t pflags = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.z) : (uint32_t)slot.z;
+  const uint32_t lo_slot = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.w) : 0u;   // wave-uniform: an SGPR from here on
   const bool is_ssb = DO2 && ((mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                               (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode));
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
@@ -1001,7 +1002,6 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // oscillator role has left for block blk (EVERY block of the call can hit; read with `sc1` loads, see stream_wait)
     // this wave's entry of the local-oscillator cache: one per settings group (the host numbers the groups; waves of mixed slots
     // and groups beyond ASDR_LO_ENTRIES have none and compute their own pairs)
-    const uint32_t lo_slot = UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane(slot.w) : 0u;
     const uint32_t lo_e = (lo_slot & 0xFFu) ? (lo_slot & 0xFFu) - 1u : 0u;
     const bool lo_has = (ROLE == 2) || ((lo_slot & 0xFFu) != 0u);
     const LoEntry *lo_rd = (ROLE == 2) ? a.lo_ring + (blk % ASDR_LO_RING) : a.lo_cache + (a.lo_parity & 1u) * ASDR_LO_ENTRIES + lo_e;
@@ -2024,8 +2024,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const float lam = P.als_lambda;   // (requested once, not in every tap-update epoch)
         const bool adaptive = pflags & ASDR_F_ALS_ADAPTIVE, notch = pflags & ASDR_F_ALS_NOTCH;
         const uint32_t as = (a.als_phase + (uint32_t)blk) & 1u;   // ring slot of this block's input; the other one holds the previous block's
-        float *gx = a.als_x + (size_t)ch * (2 * ASDR_N) + as * ASDR_N + kF, *gw = a.als_w + (size_t)ch * ASDR_N + kF;   // float rows: pieces kF + 32m
-        const float *gx_prev = a.als_x + (size_t)ch * (2 * ASDR_N) + (as ^ 1u) * ASDR_N + kF;
+        const uint32_t xoff = (uint32_t)ch * 1024u + 4u * (uint32_t)kF;   // float rows: pieces kF + 32m
+        float *gx = row_ptr(a.als_x, xoff + as * 512u), *gw = row_ptr(a.als_w, (uint32_t)ch * 512u + 4u * (uint32_t)kF);
+        const float *gx_prev = row_ptr(a.als_x, xoff + (as ^ 1u) * 512u);
         if (als_en) {
           float tx[16], tw[16], tn[16];   // all row loads in flight together
 #pragma unroll
@@ -2060,7 +2061,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
     if (TO_ALS && valid) {   // this block's ALS input (AudioSDR.cpp:326-329: _als_in[n_block + i] = buff[i]) -> its ring slot; the filter is the next launch
-      float *gx = a.als_x + (size_t)ch * (2 * ASDR_N) + ((a.als_phase + (uint32_t)blk) & 1u) * ASDR_N + kF;
+      float *gx = row_ptr(a.als_x, (uint32_t)ch * 1024u + ((a.als_phase + (uint32_t)blk) & 1u) * 512u + 4u * (uint32_t)kF);
 #pragma unroll
       for (int m = 0; m < 4; ++m) { float t[4]; load4(L + W0 + kF + 32 * m, t); store4(gx + 32 * m, t); }
     }
@@ -2106,7 +2107,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     WAVE_SYNC();
     // The first wave of every settings group leaves the NEXT block's local-oscillator pairs in the group's entry of the other half (LoEntry).
     if (a.lo_write && ROLE != 2 && (lo_slot & ASDR_LO_WRITER) && (lo_slot & 0xFFu) != 0u && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
-      LoEntry *lo_wr = a.lo_cache + ((a.lo_parity & 1u) ^ 1u) * ASDR_LO_ENTRIES + lo_e;
+      uint32_t lo_wi = ((a.lo_parity & 1u) ^ 1u) * ASDR_LO_ENTRIES + lo_e;
+      asm volatile("" : "+v"(lo_wi));   // the entry's address is formed HERE (hoisted, it sits in a VGPR pair for the whole kernel)
+      LoEntry *lo_wr = a.lo_cache + lo_wi;
       const float start = lo_hit ? lo_end : __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mphase_end)));
       const float inc = __uint_as_float(inc_first);
       if (lane == 0) {
