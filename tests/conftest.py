@@ -33,7 +33,14 @@ def ao():
 
 @pytest.fixture(scope="session")
 def A():
-    """The product binding; the HIP library is built on demand (hipcc cross-compiles without a GPU)."""
+    """The product binding; the HIP library is built on demand (hipcc cross-compiles without a GPU).
+    PyTorch (the device buffers of the full-size tests) is imported BEFORE the library is loaded: this image's torch wheel bundles its
+    own libamdhip64, and torch finds no device when /opt/rocm's copy -- the one libasdr_hip.so names -- was mapped first (imported
+    first, torch's copy serves both)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     from audiosdr_amd import build as b
     b.build()
     import audiosdr_amd
@@ -44,7 +51,8 @@ def A():
 @pytest.fixture(scope="session")
 def gpu(A):
     """Skips (loudly named) ONLY when there is no HIP device; any other asdr_create failure (allocation, table upload,
-    bad ordinal) fails the suite instead of skipping it green.  GPU tests call through the C ABI only."""
+    bad ordinal) fails the suite instead of skipping it green.  GPU tests call through the C ABI only.
+    """
     try:
         b = A.AudioSDRBatch(1, device=0)
     except A.AsdrError as e:

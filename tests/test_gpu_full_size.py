@@ -176,3 +176,88 @@ def test_full_size_c2_divergent_phases(gpu, ao, adverse):
     if case["impulses"]:
         assert int(st["nb_detected"].sum()) > n_ch // 2
     batch.close()
+
+
+def _scatter_group(c, n_groups):
+    """Settings group of channel c: a multiplicative hash, so that neither the group pattern nor its combination with the
+    tiled inputs repeats with any period the wave schedule could line up with."""
+    return (((c * 2654435761) & 0xFFFFFFFF) >> 16) % n_groups
+
+
+_SCATTER_CONFIGS = [
+    # (mode, audio filter or None, blanker dB or None, ALS (M, lambda, D, peak, static) or None, AGC hang ms or None)
+    (1, 0, 10.0, None, None), (0, 3, None, None, 20.0), (2, None, 10.0, (55, 0.5, 3.0, False, False), None),
+    (3, 5, 6.0, None, 0.0), (4, 0, 10.0, None, None), (4, None, None, (55, 0.5, 3.0, True, False), None),
+    (5, 0, 10.0, None, None), (5, None, 10.0, (32, 0.5, 1.0, False, False), None), (6, 2, None, None, None),
+    (1, None, 3.0, (100, 0.05, 7.0, False, False), None), (1, 7, 10.0, (55, 0.5, 3.0, False, True), 1.0), (0, None, None, None, None),
+    (6, 2, 20.0, (64, 0.5, 1.0, False, False), None),
+]
+
+
+def _apply_scatter_config(s, cfg, ch=None):
+    mode, af, nb_db, als, hang = cfg
+    kw = {} if ch is None else {"ch": ch}
+    s.setDemodMode(mode, **kw)
+    if af is not None:
+        s.enableAudioFilter(**kw); s.setAudioFilter(af, **kw)
+    if nb_db is not None:
+        s.enableNoiseBlanker(**kw); s.setNoiseBlankerThresholdDb(nb_db, **kw)
+    else:
+        s.disableNoiseBlanker(**kw)
+    if als is not None:
+        M, lam, D, peak, static = als
+        s.enableALSfilter(**kw); s.setALSfilterParams(M, lam, D, **kw)
+        if peak: s.setALSfilterPeak(**kw)
+        if static: s.setALSfilterStatic(**kw)
+    if hang is not None:
+        s.setAGChangTime(hang, **kw)
+
+
+def test_full_size_scattered_settings(gpu, ao):
+    """131,072 channels whose settings group is a HASH of the channel index (13 groups covering every kernel kind: plain, SAM as
+    three launches, ALS on compact and long rows, SAM + ALS, static and peak ALS) and whose inputs are 1,021 distinct rows tiled
+    over the batch (1,021 is prime: the (group, input) combinations do not repeat with the tiling).  Unlike the tiled configs
+    above, which channels share a wave -- and which end up in the remainders' mixed waves next to a different-key neighbour --
+    differs all over the batch.  Checks per block: (1) every channel equals the first channel with the same (group, input row),
+    which sits in a different wave with different neighbours; (2) 39 sampled channels (3 per group, spread over the batch) bit-for-bit
+    against the oracle.  AudioSDR.cpp:39-168 (channels never interact)."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, uniq, n_blk = 131072, 1021, 6
+    n_groups = len(_SCATTER_CONFIGS)
+    fc = 6890.0 + (np.arange(uniq) % 11 - 5) * 37.0
+    I, Q = make_iq(uniq, n_blk, fc=fc, A=0.3, m=0.4, fm=350.0, f2=fc + 640.0, a2=0.1, impulse_every=700)
+    dI, dQ = _device_tiles(torch, I, Q, n_ch)
+    grp = np.array([_scatter_group(c, n_groups) for c in range(n_ch)], dtype=np.int64)
+    batch = gpu.AudioSDRBatch(n_ch)
+    for c in range(n_ch):
+        _apply_scatter_config(batch, _SCATTER_CONFIGS[grp[c]], ch=c)
+    # representative (first) channel of every (group, input row) combination
+    combo = grp * uniq + (np.arange(n_ch) % uniq)
+    _, first, inverse = np.unique(combo, return_index=True, return_inverse=True)
+    rep = torch.from_numpy(first[inverse]).cuda()
+    rng = np.random.default_rng(5)
+    sample = []
+    for g in range(n_groups):
+        members = np.nonzero(grp == g)[0]
+        sample += [int(members[0]), int(members[len(members) // 2 + int(rng.integers(0, 50))]), int(members[-1])]
+    dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device="cuda")
+    got = {c: [] for c in sample}
+    for b in range(n_blk):
+        batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, 0)
+        batch.synchronize()
+        if b == 0:   # (the layout is the one the call's flush built)
+            layout = batch.schedule_layout()
+            assert layout["remainders"] > 0, "the schedule has no mixed waves: the test would not cover what it is for"
+            assert min(layout[k] for k in ("plain", "sam", "als_long", "als_compact", "sam_als")) > 0, layout
+        same = (dOut == dOut[rep]).all(dim=1)
+        assert bool(same.all()), "block %d: channel %d differs from channel %d (same settings, same input)" % (
+            b, int((~same).nonzero()[0]), int(rep[int((~same).nonzero()[0])]))
+        for c in sample:
+            got[c].append(dOut[c].cpu().numpy().copy())
+    for c in sample:
+        o = ao.OracleSDR()
+        _apply_scatter_config(o, _SCATTER_CONFIGS[grp[c]])
+        want = o.update(I[c % uniq], Q[c % uniq]).reshape(n_blk, BLOCK)
+        assert np.array_equal(np.stack(got[c]), want), "channel %d (group %d)" % (c, grp[c])
+    batch.close()
