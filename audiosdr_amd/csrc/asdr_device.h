@@ -161,6 +161,7 @@ typedef struct {
    * (blanker + IF | mixer + Hilbert | audio filter + AGC + output) work on consecutive blocks of one call at the same time */
   float *xch_a;           /* [n_channels][ASDR_STREAM_DEPTH][2][128]: IF output I, Q of the blocks in flight (role 1 -> role 2) */
   float *xch_b;           /* [n_channels][ASDR_STREAM_DEPTH][128]:    demodulated audio (role 2 -> role 3) */
+  float *xch_c;           /* [n_channels][ASDR_STREAM_DEPTH]:         AM carrier level after the block (role 2 -> role 3's AGC, AudioSDR.cpp:141, 407) */
   uint32_t *stream_prog;  /* [3][stream_waves] blocks completed by each role's wave in this launch (zeroed before it); [3 * stream_waves] =
                              the oscillator role's progress */
   uint32_t *stream_err;   /* [0] set to 1 by a wave that gave up waiting (stream_spin_limit polls): every wave of the launch then leaves

@@ -199,7 +199,7 @@ struct asdr_batch {
   bool als_split = false;           // decided when the schedule is built
   float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
   size_t xch_sam_slots = 0;
-  bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode (checked when the schedule is built)
+  bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode or AM: the modes the block pipeline has roles for (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   long stat_stream_launches = 0;
   uint32_t lo_parity = 0;
@@ -453,7 +453,8 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       bool ssb = b->kind_uniform_slots[ASDR_KERNEL_PLAIN] > 0;
       for (int j = 0; j < b->kind_uniform_slots[ASDR_KERNEL_PLAIN] && ssb; j += 8) {
         const uint32_t m = sl[j].mode;
-        ssb = (m == ASDR_USBmode || m == ASDR_LSBmode || m == ASDR_CW_USBmode || m == ASDR_CW_LSBmode || m == ASDR_WSPRmode);
+        ssb = (m == ASDR_USBmode || m == ASDR_LSBmode || m == ASDR_CW_USBmode || m == ASDR_CW_LSBmode || m == ASDR_WSPRmode ||
+               m == ASDR_AMmode);   // (round 3: the pipeline's role 2 also runs the envelope detector)
       }
       b->plain_uniform_ssb = ssb;
     }
@@ -771,7 +772,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
       float *xa = nullptr, *xb = nullptr; uint32_t *prog = nullptr; LoEntry *ring = nullptr; void *snap = nullptr;
       const size_t n_prog = (size_t)(3 * ((b->n + 7) / 8) + 3);   // [.. + 1] = the error word, [.. + 2] = the recovery counter
       bool ok = hipMalloc(&xa, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * 2 * ASDR_N * sizeof(float)) == hipSuccess &&
-                hipMalloc(&xb, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N * sizeof(float)) == hipSuccess &&
+                hipMalloc(&xb, (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * (ASDR_N + 1) * sizeof(float)) == hipSuccess &&   // + the AM carrier words (xch_c) behind the rows
                 hipMalloc(&prog, n_prog * sizeof(uint32_t)) == hipSuccess &&
                 hipMalloc(&ring, ASDR_LO_RING * sizeof(LoEntry)) == hipSuccess &&
                 hipMalloc(&snap, (size_t)(((b->n + 7) / 8) * 8) * ASDR_SNAP_BYTES) == hipSuccess &&
@@ -787,7 +788,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     a.direct_ch0 = -1;
     if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo; }
     a.lo_write = 0u;
-    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.stream_prog = b->d_stream_prog; a.stream_err = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1;
+    a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.xch_c = b->d_xch_b + (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N; a.stream_prog = b->d_stream_prog; a.stream_err = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1;
     a.stream_waves = w; a.lo_ring = b->d_lo_ring; a.stream_spin_limit = b->stream_spin_limit;
     if (e0) HIPCHK(hipEventRecord(e0, stream));
     if (asdr_launch_stream_snapshot(&a, b->d_stream_snap, 0, stream) != 0) return fail("stream snapshot launch failed");
@@ -795,7 +796,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
     if (asdr_launch_stream_snapshot(&a, b->d_stream_snap, 1, stream) != 0) return fail("stream restore launch failed");
     {   // the same call on the in-kernel block loop, gated on the error word: its waves return at once when the pipeline completed
       UpdateArgs f = a;
-      f.run_if = a.stream_err; f.stream_waves = 0; f.xch_a = nullptr; f.xch_b = nullptr; f.stream_prog = nullptr; f.lo_ring = nullptr;
+      f.run_if = a.stream_err; f.stream_waves = 0; f.xch_a = nullptr; f.xch_b = nullptr; f.xch_c = nullptr; f.stream_prog = nullptr; f.lo_ring = nullptr;
       if (asdr_launch_update(&f, ASDR_KERNEL_PLAIN, 1, stream) != 0) return fail("stream fallback launch failed");
     }
     if (asdr_launch_stream_ack(a.stream_err, stream) != 0) return fail("stream acknowledge launch failed");

@@ -657,6 +657,9 @@ template <int STRIDE>
 __device__ __forceinline__ void asdr_stream_fir_helper(const UpdateArgs &a, float *lds) {
   const int lane = threadIdx.x & 63, c8 = lane >> 3, s8 = lane & 7, k0 = 16 * s8;
   float *L = lds + c8 * STRIDE;
+  // an AM group has no FIR (and its first wave passes no barrier): this wave is done
+  const int wave_g = (int)blockIdx.x % a.stream_waves;
+  if (((a.direct_ch0 >= 0) ? a.direct_mode : a.sched[wave_g * 8].mode) == ASDR_AMmode) return;
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
     v2f acc2[4];
@@ -990,7 +993,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     uint32_t status = S->status;
     // Small operands first (memory waits count loads in order: what is requested first can be waited for alone): the carried
     // mixer phase of the modes whose mixer does not depend on this block's data, the frequency shift, the oscillator cache's key.
-    const bool mix_early = is_ssb || is_am;
+    const bool mix_early = is_ssb || (DO2 && is_am);   // (the pipeline's roles 1 and 3 run no mixer)
     float mphase = 0.0f, minc = 0.0f, mphase_end = 0.0f;   // mphase_end: valid on the lead lanes once the sequence has been computed
     float fsh_raw = 0.0f;
     if (mix_early) {
@@ -1563,7 +1566,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       WAVE_SYNC();
     }
     // envelope detector runs for AM, and for SAM when the PLL is unlocked at the end of the block (:132)
-    const bool do_env = is_am || (is_sam && !pll_locked);
+    const bool do_env = DO2 && (is_am || (is_sam && !pll_locked));
     const bool do_mix = is_ssb || do_env;
 
     // ---- mixer phase sequence, AudioSDR.h:508-526 (phase accumulates sequentially in float) -----------------
@@ -1801,6 +1804,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           lvl = (float)(.995 * (double)lvl + 0.005 * (double)fabsf(x4.w));
         }
         S->am_carrier = lvl; carrier_now = lvl; carrier_fresh = true;
+        if (ROLE == 2) {   // the AGC of this block runs in role 3 (:407-409 take twice THIS block's level): crosses beside the audio row
+          float *xc = a.xch_c + (size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH);
+          asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" :: "v"(xc), "v"(lvl) : "memory");
+        }
       }
     }
     if (is_sam && pll_locked) {   // audio = rotated Q (:126-128)
@@ -1840,6 +1847,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         continue;
       } else {
         v4f v[4];
+        if (is_am) {   // ... and the carrier level role 2's envelope path left for this block (one wait for both)
+          const float *xc = a.xch_c + (size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH);
+          asm volatile("global_load_dword %4, %6, off sc1\n\t"
+                       "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %5, off offset:128 sc1\n\t"
+                       "global_load_dwordx4 %2, %5, off offset:256 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:384 sc1\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(carrier_now) : "v"(xb), "v"(xc) : "memory");
+          carrier_fresh = true;
+        } else
         xch_load4x4(xb, v[0], v[1], v[2], v[3]);
         if (sig_pending) { if (lane == 0) __hip_atomic_store(my_prog, sig_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sig_pending = 0u; }   // (vmcnt(0) inside the loads)
 #pragma unroll
@@ -2348,8 +2364,9 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
   const ChainConsts K = a.k;
   const float two_pi = K.two_pi_f;
   const int ch0 = (a.direct_ch0 >= 0) ? a.direct_ch0 : a.sched[0].ch;
-  float phase = a.small[ch0].phase_ssb;
-  const float inc = (-a.params[ch0].freq_shift) * K.phase_inc_unit;   // as the role-2 waves form it (AudioSDR.h:508-512)
+  const bool am0 = ((a.direct_ch0 >= 0) ? a.direct_mode : a.sched[0].mode) == ASDR_AMmode;
+  float phase = am0 ? a.small[ch0].phase_am : a.small[ch0].phase_ssb;
+  const float inc = (am0 ? -K.if_center : -a.params[ch0].freq_shift) * K.phase_inc_unit;   // as the role-2 waves form it (AudioSDR.h:508-512, .cpp:86, 134)
   uint32_t *const prog = a.stream_prog, *const err = a.stream_err, *const my = a.stream_prog + 3 * a.stream_waves;
   const bool up = !(inc < 0.0f);
   const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;

@@ -213,7 +213,7 @@ unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]);
  * Switching it back on starts from silent rows. */
 int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on);
 int asdr_get_exact_unknown_mode(asdr_batch_t *b);
-/* How many calls so far ran as the streaming block pipeline (a multi-block call on a small batch of SSB-class channels:
+/* How many calls so far ran as the streaming block pipeline (a multi-block call on a small batch of SSB-class or AM channels:
  * three role-specialised waves per group of 8 channels -- blanker + IF | mixer + Hilbert | audio filter + AGC + output -- work
  * on consecutive blocks at the same time).  Results are bit-identical to the block-by-block path; the counter
  * exists so that tests and benchmarks can tell which path ran. */

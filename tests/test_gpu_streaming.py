@@ -164,10 +164,12 @@ def test_block_pipeline_key_groups(gpu, ao):
 
 
 def test_block_pipeline_is_not_used_where_it_does_not_apply(gpu, ao):
-    """An AM channel group, stage taps, a ragged channel count or a short call keep the block-by-block path (same results either way)."""
+    """A SAM channel group (its PLL is a 128-step chain per block: no role set), an ALS filter, stage taps, a ragged channel count or
+    a short call keep the block-by-block path (same results either way)."""
     from audiosdr_amd.synth import make_iq
     T = 12
-    for n_ch, setters, taps in ((64, [S("setDemodMode", 4)], False), (64, [S("setDemodMode", 1)], True), (61, [S("setDemodMode", 1)], False)):
+    for n_ch, setters, taps in ((64, [S("setDemodMode", 5)], False), (64, [S("setDemodMode", 4), S("enableALSfilter")], False),
+                                (64, [S("setDemodMode", 1)], True), (61, [S("setDemodMode", 1)], False)):
         I, Q = make_iq(n_ch, T, fc=6290.0, A=0.25)
         batch, orcs = _mk(gpu, ao, n_ch, setters)
         if taps:
@@ -180,6 +182,71 @@ def test_block_pipeline_is_not_used_where_it_does_not_apply(gpu, ao):
         batch.synchronize()
         assert batch.stream_pipeline_launches() == 0
         hip.free_all(); batch.close()
+
+
+def test_block_pipeline_am_role_set(gpu, ao):
+    """AM through the block pipeline (round 3): role 2 runs mixer + image filter + envelope detector + carrier tracker
+    (AudioSDR.cpp:132-143), the block's carrier level crosses to role 3 beside the audio row, whose AGC takes twice that level in
+    place of |x| (:407-409).  96 channels in three key groups -- AM with blanker + audio filter + AGC, AM with AGC mode 1 and no
+    blanker, USB (so that SSB and AM waves share one pipeline launch; the oscillator role serves the first group) -- with
+    different carrier levels and modulation depths; calls of 40, 1, 24, 2 and 16 blocks: the carrier tracker's state, the image
+    filter's state and the AGC's state are handed over in both directions.  Every block of every channel and the getters
+    (AM carrier level included) against the oracle."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 96, (40, 1, 24, 2, 16)
+    total = sum(plan)
+    fc = 6890.0 + (np.arange(n_ch) % 5 - 2) * 30.0
+    I, Q = make_iq(n_ch, total, fc=fc, A=0.05 + 0.5 * (np.arange(n_ch) % 7) / 7.0, m=0.6, fm=440.0, noise=0.01, impulse_every=900)
+    grp = lambda g: (lambda c: c // 32 == g)
+    setters = [S("setDemodMode", 4, sel=grp(0)), S("enableAudioFilter", sel=grp(0)), S("setNoiseBlankerThresholdDb", 10.0, sel=grp(0)),
+               S("setDemodMode", 4, sel=grp(1)), S("disableNoiseBlanker", sel=grp(1)), S("setAGCmode", 1, sel=grp(1)), S("setAGChangTime", 5.0, sel=grp(1)),
+               S("setDemodMode", 1, sel=grp(2)), S("enableAudioFilter", sel=grp(2))]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    hip = Hip()
+    pos = 0
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call of %d blocks at %d, ch %d" % (T, pos, c)
+        pos += T
+    assert batch.stream_pipeline_launches() == 3
+    assert batch.stream_pipeline_recoveries() == 0
+    from helpers import compare_status
+    compare_status(gpu, batch, orcs)
+    hip.free_all(); batch.close()
+
+
+def test_block_pipeline_am_timeout_is_recovered(gpu, ao):
+    """The transaction with an all-AM batch: injected timeouts (poll limit 30) are recovered in-stream; audio and getters exact."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 64, (20, 18)
+    total = sum(plan)
+    I, Q = make_iq(n_ch, total, fc=6890.0, A=0.3, m=0.5, fm=300.0, noise=0.01)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 4), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0)])
+    batch.debug_set_stream_spin_limit(30)
+    hip = Hip()
+    outs, pos = [], 0
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        outs.append((dO, pos, T))
+        pos += T
+    batch.synchronize()
+    assert batch.stream_pipeline_launches() == 2 and batch.stream_pipeline_recoveries() >= 1
+    gots = [(hip.download(dO, (n_ch, T, 128), np.int16), p0, T) for dO, p0, T in outs]
+    for c in range(n_ch):
+        want = orcs[c].update(I[c], Q[c]).reshape(total, 128)
+        for got, p0, T in gots:
+            assert np.array_equal(got[c], want[p0:p0 + T]), "call at block %d, ch %d" % (p0, c)
+    from helpers import compare_status
+    compare_status(gpu, batch, orcs)
+    hip.free_all(); batch.close()
 
 
 @pytest.mark.parametrize("n_ch,T,pipelined", [(8, 9, True), (672, 11, True), (680, 9, True), (4096, 9, True), (4104, 8, False)])
