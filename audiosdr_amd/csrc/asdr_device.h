@@ -91,6 +91,9 @@ typedef struct {
  * in-class initialisers evaluate them (AudioSDR.h:164-168, 238-239, 249-284) */
 typedef struct {
   double inv_two_pi_d;          /* RN(1.0 / (double)two_pi_f): reciprocal for the exact sine-index division */
+  double sin_index_scale_d;     /* RN(RN(65535.0 / (double)two_pi_f) * (1 + 2^-49)): sin_f32's table phase (long)(Phase * 65535.0 / twoPI)
+                                   (AudioSDR.h:364) as ONE binary64 multiply + truncation (asdr_kernels.hip sin_index; proof and exhaustive
+                                   check: oracle ao_check_sin_index_one_multiply) */
   double half_pi_d;             /* PI / 2.0 (Arduino PI, double): cos_f32's phase offset, AudioSDR.h:376 -- a kernel argument so that it
                                    lives in SGPRs (as a literal the compiler parks it in a VGPR pair for the whole kernel) */
   float if_center;              /* 6890.0f */

@@ -640,6 +640,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   k.two_pi_f = (float)(2.0 * kPI);
   k.half_pi_f = (float)(0.5 * kPI);
   k.inv_two_pi_d = 1.0 / (double)k.two_pi_f;
+  k.sin_index_scale_d = (65535.0 / (double)k.two_pi_f) * (1.0 + 0x1p-49);
   k.half_pi_d = kPI / 2.0;
   k.phase_inc_unit = k.two_pi_f / kFs;
   k.nb_alpha = 0.995f;

@@ -108,16 +108,30 @@ __device__ __forceinline__ double div_by_const(double x, double c, double r) {
   const double rem = __builtin_fma(-q0, c, x);
   return __builtin_fma(rem, r, q0);
 }
-// sin_f32's phase -> uint16 table phase (AudioSDR.h:362-364): index logic, evaluated in binary64.
+// sin_f32's phase -> uint16 table phase (AudioSDR.h:362-364): intPhase = (long)(Phase * 65535.0 / twoPI) in binary64, after one
+// conditional wrap each way.  The quotient as ONE multiply: q' = (double)phase * S with S = RN(RN(65535 / c) (1 + 2^-49)), c = (double)twoPI.
+//   * The exact quotient q = P 2^a 65535 / (C 2^b) (P, C the 24-bit significands) is an integer n or at least 2^-40 q away from
+//     one: |P 65535 2^a - n C 2^b| is a non-zero multiple of 2^min(a, b), which is >= q C 2^b 2^-40 in either case.
+//   * q' lies in (q, q (1 + 2^-48)) for q > 0: the bias 2^-49 exceeds the three roundings (3 x 2^-53), so q' > q, and it stays far
+//     inside the 2^-40 gap -- trunc(q') == trunc(q) whether or not q is an integer.  The reference's own RN(x / c) is within 2^-53
+//     of q, so its truncation is trunc(q) as well.
+// (Round 2 formed the correctly rounded quotient with a multiply and two fmas: two binary64 operations more per lookup, all of
+// them on the PLL's dependent chain.)  Checked for every float32 phase in [0, 2 pi] by the CPU suite (oracle
+// ao_check_sin_index_one_multiply).  -DASDR_SIN_INDEX_DIV: the round-2 form (measurements).
 // BELOW_TWO_PI: the caller guarantees phase < twoPI (the PLL: |phase_est| < pi after its wrap, so phase_est and
 // phase_est + pi/2 are below 4.72), which makes the first test dead -- three instructions less on the PLL's dependent chain.
 // NONNEG: the caller guarantees phase >= 0 (the mixer: its phase stays in [0, twoPI], AudioSDR.h:514-517, and so does phase + pi/2),
 // which makes the second test dead.
+struct SinIndexK { double inv_two_pi, scale; };
 template <bool BELOW_TWO_PI = false, bool NONNEG = false>
-__device__ __forceinline__ uint32_t sin_index(float phase, float two_pi, double inv_two_pi) {
+__device__ __forceinline__ uint32_t sin_index(float phase, float two_pi, SinIndexK k) {
   if (!BELOW_TWO_PI && phase >= two_pi) phase -= two_pi;
   if (!NONNEG && phase < 0.0f) phase += two_pi;
-  const double q = div_by_const((double)phase * 65535.0, (double)two_pi, inv_two_pi);
+#ifdef ASDR_SIN_INDEX_DIV
+  const double q = div_by_const((double)phase * 65535.0, (double)two_pi, k.inv_two_pi);
+#else
+  const double q = (double)phase * k.scale;
+#endif
   return (uint32_t)(int)q & 0xFFFFu;
 }
 // AudioSDR.h:365-369: val1 + (((val2 - val1) * (float)delta) / 256.0).  The double divide-by-256 is exact and the
@@ -131,19 +145,19 @@ __device__ __forceinline__ float sin_lut(const float *sine, uint32_t ip) {
   return v1 + ((v2 - v1) * (float)d) * (1.0f / 256.0f);
 }
 template <bool BELOW_TWO_PI = false>
-__device__ __forceinline__ float sin_f32(const float *sine, float phase, float two_pi, double inv_two_pi) {
+__device__ __forceinline__ float sin_f32(const float *sine, float phase, float two_pi, SinIndexK inv_two_pi) {
   return sin_lut(sine, sin_index<BELOW_TWO_PI>(phase, two_pi, inv_two_pi));
 }
 // AudioSDR.h:375-377
 template <bool BELOW_TWO_PI = false>
-__device__ __forceinline__ float cos_f32(const float *sine, float phase, float two_pi, double inv_two_pi, double half_pi_d) {
+__device__ __forceinline__ float cos_f32(const float *sine, float phase, float two_pi, SinIndexK inv_two_pi, double half_pi_d) {
   return sin_f32<BELOW_TWO_PI>(sine, (float)((double)phase + half_pi_d), two_pi, inv_two_pi);
 }
 // cos_f32 / sin_f32 of NP phases (the mixer, AudioSDR.h:519-520): all 2 NP table phases first, then the 2 NP gathers TOGETHER, then the
 // interpolations.  Written lookup by lookup the compiler waits for every gather right behind its issue -- one exposed L1 round
 // trip per lookup.  Same operations per value as sin_f32 / cos_f32 above.
 template <int NP>
-__device__ __forceinline__ void sincos_batch(const float *sine, const float *ph, float *cc, float *sn, float two_pi, double inv_two_pi, double half_pi_d) {
+__device__ __forceinline__ void sincos_batch(const float *sine, const float *ph, float *cc, float *sn, float two_pi, SinIndexK inv_two_pi, double half_pi_d) {
   uint32_t ipc[NP], ips[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
@@ -169,7 +183,7 @@ __device__ __forceinline__ void sincos_batch(const float *sine, const float *ph,
 // against the vector-memory counter as well -- every lookup then waited for the PLL kernel's outstanding global sample loads too.
 // Both table phases first, both reads together, then the interpolations (same operations per value as sin_f32 / cos_f32).
 typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;
-__device__ __forceinline__ void sincos_pll(const float *sine, float phase, float &c, float &s, float two_pi, double inv_two_pi, double half_pi_d) {
+__device__ __forceinline__ void sincos_pll(const float *sine, float phase, float &c, float &s, float two_pi, SinIndexK inv_two_pi, double half_pi_d) {
   const uint32_t ipc = sin_index<true>((float)((double)phase + half_pi_d), two_pi, inv_two_pi);
   const uint32_t ips = sin_index<true>(phase, two_pi, inv_two_pi);
   lds_cfloat_ptr tab = (lds_cfloat_ptr)sine;
@@ -628,10 +642,10 @@ __device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, co
             if (turns >= ASDR_PLL_WRAP_MAX) phase_est = 0.0f;
           } }
 #ifndef ASDR_PLL_FLAT_LOOKUPS
-        sincos_pll(sine, phase_est, y_re, y_im, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
+        sincos_pll(sine, phase_est, y_re, y_im, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);   // |phase_est| < pi here (wrap above)
 #else
-        y_re = cos_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d, K.half_pi_d);   // |phase_est| < pi here (wrap above)
-        y_im = sin_f32<true>(sine, phase_est, two_pi, K.inv_two_pi_d);
+        y_re = cos_f32<true>(sine, phase_est, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);   // |phase_est| < pi here (wrap above)
+        y_im = sin_f32<true>(sine, phase_est, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d});
 #endif
         pfreq = K.pll_alpha_freq * pfreq + K.pll_beta_freq * (filt * K.pll_f_conv);
         locked = (pfreq > K.pll_lock_lo) && (pfreq < K.pll_lock_hi);
@@ -1614,7 +1628,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane);
       const float ph2[2] = {p2.x, p2.y};
       float c2[2], s2[2];
-      sincos_batch<2>(sine, ph2, c2, s2, two_pi, K.inv_two_pi_d, K.half_pi_d);
+      sincos_batch<2>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
       *reinterpret_cast<float2 *>(lds + STRIDE + PH + 2 * lane) = make_float2(c2[0], c2[1]);
       *reinterpret_cast<float2 *>(lds + 2 * STRIDE + PH + 2 * lane) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
@@ -1638,11 +1652,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           float ph[4];
           load4(L + PH + kF + 32 * m, ph);
 #ifndef ASDR_MIX_SERIAL_LOOKUPS
-          sincos_batch<4>(sine, ph, cc, sn, two_pi, K.inv_two_pi_d, K.half_pi_d);
+          sincos_batch<4>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
 #else
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            cc[j] = cos_f32(sine, ph[j], two_pi, K.inv_two_pi_d, K.half_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, K.inv_two_pi_d);
+            cc[j] = cos_f32(sine, ph[j], two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d); sn[j] = sin_f32(sine, ph[j], two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d});
             if ((j & 1) == 1) SCHED_FENCE();
           }
 #endif
@@ -2150,7 +2164,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane_i);
       const float ph2[2] = {p2.x, p2.y};
       float c2[2], s2[2];
-      sincos_batch<2>(sine, ph2, c2, s2, two_pi, K.inv_two_pi_d, K.half_pi_d);
+      sincos_batch<2>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
       *reinterpret_cast<float2 *>(lo_wr->c + 2 * lane_i) = make_float2(c2[0], c2[1]);
       *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
@@ -2410,7 +2424,7 @@ __device__ __forceinline__ void asdr_stream_lo_role(const UpdateArgs &a, float *
     {
       const float ph2[2] = {p2.x, p2.y};
       float cb[2], sb[2];
-      sincos_batch<2>(nullptr, ph2, cb, sb, two_pi, K.inv_two_pi_d, K.half_pi_d);
+      sincos_batch<2>(nullptr, ph2, cb, sb, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
       c2[0] = cb[0]; c2[1] = cb[1]; s2[0] = sb[0]; s2[1] = sb[1];
     }
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1\n\ts_nop 1"

@@ -720,6 +720,20 @@ uint64_t ao_check_sin_index_division(uint32_t bits_lo, uint32_t bits_hi) {
   return bad;
 }
 
+/* The kernels' ONE-multiply table phase (asdr_kernels.hip sin_index): (long)((double)phase * S) with S = RN(RN(65535 / c) * (1 + 2^-49))
+ * against the reference's (long)((double)phase * 65535.0 / c) (AudioSDR.h:364), for every float32 bit pattern in [bits_lo, bits_hi).
+ * Returns the number of phases whose truncations differ. */
+uint64_t ao_check_sin_index_one_multiply(uint32_t bits_lo, uint32_t bits_hi) {
+  const double c = (double)(float)(2.0 * AO_PI), S = (65535.0 / c) * (1.0 + 0x1p-49);
+  uint64_t bad = 0;
+  for (uint32_t b = bits_lo; b < bits_hi; b++) {
+    union { uint32_t u; float f; } v; v.u = b;
+    const double x = (double)v.f;
+    if ((long)(x * S) != (long)(x * 65535.0 / c)) bad++;
+  }
+  return bad;
+}
+
 /* all int16: s/32767.0 (AudioSDR.cpp:68) */
 int ao_check_scale_division(void) {
   int bad = 0;

@@ -340,6 +340,23 @@ def test_reciprocal_division_is_exact_for_every_phase(ao):
     assert bad == 0
 
 
+def test_sine_table_phase_as_one_multiply(ao):
+    """asdr_kernels.hip sin_index(): (long)((double)phase * S), S = RN(RN(65535 / c)(1 + 2^-49)), equals the reference's
+    (long)(Phase * 65535.0 / twoPI) (AudioSDR.h:364) for EVERY float32 phase in [0, 2*pi] (all 1.09e9 bit patterns): the exact
+    quotient is an integer or at least 2^-40 away from one, and the biased product stays strictly between."""
+    import ctypes as C
+    import struct
+    from concurrent.futures import ThreadPoolExecutor
+    L = ao.lib()
+    L.ao_check_sin_index_one_multiply.argtypes = [C.c_uint32, C.c_uint32]; L.ao_check_sin_index_one_multiply.restype = C.c_uint64
+    hi = struct.unpack("<I", struct.pack("<f", np.float32(2.0 * 3.1415926535897932384626433832795)))[0] + 1
+    n = 16
+    edges = [hi * k // n for k in range(n + 1)]
+    with ThreadPoolExecutor(max_workers=8) as ex:      # ctypes releases the GIL
+        bad = sum(ex.map(lambda k: L.ao_check_sin_index_one_multiply(edges[k], edges[k + 1]), range(n)))
+    assert bad == 0
+
+
 def test_pll_phase_update_as_one_fma(ao):
     """asdr_kernels.hip: phase_est = fmaf(filt + prev_filt, 0.5f, phase_est) == the reference's binary64 form (.cpp:732) for 6e7
     random / near-tie operand pairs over all exponents (denormals included)."""
