@@ -182,8 +182,8 @@ def test_pathological_inputs(gpu, ao):
 @pytest.mark.parametrize("seed,ssb_only", [(101, True), (102, True), (103, False), (104, False)])
 def test_fuzz_multi_block_calls(gpu, ao, seed, ssb_only):
     """64 channels in groups of 8 that always share their configuration (so the waves keep one schedule key), random setter calls
-    between calls of 1 / 3 / 8 / 17 / 30 blocks.  With SSB-class modes only, the calls of 8 blocks and more run as the streaming
-    block pipeline; with all modes they run block by block or through the in-kernel block loop.  Every block against the oracle."""
+    between calls of 1 / 3 / 8 / 17 / 30 blocks.  With SSB-class and AM modes only, the calls of 8 blocks and more run as the streaming
+    block pipeline (groups change between SSB and AM role sets mid-stream); with all modes they run block by block or through the in-kernel block loop.  Every block against the oracle."""
     from audiosdr_amd.synth import make_iq
     rng = np.random.default_rng(seed)
     n_ch, plan = 64, [int(rng.choice([1, 3, 8, 17, 30])) for _ in range(7)]
@@ -200,7 +200,7 @@ def test_fuzz_multi_block_calls(gpu, ao, seed, ssb_only):
         for _ in range(k):
             meth, args, _sel = _random_setter(rng)
             if ssb_only and meth == "setDemodMode":
-                args = (int(rng.choice([0, 1, 2, 3, 6])),)
+                args = (int(rng.choice([0, 1, 2, 3, 4, 6])),)   # the modes the block pipeline has role sets for (SSB class + AM)
             if meth in ("enableALSfilter", "setALSfilterParams") and ssb_only:
                 continue
             groups = rng.random(n_ch // 8) < 0.35
