@@ -767,7 +767,11 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // role's bounded wait fired (asdr_kernels.hip).  3 w + 1 workgroups must be co-resident: w <= stream_max_waves (occupancy query at
   // asdr_create, at most one workgroup per compute unit).
   if (b->stream_pipeline && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN && subs[0].uniform &&
-      b->plain_uniform_ssb && !b->taps_on && subs[0].slots / 8 <= b->stream_max_waves) {
+      b->plain_uniform_ssb &&
+#ifndef ASDR_TIMELINE   /* (the profiling build writes its timestamps through the taps buffer: tools/timeline.py stream) */
+      !b->taps_on &&
+#endif
+      subs[0].slots / 8 <= b->stream_max_waves) {
     const int w = subs[0].slots / 8;
     if (!b->d_xch_a) {   // first use: every buffer, or none (a failed allocation leaves the batch on the other launch forms)
       float *xa = nullptr, *xb = nullptr; uint32_t *prog = nullptr; LoEntry *ring = nullptr; void *snap = nullptr;

@@ -966,6 +966,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int loff = loff_; asm volatile("" : "+v"(loff));
     int ch = ch_; asm volatile("" : "+v"(ch));
     int lane_i = lane; asm volatile("" : "+v"(lane_i));   // for the rarely taken paths: their addresses must not be hoisted (and spilled)
+#ifdef ASDR_TIMELINE
+    // (pipeline roles of channel group 0: slots 2 (3 + role) + block parity, entry 16 = the time before the role's waits)
+    if (STREAM && a.taps != nullptr && wave_g == 0 && lane == 0) (reinterpret_cast<unsigned long long *>(a.taps) + 64 * (3 + ROLE) + 32 * (blk & 1))[16] = clock64();
+#endif
     if (STREAM) {   // streaming pipeline: wait for this block's input rows and for a free slot in the ring this role writes
       uint32_t *prog = a.stream_prog, *err = a.stream_err;
       const uint32_t b1 = (uint32_t)blk + 1u, freed = (blk >= ASDR_STREAM_DEPTH) ? (uint32_t)(blk - ASDR_STREAM_DEPTH + 1) : 0u;
@@ -988,7 +992,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const bool lead = (s8 == 0);
 #ifdef ASDR_TIMELINE
     // profiling build (tools/timeline.py): lane 0 of a few waves timestamps the phase boundaries into the taps buffer
-    const int tl_slot = (wave_g == 0) ? 0 : ((wave_g == 2731) ? 1 : ((wave_g == 5461) ? 2 : ((wave_g == 8191) ? 3 : -1)));
+    const int tl_slot = STREAM ? ((wave_g == 0) ? 2 * (3 + ROLE) + (blk & 1) : -1)
+                               : ((wave_g == 0) ? 0 : ((wave_g == 2731) ? 1 : ((wave_g == 5461) ? 2 : ((wave_g == 8191) ? 3 : -1))));
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(a.taps) + 32 * (tl_slot < 0 ? 0 : tl_slot);
 #define TL(i) do { if (a.taps != nullptr && tl_slot >= 0 && lane == 0) tl[i] = clock64(); } while (0)
     const bool tap_on = false;

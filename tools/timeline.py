@@ -66,5 +66,54 @@ def run():
         L.asdr_destroy(h)
 
 
+def stream(T=256, n_ch=512):
+    """The block pipeline's three roles of channel group 0 over the last two blocks of a T-block call (WSPR settings, as C5):
+    time between two consecutive block starts of each role (its cycle time = the pipeline's time per block if it is the slowest)
+    and where inside the block it goes: waits for the neighbours' counters | every phase boundary of the chain."""
+    import audiosdr_amd as A
+    from audiosdr_amd.synth import make_iq
+    import torch
+    import bench
+    L = A.binding.load_library(LIB)
+    I, Q = make_iq(n_ch, T, fc=6890.0, A=0.02, noise=0.05)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    dO = torch.empty((n_ch, T, 128), dtype=torch.int16, device="cuda")
+    h = L.asdr_create(n_ch, 0)
+    class H:   # the bench's C5 settings through the raw handle
+        def __getattr__(self, name):
+            return lambda *a: getattr(L, "asdr_" + name)(h, -1, *a)
+    bench.configure_c5(H())
+    L.asdr_enable_taps(h, 1)
+    names = ["waits for the neighbours"] + NAMES
+    acc = []
+    for rep in range(8):
+        L.asdr_update_device(h, C.c_void_p(dI.data_ptr()), C.c_void_p(dQ.data_ptr()), C.c_void_p(dO.data_ptr()), T, None)
+        L.asdr_synchronize(h)
+        taps = np.zeros((12, n_ch, 128), dtype=np.float32)
+        L.asdr_read_taps(h, taps.ctypes.data_as(C.POINTER(C.c_float)))
+        tl = taps.reshape(-1).view(np.uint64)[:32 * 14].reshape(14, 32).astype(np.int64)
+        if rep >= 2:
+            acc.append(tl)
+    print("pipeline launches:", L.asdr_stream_pipeline_launches(h))
+    tl = np.stack(acc)   # [rep][slot][32]
+    last, prev = (T - 1) & 1, (T - 2) & 1
+    for role in (1, 2, 3):
+        a_, p_ = tl[:, 2 * (3 + role) + last], tl[:, 2 * (3 + role) + prev]
+        cyc = np.median(a_[:, 16] - p_[:, 16])
+        print("== role %d: %.0f cycles between two block starts" % (role, cyc))
+        seq = np.concatenate([a_[:, 16:17], a_[:, :16]], axis=1)    # pre-wait, TL0..TL15
+        d = np.diff(seq, axis=1)
+        med = np.median(d, axis=0)
+        for nm, v in zip(names, med):
+            if v > 0 and v < 10 * cyc:
+                print("   %-36s %8.0f cycles" % (nm, v))
+    L.asdr_destroy(h)
+
+
 if __name__ == "__main__":
-    (build if sys.argv[1:] == ["build"] else run)()
+    if sys.argv[1:2] == ["build"]:
+        build()
+    elif sys.argv[1:2] == ["stream"]:
+        stream(*[int(x) for x in sys.argv[2:]])
+    else:
+        run()
