@@ -273,8 +273,8 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
   for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
   const bool s0 = (st == 0);
   const unsigned long long s0m = __ballot(s0);   // EXEC is full here
-#pragma unroll 1
-  for (int c = 0; c < NSTEP; ++c) {
+  auto step = [&](auto edge_tag, const int c) {
+    constexpr bool EDGE = decltype(edge_tag)::value;   // a step of the systolic fill / drain: some stages have no chunk
     const int cn = c - st;
     float x[C], p[C], y[C];
 #if defined(ASDR_PIPE_PLAIN_SELECT) || ASDR_PIPE_CHUNK != 8
@@ -318,7 +318,7 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
       float t = p[j] + a1 * ym1; t += a2 * ym2;
       y[j] = t;
     }
-    const bool act = (cn >= 0) && (cn < ASDR_N / C);
+    const bool act = !EDGE || ((cn >= 0) && (cn < ASDR_N / C));
     if (act) { x1 = x[C - 1]; x2 = x[C - 2]; y1 = y[C - 1]; y2 = y[C - 2]; }
 #pragma unroll
     for (int j = 0; j < C; ++j) yo[j] = y[j];
@@ -326,7 +326,21 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
 #pragma unroll
       for (int q = 0; q < C / 4; ++q) reinterpret_cast<float4 *>(row)[cn * (C / 4) + q] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
     }
-  }
+  };
+#if defined(ASDR_PIPE_ONE_LOOP) || ASDR_PIPE_CHUNK != 8
+#pragma unroll 1
+  for (int c = 0; c < NSTEP; ++c) step(std::true_type{}, c);
+#else
+  // Steps 3 .. 15 have a chunk for every stage: no activity test, no predicated state update (round 2 ran all 19 steps through the
+  // general form: 9 instructions of 102 per step).  Two steps per trip, so that the carried state is a register renaming.
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) step(std::true_type{}, c);
+#pragma unroll 1
+  for (int c = 3; c < 15; c += 2) { step(std::false_type{}, c); step(std::false_type{}, c + 1); }
+  step(std::false_type{}, 15);
+#pragma unroll 1
+  for (int c = 16; c < NSTEP; ++c) step(std::true_type{}, c);
+#endif
   sv[0] = x1; sv[1] = x2; sv[2] = y1; sv[3] = y2;
 }
 
