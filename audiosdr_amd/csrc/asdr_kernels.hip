@@ -821,8 +821,18 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
           if (g == 6) p[3] = (h == 0) ? p[3] : 0.0f;   // tap 55 does not exist (the running sum starts at +0.0: adding +0.0 leaves it)
 #pragma unroll
           for (int t = 0; t < 4; ++t) { y += p[t]; y += dpp_row_shl4(p[t]); }
-          __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from forming all 28 products -- and 28 moved copies -- up front: registers)
+#ifdef ASDR_ALS_GROUP_BARRIER   /* (round 3, first form: kept the scheduler from forming all 28 products up front -- and kept 20 of the 28 DPP operands from folding) */
+          __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#ifndef ASDR_ALS_SUMS_SINKABLE
+        // The sum is formed by ALL lanes, here: left to itself the compiler sinks the 56 additions into the `mine` branch below (only
+        // there is y used), where the partner quad is inactive -- so the 28 `row_shl:4` operands cannot fold into the additions and
+        // become 28 v_mov_b32_dpp per tap set in front of the branch.  With the sums here and no scheduling barrier between the tap
+        // groups every one of them is a v_add_f32_dpp, the products rotate through four registers (mul | add | add_dpp per tap pair)
+        // and a tap set is 144 instructions instead of 151 (21 of them one-cycle s_nop for the DPP read-after-write hazard): C4 -3.8 %.
+        asm volatile("" : "+v"(y));
+#endif
         if (mine) {
           const float e = L[XB + i] - y;
           L[OUT + n] = notch ? e : y;
