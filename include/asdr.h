@@ -237,8 +237,8 @@ int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels)
 /* Channels with a short ALS filter (taps <= 64, delay + taps <= 65; not SAM) CAN run as two launches -- the chain up to the AGC as the
  * plain kernel, then the filter and the output stage on small LDS rows (asdr_als_kernel) -- when the batch has at least
  * split_min_channels of them.  Default (<= 0, or environment ASDR_ALS_SPLIT_MIN unset at asdr_create time): never -- measured on
- * MI355X the two-launch form is 2 % faster for 131,072 mixed channels, 6 % slower for 1,048,576 and 3 % slower for an all-ALS batch
- * (profiles/README.md).  Bit-identical results.  asdr_schedule_layout()'s out[7] carries the choice in bit 1. */
+ * MI355X the two-launch form is 2 % slower for 131,072 mixed channels, 12 % slower for 1,048,576 and 9 % slower for an all-ALS batch
+ * (profiles/README.md; it is the measuring bench that found the filter's LDS bound).  Bit-identical results.  asdr_schedule_layout()'s out[7] carries the choice in bit 1. */
 int asdr_set_als_launch_form(asdr_batch_t *b, int split_min_channels);
 /* Test hook: the number of polls after which a pipeline wait gives up (0 = the default, 2^18).  A tiny value injects timeouts, so
  * that the recovery path can be tested on an idle GPU. */

@@ -9,7 +9,7 @@ Workloads (65,536 channels unless stated; one block per launch; ms per launch fr
   c2      bench.py's headline            c2div   8 different mixer phases per wave      c2agc   AGC hang time 0
   c2imp   an impulse in every block      c2adv   the three together                     c2x0    c2 without the kept audio row
   c3      SAM, 262,144 ch                c4      mode = c mod 7 + ALS, 131,072 ch       als1    all USB + ALS, 131,072 ch
-  am      all AM, 131,072 ch             c4big   c4 at 1,048,576 ch
+  am      all AM, 131,072 ch             c4big   c4 at 1,048,576 ch             c4s / c4bigs / als1s   the same with the ALS filter as a launch of its own
 Variants are timed interleaved, `rounds` times each; medians are printed, with the ratio to the in-tree library ("tree").
 """
 import ctypes as C
@@ -50,12 +50,16 @@ def setup(L, h, wl, n_ch, step):
             L.asdr_set_exact_unknown_mode(h, 0)
     elif wl == "c3":
         L.asdr_setDemodMode(h, -1, 5); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0); L.asdr_enableAudioFilter(h, -1); L.asdr_setAudioFilter(h, -1, 0)
-    elif wl in ("c4", "c4big"):
+    elif wl in ("c4", "c4big", "c4s", "c4bigs"):
         for c in range(n_ch):
             L.asdr_setDemodMode(h, c, c % 7)
         L.asdr_enableALSfilter(h, -1); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
-    elif wl == "als1":
+        if wl.endswith("s"):
+            L.asdr_set_als_launch_form(h, 1)   # short ALS filters as a launch of their own
+    elif wl in ("als1", "als1s"):
         L.asdr_setDemodMode(h, -1, 1); L.asdr_enableALSfilter(h, -1); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
+        if wl.endswith("s"):
+            L.asdr_set_als_launch_form(h, 1)
     elif wl == "am":
         L.asdr_setDemodMode(h, -1, 4); L.asdr_setNoiseBlankerThresholdDb(h, -1, 10.0)
     else:
@@ -65,7 +69,7 @@ def setup(L, h, wl, n_ch, step):
 def signal(wl):
     if wl == "c3":
         return dict(fc=None, A=0.3, m=0.5, fm=400.0)
-    if wl in ("c4", "c4big", "als1", "am"):
+    if wl in ("c4", "c4big", "als1", "am", "c4s", "c4bigs", "als1s"):
         return dict(fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15)
     s = dict(fc=6290.0, A=0.25)
     if wl in ("c2imp", "c2adv"):
@@ -85,10 +89,10 @@ def run(workloads, rounds, n_rep):
         paths = {k: v for k, v in paths.items() if k in only.split(",") or k == "tree"}
     dev = torch.device("cuda", 0)
     for wl in workloads:
-        n_ch = {"c3": 262144, "c4": 131072, "als1": 131072, "am": 131072, "c4big": 1048576, "c2n2": 131072, "c2n3": 196608, "c2n4": 262144,
+        n_ch = {"c3": 262144, "c4": 131072, "als1": 131072, "am": 131072, "c4big": 1048576, "c4s": 131072, "als1s": 131072, "c4bigs": 1048576, "c2n2": 131072, "c2n3": 196608, "c2n4": 262144,
                 "c2h": 73728}.get(wl, 65536)
         sig = signal(wl)
-        uniq = 3584 if wl in ("c3", "c4", "c4big", "als1", "am") else n_ch // 4
+        uniq = 3584 if wl in ("c3", "c4", "c4big", "als1", "am", "c4s", "c4bigs", "als1s") else n_ch // 4
         if sig.get("fc") is None:
             sig["fc"] = 6890.0 + (np.arange(uniq) % 7 - 3) * 50.0
         dI, dQ = bench.tiled_input(np, torch, dev, n_ch, 4, uniq, **sig)
