@@ -1239,7 +1239,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                 pv[u] = phase;
                 const float t = phase + minc, tw = t + two_pi;
                 const uint32_t tb = __float_as_uint(t), m = (uint32_t)((int32_t)tb >> 31);
+#ifdef ASDR_PHASE_SELECT_C
                 phase = __uint_as_float((__float_as_uint(tw) & m) | (tb & ~m));
+#else
+                // (m & tw) | (~m & t) as ONE v_bfi_b32: from the C expression the compiler builds v_max_i32(0, t) + v_and_or_b32
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(phase) : "v"(m), "v"(tw), "v"(t));
+#endif
               }
               store8(L + PH + 8 * (c + half), pv);
               store8(L + NB_B + 2 + 8 * (c + half), av);
