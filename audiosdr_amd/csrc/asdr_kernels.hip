@@ -810,6 +810,7 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
         float xo[7];
 #pragma unroll
         for (int g = 0; g < 7; ++g) xo[g] = xu[-8 * g];
+        const float xi = L[XB + i];   // the sample itself (e = x[i] - y), requested with the operands
         float y = 0.0f;
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
@@ -833,6 +834,7 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
         // and a tap set is 144 instructions instead of 151 (21 of them one-cycle s_nop for the DPP read-after-write hazard): C4 -3.8 %.
         asm volatile("" : "+v"(y));
 #endif
+#ifdef ASDR_ALS_E_THROUGH_LDS   /* round 3, first form: the error of the tap set's updating sample through an LDS word, two wave syncs per tap set */
         if (mine) {
           const float e = L[XB + i] - y;
           L[OUT + n] = notch ? e : y;
@@ -848,6 +850,26 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
           }
         }
         WAVE_SYNC();
+#else
+        // The error of the updating sample (n = nu: lane tq = 3 of the low quad, tq = 0 in the first tap set) goes to the channel's
+        // eight lanes through two DPP moves -- its quad, then the partner quad (row_shr:4 into banks 1 and 3 only) -- instead of an
+        // LDS word between two wave syncs: the tap set's dependent path error -> tap update -> next products stays in registers.
+        // (Nothing else crosses lanes through LDS inside the loop: the history is read-only and the output samples are read after it.)
+        float e_own = 0.0f;
+        if (mine) {
+          e_own = xi - y;
+          L[OUT + n] = notch ? e_own : y;
+        }
+        if (nu < ASDR_N) {
+          const int eq = __builtin_amdgcn_update_dpp(0, __float_as_int(e_own), FIRST ? 0x00 : 0xFF, 0xF, 0xF, true);   // quad_perm [0,0,0,0] / [3,3,3,3]
+          const float e = __int_as_float(__builtin_amdgcn_update_dpp(eq, eq, 0x114, 0xF, 0xA, false));                // row_shr:4, banks 1 and 3
+#pragma unroll
+          for (int g = 0; g < 7; ++g) {
+            const float gq = e * xo[g]; const float dq = lam * gq; const float wn = wr[g] + dq;
+            wr[g] = (g == 6 && !own_valid6) ? wr[g] : wn;
+          }
+        }
+#endif
       };
       epoch(std::true_type{}, -1);
 #pragma unroll 1
