@@ -1,0 +1,176 @@
+"""Pins the oracle's restatement of CMSIS-DSP `arm_biquad_cascade_df1_f32` / `_init_f32` against THE REFERENCE'S OWN BINARY.
+
+The functions are the only third-party arithmetic on the hot path (call sites AudioSDR.cpp:77-78, 136-137, 285; prototypes
+arm_math.h:1257-1262, 1360-1378) and the reference ships them only as Cortex-M4 objects inside
+`ARM_MATH UPDATE/TeensyduinoArmMathUpdate/libarm_cortexM4lf_math.a`.  tests/thumb_emu.py reads the archive members and executes
+their code; here:
+  * a static census of the object: 25 vmul.f32, 20 vadd.f32, NO fused multiply-add of any kind (SURVEY.md 8(c) said so in prose);
+  * the symbolic dataflow of one sample through the single-sample loop and of four through the 4x-unrolled loop:
+    (((b0*x + b1*x1) + b2*x2) + a1*y1) + a2*y2, state written back as {x1, x2, y1, y2};
+  * the object EXECUTED on random and adversarial inputs (every table of the reference, block sizes that take the unrolled loop,
+    the tail loop and both, in place as AudioSDR.cpp calls it) == oracle.biquad_cascade, bit for bit, outputs and state;
+  * `_init_f32` executed: the three instance fields and memset(pState, 0, 4 * numStages floats).
+Those tests need /root/reference and skip without it (the GPU box); the committed vectors in tests/golden/cmsis_biquad_vectors.npz
+(made by tests/golden/make_cmsis_vectors.py from the same emulated object) are checked against the oracle everywhere.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import asdr_oracle as ao
+from tests import thumb_emu as T
+
+ARCHIVE = "/root/reference/ARM_MATH UPDATE/TeensyduinoArmMathUpdate/libarm_cortexM4lf_math.a"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cmsis_biquad_vectors.npz")
+needs_reference = pytest.mark.skipif(not os.path.exists(ARCHIVE), reason="the reference's CMSIS archive is not on this machine")
+
+CODE, INST, COEF, STATE, SRC, DST, SP = 0x100, 0x1000, 0x1100, 0x1400, 0x2000, 0x6000, 0xF000
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def run_object(code, coefs, state, x, in_place=True, symbolic=False):
+    """arm_biquad_cascade_df1_f32(&S, pSrc, pDst, blockSize) on the emulator -> (y, state after, cpu)."""
+    coefs = np.asarray(coefs, dtype=np.float32).ravel()
+    n_stages, n = coefs.size // 5, len(x)
+    cpu = T.Cpu()
+    cpu.symbolic = symbolic
+    if symbolic:
+        for st in range(n_stages):
+            for k, nm in enumerate(("b0", "b1", "b2", "a1", "a2")): cpu.names[COEF + 20 * st + 4 * k] = "%s_%d" % (nm, st)
+            for k, nm in enumerate(("x1", "x2", "y1", "y2")): cpu.names[STATE + 16 * st + 4 * k] = "%s_%d" % (nm, st)
+        for k in range(n): cpu.names[SRC + 4 * k] = "in%d" % k
+    cpu.load_code(code, CODE)
+    cpu.wr32(INST, n_stages); cpu.wr32(INST + 4, STATE); cpu.wr32(INST + 8, COEF)     # arm_biquad_casd_df1_inst_f32, arm_math.h:1257-1262
+    cpu.write_f32(COEF, coefs); cpu.write_f32(STATE, state); cpu.write_f32(SRC, x)
+    dst = SRC if in_place else DST
+    cpu.call(CODE, [INST, SRC, dst, n], SP)
+    return cpu.read_f32(dst, n), cpu.read_f32(STATE, 4 * n_stages), cpu
+
+
+def cases():
+    """(name, coefs[n_stages*5], state[n_stages*4], x): the inputs of the committed vectors and of the live comparison."""
+    rng = np.random.default_rng(20260410)
+    out = []
+    n_tables = 15
+    for tbl in range(n_tables):                       # every biquad table the reference holds (AudioSDR.h:582-738)
+        co = ao.biquad_table(tbl).ravel()
+        for n in (128, 7):
+            out.append(("table%d_n%d" % (tbl, n), co, (0.1 * rng.standard_normal(16)).astype(np.float32),
+                        (0.5 * rng.standard_normal(n)).astype(np.float32)))
+    co = ao.biquad_table(0).ravel()
+    for n in (1, 2, 3, 4, 5, 8, 9, 127, 130):          # tail only | unrolled only | both
+        out.append(("len%d" % n, co, (0.1 * rng.standard_normal(16)).astype(np.float32), rng.standard_normal(n).astype(np.float32)))
+    for ns in (1, 2, 3):                               # fewer stages than the reference uses
+        out.append(("stages%d" % ns, co[:5 * ns], (0.1 * rng.standard_normal(4 * ns)).astype(np.float32), rng.standard_normal(37).astype(np.float32)))
+    # products whose exact sum needs more than 24 bits: a fused multiply-add would round differently from mul-then-add
+    x = (1.0 + rng.integers(1, 1 << 23, 128) * 2.0 ** -23).astype(np.float32)
+    coa = (rng.choice([-1.0, 1.0], 20) * (1.0 + rng.integers(1, 1 << 23, 20) * 2.0 ** -23) * 0.3).astype(np.float32)
+    out.append(("fma_sensitive", coa, np.zeros(16, np.float32), x))
+    # denormals (the FPv4-SP unit runs without flush-to-zero by default) and signed zeros
+    tiny = (rng.standard_normal(64) * 1e-41).astype(np.float32)
+    out.append(("denormal", co, (rng.standard_normal(16) * 1e-42).astype(np.float32), tiny))
+    out.append(("zeros", co, np.zeros(16, np.float32), np.concatenate([np.zeros(5, np.float32), -np.zeros(5, np.float32)])))
+    return out
+
+
+@needs_reference
+def test_object_holds_only_separate_multiplies_and_adds():
+    code, rel = T.load_function(ARCHIVE, "arm_biquad_cascade_df1_f32.o", "arm_biquad_cascade_df1_f32")
+    assert len(code) == 416 and rel == []             # self-contained: no calls, no literal pool
+    c = T.vfp_census(code)
+    assert c["vmul.f32"] == 25 and c["vadd.f32"] == 20, c    # (4x unrolled + tail) x (5 products, 4 sums)
+    assert c["fused"] == 0 and c["vsub.f32"] == 0 and c["vnmul.f32"] == 0 and c["vdiv.f32"] == 0 and c["other"] == 0 and c["f64"] == 0, c
+
+
+def _sum5(b0, x, b1, x1, b2, x2, a1, y1, a2, y2):
+    """(((b0*x + b1*x1) + b2*x2) + a1*y1) + a2*y2 in the emulator's notation (operands of a commutative operation sorted)."""
+    def op(a, b, o): a, b = sorted([a, b]); return "(%s%s%s)" % (a, o, b)
+    acc = op(op(b0, x, "*"), op(b1, x1, "*"), "+")
+    acc = op(acc, op(b2, x2, "*"), "+")
+    acc = op(acc, op(a1, y1, "*"), "+")
+    return op(acc, op(a2, y2, "*"), "+")
+
+
+@needs_reference
+def test_dataflow_association_and_state_order():
+    code, _ = T.load_function(ARCHIVE, "arm_biquad_cascade_df1_f32.o", "arm_biquad_cascade_df1_f32")
+    co = np.arange(1, 6, dtype=np.float32)
+    c = ("b0_0", "b1_0", "b2_0", "a1_0", "a2_0")
+    # one sample: the tail loop
+    _, _, cpu = run_object(code, co, np.zeros(4, np.float32), np.ones(1, np.float32), in_place=False, symbolic=True)
+    y0 = _sum5(c[0], "in0", c[1], "x1_0", c[2], "x2_0", c[3], "y1_0", c[4], "y2_0")
+    assert cpu.mem_expr[DST] == y0
+    assert [cpu.mem_expr[STATE + 4 * k] for k in range(4)] == ["in0", "x1_0", y0, "y1_0"]      # {x1, x2, y1, y2}
+    # four samples: the unrolled loop; five: unrolled + tail
+    for n in (4, 5):
+        _, _, cpu = run_object(code, co, np.zeros(4, np.float32), np.ones(n, np.float32), in_place=False, symbolic=True)
+        xs = ["x2_0", "x1_0"] + ["in%d" % k for k in range(n)]
+        ys = ["y2_0", "y1_0"]
+        for k in range(n):
+            ys.append(_sum5(c[0], xs[k + 2], c[1], xs[k + 1], c[2], xs[k], c[3], ys[k + 1], c[4], ys[k]))
+            assert cpu.mem_expr[DST + 4 * k] == ys[-1], (n, k)
+        assert [cpu.mem_expr[STATE + 4 * k] for k in range(4)] == [xs[-1], xs[-2], ys[-1], ys[-2]]
+    # two stages: stage 1 reads stage 0's OUTPUT (pDst), stage-major
+    co2 = np.arange(1, 11, dtype=np.float32)
+    _, _, cpu = run_object(code, co2, np.zeros(8, np.float32), np.ones(1, np.float32), in_place=False, symbolic=True)
+    s0 = _sum5("b0_0", "in0", "b1_0", "x1_0", "b2_0", "x2_0", "a1_0", "y1_0", "a2_0", "y2_0")
+    assert cpu.mem_expr[DST] == _sum5("b0_1", s0, "b1_1", "x1_1", "b2_1", "x2_1", "a1_1", "y1_1", "a2_1", "y2_1")
+
+
+@needs_reference
+def test_executed_object_equals_the_oracle():
+    code, _ = T.load_function(ARCHIVE, "arm_biquad_cascade_df1_f32.o", "arm_biquad_cascade_df1_f32")
+    for name, co, st, x in cases():
+        for in_place in (True, False):
+            y, st_after, cpu = run_object(code, co, st, x, in_place=in_place)
+            yo, so = ao.biquad_cascade(co, st.copy(), x)
+            assert np.array_equal(_bits(y), _bits(yo)), (name, in_place)
+            assert np.array_equal(_bits(st_after), _bits(so)), (name, in_place)
+            ns, n = len(co) // 5, len(x)
+            assert cpu.trace.count("vmul.f32") == 5 * ns * n and cpu.trace.count("vadd.f32") == 4 * ns * n
+
+
+@needs_reference
+def test_init_object():
+    code, rel = T.load_function(ARCHIVE, "arm_biquad_cascade_df1_init_f32.o", "arm_biquad_cascade_df1_init_f32")
+    assert [(r[1], r[2]) for r in rel] == [(10, "memset")]      # R_ARM_THM_CALL memset: the one external call
+    cpu = T.Cpu()
+    cpu.load_code(code, CODE)
+    cpu.mem[STATE - 16:STATE + 16 * 5] = b"\xAA" * (16 * 6)
+    calls = []
+
+    def memset(c):
+        dst, val, n = c.r[0], c.r[1], c.r[2]
+        calls.append((dst, val, n))
+        c.mem[dst:dst + n] = bytes([val & 0xFF]) * n
+    cpu.hooks[rel[0][0]] = memset
+    cpu.call(CODE, [INST, 4, COEF, STATE], SP)       # (S, numStages, pCoeffs, pState), arm_math.h:1372-1378
+    assert calls == [(STATE, 0, 4 * 4 * 4)]           # 4 state words per stage, zeroed
+    assert (cpu.rd32(INST), cpu.rd32(INST + 4), cpu.rd32(INST + 8)) == (4, STATE, COEF)
+    assert bytes(cpu.mem[STATE - 16:STATE]) == b"\xAA" * 16 and bytes(cpu.mem[STATE + 64:STATE + 80]) == b"\xAA" * 16
+
+
+def test_committed_vectors_from_the_reference_binary_equal_the_oracle():
+    """Runs everywhere (also on the GPU box): outputs of the reference's object, emulated here when the fixture was made."""
+    g = np.load(GOLDEN)
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 40
+    for i, name in enumerate(names):
+        co, st, x = g["coefs_%d" % i], g["state_%d" % i], g["x_%d" % i]
+        yo, so = ao.biquad_cascade(co, st.copy(), x)
+        assert np.array_equal(_bits(yo), g["y_bits_%d" % i]), name
+        assert np.array_equal(_bits(so), g["state_after_bits_%d" % i]), name
+
+
+@needs_reference
+def test_committed_vectors_are_what_the_object_computes():
+    code, _ = T.load_function(ARCHIVE, "arm_biquad_cascade_df1_f32.o", "arm_biquad_cascade_df1_f32")
+    g = np.load(GOLDEN)
+    assert str(g["object_sha256"]) == __import__("hashlib").sha256(code).hexdigest()
+    for i in (0, 7, len(g["names"]) - 3):
+        y, st_after, _ = run_object(code, g["coefs_%d" % i], g["state_%d" % i], g["x_%d" % i])
+        assert np.array_equal(_bits(y), g["y_bits_%d" % i]) and np.array_equal(_bits(st_after), g["state_after_bits_%d" % i])
