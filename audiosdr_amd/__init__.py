@@ -9,7 +9,7 @@ missing, construction raises.
 from .binding import (AGCfast, AGCmedium, AGCoff, AGCslow, ALL, AMmode, BLOCK, CW_LSBmode, CW_USBmode, LSBmode, SAMmode,
                       TAPS, USBmode, WSPRmode, AudioSDRBatch, AsdrError, audio2100, audio2300, audio2500, audio2700,
                       audio2900, audio3100, audio3300, audioAM, audioBypass, audioCW, audioWSPR, library_path,
-                      library_sha256, load_library)
+                      library_sha256, load_library, host_alloc, host_free)
 from .front import (NO_DEVICE, AudioGrabberComplex256Batch, AudioIQgeneratorBatch, AudioSDRpreProcessorBatch,  # noqa: E402
                     FRONT_EXPORTS)
 

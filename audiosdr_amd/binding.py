@@ -56,7 +56,10 @@ EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels",
             "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_set_exact_unknown_mode", "asdr_get_exact_unknown_mode", "asdr_stream_pipeline_recoveries", "asdr_stream_pipeline_max_groups", "asdr_set_stream_pipeline", "asdr_set_sam_launch_form", "asdr_set_als_launch_form", "asdr_debug_set_stream_spin_limit", "asdr_debug_set_stream_max_groups", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
             "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_set_launch_timing", "asdr_region_timing_begin", "asdr_region_timing_end", "asdr_update_device_strided", "asdr_capture_open",
             "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
-            "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read"] +
+            "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read",
+            "asdr_create_sharded", "asdr_n_shards", "asdr_shard", "asdr_shard_first_channel", "asdr_shard_device",
+            "asdr_host_alloc", "asdr_host_free", "asdr_host_register", "asdr_host_unregister", "asdr_set_host_chunks",
+            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures"] +
            ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
 
 _lib = None
@@ -135,6 +138,19 @@ def load_library(path=None):
         L.asdr_region_timing_begin.argtypes = [vp, vp]; L.asdr_region_timing_begin.restype = _i
         L.asdr_region_timing_end.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_long)]; L.asdr_region_timing_end.restype = _i
     L.asdr_kernel_timing_end.argtypes = [vp, fp, _i]; L.asdr_kernel_timing_end.restype = _i
+    if path is None or hasattr(L, "asdr_create_sharded"):   # (older builds timed by tools/ablate.py lack these)
+        L.asdr_create_sharded.argtypes = [_i, _i, C.POINTER(C.c_int)]; L.asdr_create_sharded.restype = vp
+        L.asdr_n_shards.argtypes = [vp]; L.asdr_n_shards.restype = _i
+        L.asdr_shard.argtypes = [vp, _i]; L.asdr_shard.restype = vp
+        L.asdr_shard_first_channel.argtypes = [vp, _i]; L.asdr_shard_first_channel.restype = _i
+        L.asdr_shard_device.argtypes = [vp, _i]; L.asdr_shard_device.restype = _i
+        L.asdr_host_alloc.argtypes = [C.c_size_t]; L.asdr_host_alloc.restype = vp
+        L.asdr_host_free.argtypes = [vp]; L.asdr_host_free.restype = None
+        L.asdr_host_register.argtypes = [vp, C.c_size_t]; L.asdr_host_register.restype = _i
+        L.asdr_host_unregister.argtypes = [vp]; L.asdr_host_unregister.restype = _i
+        L.asdr_set_host_chunks.argtypes = [vp, _i]; L.asdr_set_host_chunks.restype = _i
+        L.asdr_host_path_info.argtypes = [vp, C.POINTER(C.c_int)]; L.asdr_host_path_info.restype = _i
+        L.asdr_stream_pipeline_alloc_failures.argtypes = [vp]; L.asdr_stream_pipeline_alloc_failures.restype = C.c_long
     if path is None:
         _lib = L
     return L
@@ -143,18 +159,64 @@ def load_library(path=None):
 class AudioSDRBatch:
     """N independent AudioSDR channels on one MI355X.  Method names follow the reference class."""
 
-    def __init__(self, n_channels, device=0):
+    def __init__(self, n_channels, device=0, devices=None, _handle=None, _owner=None):
+        """`device`: one HIP device ordinal (asdr_create).  `devices`: a list of ordinals, one per shard -> a sharded batch
+        (asdr_create_sharded): shard g owns channels [g*C/G, (g+1)*C/G) on devices[g]; every method keeps taking GLOBAL channel
+        indices."""
         self._L = load_library()
-        self._h = self._L.asdr_create(int(n_channels), int(device))
+        self._owner = _owner          # a shard view keeps its sharded batch alive and never destroys the handle
+        if _handle is not None:
+            self._h = _handle
+        elif devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            self._h = self._L.asdr_create_sharded(int(n_channels), len(devices), devs)
+        else:
+            self._h = self._L.asdr_create(int(n_channels), int(device))
         if not self._h:
             raise AsdrError("asdr_create failed: " + self._L.asdr_last_error().decode())
         self.n_channels = int(n_channels)
-        self.device = int(device)
+        self.device = int(device) if devices is None else None
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.asdr_destroy(self._h)
+            if self._owner is None:
+                self._L.asdr_destroy(self._h)
             self._h = None
+
+    # ---- sharded batches ----
+    @property
+    def n_shards(self):
+        return int(self._L.asdr_n_shards(self._h))
+
+    def shard(self, g):
+        """Shard g as a batch of its own (local channel indices, the shard's device): for device-resident rows on several GPUs."""
+        h = self._L.asdr_shard(self._h, int(g))
+        if not h:
+            raise AsdrError("no such shard")
+        lo, hi = self.shard_range(g)
+        v = AudioSDRBatch(hi - lo, device=self._L.asdr_shard_device(self._h, int(g)), _handle=h, _owner=self)
+        return v
+
+    def shard_range(self, g):
+        return int(self._L.asdr_shard_first_channel(self._h, int(g))), int(self._L.asdr_shard_first_channel(self._h, int(g) + 1))
+
+    def set_host_chunks(self, chunks):
+        self._chk(self._L.asdr_set_host_chunks(self._h, int(chunks)))
+
+    def host_path_info(self):
+        out = (C.c_int * 2)()
+        self._chk(self._L.asdr_host_path_info(self._h, out))
+        return {"chunks": int(out[0]), "pinned": bool(out[1])}
+
+    def stream_pipeline_alloc_failures(self):
+        return int(self._L.asdr_stream_pipeline_alloc_failures(self._h))
+
+    def update_into(self, I, Q, out):
+        """asdr_update on caller-owned arrays (e.g. views of pinned memory from host_alloc): no allocation, no copy here."""
+        n_blocks = I.size // (self.n_channels * BLOCK)
+        p = C.POINTER(C.c_int16)
+        self._chk(self._L.asdr_update(self._h, I.ctypes.data_as(p), Q.ctypes.data_as(p), out.ctypes.data_as(p), n_blocks))
+        return out
 
     def __del__(self):
         try:
@@ -329,6 +391,29 @@ class AudioSDRBatch:
 
     def getAGClookup(self, i, ch=0):
         return float(self._L.asdr_getAGClookup(self._h, ch, int(i)))
+
+
+def host_alloc(shape, dtype=np.int16):
+    """A numpy array in page-locked host memory (asdr_host_alloc): asdr_update DMA-copies from / to it without staging.  Free it
+    with host_free(arr) when done (the array must not be used afterwards)."""
+    L = load_library()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = L.asdr_host_alloc(n)
+    if not p:
+        raise AsdrError("asdr_host_alloc failed: " + L.asdr_last_error().decode())
+    buf = (C.c_char * n).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    _PINNED[arr.__array_interface__["data"][0]] = p
+    return arr
+
+
+_PINNED = {}
+
+
+def host_free(arr):
+    p = _PINNED.pop(arr.__array_interface__["data"][0], None)
+    if p:
+        load_library().asdr_host_free(p)
 
 
 def _add_methods():

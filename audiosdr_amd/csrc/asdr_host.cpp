@@ -9,6 +9,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -120,6 +126,48 @@ float time_constant(float ms) {  // AudioSDR.cpp:448/553: exp(log(0.1) / (FS*ms/
 
 }  // namespace
 
+namespace {
+class CopyPool {   // a handful of threads that copy chunks between caller memory and the pinned staging area
+ public:
+  struct Job {
+    int n_chunks = 0;
+    std::function<void(int)> copy_in, copy_out;
+    std::vector<std::atomic<int>> in_done, out_ready;
+    std::atomic<int> next_in{0}, next_out{0}, out_finished{0}, workers_left{0};
+    explicit Job(int k) : n_chunks(k), in_done(k), out_ready(k) { for (int i = 0; i < k; i++) { in_done[i].store(0); out_ready[i].store(0); } }
+  };
+  explicit CopyPool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); }); }
+  ~CopyPool() { { std::lock_guard<std::mutex> g(m_); quit_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
+  int threads() const { return (int)th_.size(); }
+  void start(Job *j) { j->workers_left.store((int)th_.size()); { std::lock_guard<std::mutex> g(m_); job_ = j; gen_++; } cv_.notify_all(); }
+  static void work(Job *j) {
+    for (int k; (k = j->next_in.fetch_add(1)) < j->n_chunks;) { j->copy_in(k); j->in_done[k].store(1, std::memory_order_release); }
+    for (int k; (k = j->next_out.fetch_add(1)) < j->n_chunks;) {
+      while (!j->out_ready[k].load(std::memory_order_acquire)) std::this_thread::yield();
+      j->copy_out(k); j->out_finished.fetch_add(1, std::memory_order_release);
+    }
+  }
+ private:
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      Job *j;
+      { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return quit_ || gen_ != seen; }); if (quit_) return; seen = gen_; j = job_; }
+      work(j);
+      j->workers_left.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_; std::condition_variable cv_;
+  Job *job_ = nullptr; unsigned long gen_ = 0; bool quit_ = false;
+};
+
+// chunk plan of a host call: K channel ranges [bound[j], bound[j + 1]); kernel part p needs input chunks 0..need_in[p]; output chunk
+// j is complete after kernel part last_part[j]
+struct HostPlan { int K = 1; std::vector<int> bound, need_in, last_part; long sched_gen = -1; int n_blocks = 0; };
+
+}  // namespace
+
 #define ASDR_AUX_STREAMS (ASDR_KERNEL_KINDS + 1)   /* every sub-range but the first runs on a helper stream */
 struct asdr_batch {
   int n = 0, device = 0;
@@ -148,6 +196,7 @@ struct asdr_batch {
   bool kind_direct[ASDR_KERNEL_KINDS] = {};   // the uniform part is ONE key group of consecutive channel ids (checked when the schedule is built)
   // counters for the control-plane tests (ASDR_NO_DEVICE): what the last flush did
   long stat_rows_refilled = 0, stat_sched_rebuilds = 0, stat_bulk_uploads = 0;
+  int stat_lo_groups_without_entry = 0;   // settings groups that mix early but got none of the ASDR_LO_ENTRIES cache entries (the smallest ones)
   // device
   ChanParams *d_params = nullptr;
   ChanSmall *d_small = nullptr;
@@ -161,6 +210,20 @@ struct asdr_batch {
   SlotInfo *d_sched = nullptr;
   uint32_t *d_reset = nullptr;
   int16_t *d_io[3] = {nullptr, nullptr, nullptr};
+  // host-pointer path (asdr_update): pinned staging rows for pageable caller buffers, copy streams, per-chunk events, the chunk plan
+  int16_t *h_io[3] = {nullptr, nullptr, nullptr};
+  size_t h_io_cap = 0;
+  hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+  std::vector<hipEvent_t> ev_host;
+  HostPlan host_plan;
+  std::unique_ptr<CopyPool> copy_pool;
+  int host_chunks_forced = 0;            // asdr_set_host_chunks: 0 = chosen from the call's size
+  int stat_host_chunks = 0, stat_host_pinned = 0;   // what the last asdr_update did (asdr_host_path_info)
+  // A SHARDED batch (asdr_create_sharded) owns no channels itself: shard g holds channels [shard_first[g], shard_first[g + 1]) on
+  // its own device with its own state, schedule and streams; every entry point of the C ABI routes global channel indices to the
+  // owner (ASDR_ALL fans out), asdr_update scatters / gathers host rows with one host thread per shard, and there is no collective.
+  std::vector<asdr_batch *> shards;
+  std::vector<int> shard_first;
   int16_t *d_capture = nullptr;  // capture sink [n][capture_cap][128]
   long capture_cap = 0, capture_pos = 0;
   size_t io_cap = 0;
@@ -189,19 +252,22 @@ struct asdr_batch {
   bool sam_fused = false;           // SAM channels through the fused 4-wave kernel instead of the pre | PLL | post launches
   int sam_split_min = 512;          // ... which are chosen from this many SAM channels on
   bool stream_pipeline = true;      // small multi-block calls may run as the block pipeline (asdr_stream_kernel)
+  int stream_query_waves = 0;       // ... as the occupancy query of asdr_create answered (the debug hook cannot go beyond it)
   int stream_max_waves = 0;         // channel groups the pipeline may hold: 3 w + 1 workgroups must be co-resident, one per compute unit
   uint32_t stream_spin_limit = ASDR_STREAM_SPIN_LIMIT;
   void *d_stream_snap = nullptr;    // snapshot of the state a pipeline call advances (asdr_kernels.hip "the pipeline as a transaction")
   long stat_stream_recoveries = 0;  // pipeline calls that gave up and were re-run on the in-kernel block loop (read back at synchronisation points)
   bool sam_split = false;           // decided when the schedule is built (enough SAM channels, not sam_fused)
   int als_split_min = 0x7fffffff;   // channels with a short ALS filter (not SAM) run as chain | filter launches from this many on (default: never --
-                                    // measured: 2 % faster for C4's 131,072-channel share, 6 % slower at 1,048,576 channels, 3 % slower all-ALS)
+                                    // measured against the final fused kernel: 2 % slower for C4's 131,072-channel share, 12 % slower at 1,048,576
+                                    // channels, 9 % slower all-ALS; profiles/README.md "Round 3" is the one source of these numbers)
   bool als_split = false;           // decided when the schedule is built
   float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
   size_t xch_sam_slots = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode or AM: the modes the block pipeline has roles for (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   long stat_stream_launches = 0;
+  long stat_stream_alloc_failures = 0;   // the pipeline's buffers could not be allocated: the batch opted itself out (asdr_stream_pipeline_alloc_failures)
   uint32_t lo_parity = 0;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
   uint32_t als_phase = 0;        // blocks processed so far, mod 2 (position of every channel's ALS input ring)
@@ -209,6 +275,9 @@ struct asdr_batch {
 };
 
 namespace {
+
+int sharded_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks);
+inline bool is_sharded(const asdr_batch *b);
 
 uint64_t agc_hash(float thr, float slope, float knee) {
   uint32_t a, b2, c;
@@ -421,18 +490,34 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     b->sched.assign(pos, SlotInfo{b->n, b->hp[b->n].mode, b->hp[b->n].flags, 0u});   // padding = the dummy channel
     int at_u[ASDR_KERNEL_KINDS], at_m[ASDR_KERNEL_KINDS], at_left = b->left_first;
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) { at_u[k] = b->kind_first[k]; at_m[k] = b->kind_first[k] + uni[k]; }
-    // Local-oscillator cache: the settings groups with whole waves get an entry each, largest first come first served (the mixer's
-    // pairs are a function of (phase, increment); receivers of one group that were configured together share them for ever)
-    uint32_t lo_next = 0;
+    // Local-oscillator cache: the settings groups with whole waves get an entry each, THE LARGEST GROUPS FIRST when there are more
+    // groups than entries (the mixer's pairs are a function of (phase, increment); receivers of one group that were configured
+    // together share them for ever).  A group without an entry computes its own pairs: time only, never results.
+    std::unordered_map<uint64_t, uint32_t> lo_of_key;
+    {
+      std::vector<std::pair<int, uint64_t>> cand;   // (-whole slots, key)
+      for (int i = 0; i < b->n;) {
+        int j = i + 1;
+        while (j < b->n && order[j].first == order[i].first) j++;
+        const int k = (int)(order[i].first >> 60), g = j - i;
+        const int whole = (k == ASDR_KERNEL_SAM && sam_general_only) ? 0 : g / 8 * 8;
+        const uint32_t gm = b->hp[order[i].second].mode;
+        const bool mixes_early = (gm == ASDR_USBmode || gm == ASDR_LSBmode || gm == ASDR_CW_USBmode || gm == ASDR_CW_LSBmode || gm == ASDR_WSPRmode || gm == ASDR_AMmode);
+        if (whole > 0 && mixes_early) cand.push_back({-whole, order[i].first});
+        i = j;
+      }
+      std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, uint64_t> &x, const std::pair<int, uint64_t> &y) { return x.first < y.first; });
+      for (size_t e = 0; e < cand.size() && e < ASDR_LO_ENTRIES; e++) lo_of_key[cand[e].second] = (uint32_t)e + 1u;   // 1 + entry
+      b->stat_lo_groups_without_entry = cand.size() > ASDR_LO_ENTRIES ? (int)(cand.size() - ASDR_LO_ENTRIES) : 0;
+    }
     for (int i = 0; i < b->n;) {
       int j = i + 1;
       while (j < b->n && order[j].first == order[i].first) j++;
       const int k = (int)(order[i].first >> 60), g = j - i;
       const bool fused = (k == ASDR_KERNEL_SAM && sam_general_only);
       const int whole = fused ? 0 : g / 8 * 8;
-      const uint32_t gm = b->hp[order[i].second].mode;
-      const bool mixes_early = (gm == ASDR_USBmode || gm == ASDR_LSBmode || gm == ASDR_CW_USBmode || gm == ASDR_CW_LSBmode || gm == ASDR_WSPRmode || gm == ASDR_AMmode);
-      const uint32_t lo_id = (whole > 0 && mixes_early && lo_next < ASDR_LO_ENTRIES) ? ++lo_next : 0u;   // 1 + entry, 0 = none
+      const auto lo_it = lo_of_key.find(order[i].first);
+      const uint32_t lo_id = (whole > 0 && lo_it != lo_of_key.end()) ? lo_it->second : 0u;   // 1 + entry, 0 = none
       for (int t = 0; t < g; t++) {
         const int c = order[i + t].second;
         int &at = (t < whole) ? at_u[k] : (fused ? at_m[k] : at_left);
@@ -533,14 +618,38 @@ int apply_resets(asdr_batch *b, hipStream_t stream) {
   return 0;
 }
 
+// ---- sharded batches: routing of global channel indices ---------------------------------------------------------------------
+inline bool is_sharded(const asdr_batch *b) { return b && !b->shards.empty(); }
+// the shard that owns global channel `ch` (which becomes the shard-local index), or nullptr
+asdr_batch *shard_of(asdr_batch *b, int &ch) {
+  if (ch < 0 || ch >= b->n) return nullptr;
+  const std::vector<int> &f = b->shard_first;
+  int g = (int)(std::upper_bound(f.begin(), f.end(), ch) - f.begin()) - 1;
+  ch -= f[g];
+  return b->shards[g];
+}
+// Setters.  The lambdas of the entry points capture their `b` parameter by reference and `each` takes that same variable by
+// reference: for a sharded batch it is pointed at the owning shard (every shard in turn for ASDR_ALL) while `f` runs, so that the
+// per-batch helpers the lambdas call (chan_init, set_mode, mark_reset, rebuild_agc) work on the owner.
 template <typename F>
-void each(asdr_batch *b, int ch, F f) {
+void each(asdr_batch *&b, int ch, F f) {
   if (!b) return;
+  if (is_sharded(b)) {
+    asdr_batch *const parent = b;
+    if (ch == ASDR_ALL) { for (asdr_batch *sh : parent->shards) { b = sh; each(b, ASDR_ALL, f); } }
+    else { int local = ch; asdr_batch *sh = shard_of(parent, local); if (sh) { b = sh; each(b, local, f); } }
+    b = parent;
+    return;
+  }
   if (ch == ASDR_ALL) { for (int i = 0; i < b->n; i++) f(i, b->ch[i]); b->all_dirty = true; }
   else if (ch >= 0 && ch < b->n) { f(ch, b->ch[ch]); mark_dirty(b, ch); }
   else return;
 }
-const Chan *get(asdr_batch *b, int ch) { return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr; }
+// Getters: `b` is left pointing at the owner (the callers only read through it afterwards).
+const Chan *get(asdr_batch *&b, int ch) {
+  if (is_sharded(b)) { asdr_batch *sh = shard_of(b, ch); if (!sh) return nullptr; b = sh; }
+  return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr;
+}
 
 // The streaming pipeline's recovery counter (a wave gave up waiting for its neighbour role, the call was re-run on the in-kernel
 // block loop from the snapshot: asdr_kernels.hip "the pipeline as a transaction"): read back at the host's synchronisation points
@@ -558,6 +667,7 @@ int check_stream_error(asdr_batch *b) {
 
 int read_small(asdr_batch *b, int ch, ChanSmall &s) {
   if (!b || ch < 0 || ch >= b->n) return fail("bad channel");
+  if (is_sharded(b)) b = shard_of(b, ch);
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
@@ -569,6 +679,9 @@ int read_small(asdr_batch *b, int ch, ChanSmall &s) {
 }
 
 }  // namespace
+
+// a sharded batch: the same call on every shard, first failure wins
+#define FOR_SHARDS(b, call) do { if (is_sharded(b)) { for (asdr_batch *sh_ : (b)->shards) { const int rc_ = (call); if (rc_ != 0) return rc_; } return 0; } } while (0)
 
 extern "C" {
 
@@ -630,6 +743,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
       const int cap = asdr_stream_capacity(device, &cus);
       b->stream_max_waves = cap >= 3 ? cap / 3 : 0;
       if (b->stream_max_waves > ASDR_STREAM_MAX_WAVES) b->stream_max_waves = ASDR_STREAM_MAX_WAVES;
+      b->stream_query_waves = b->stream_max_waves;
     }
     if (!ok) { fail("device allocation / table upload failed"); asdr_destroy(b); return nullptr; }
   }
@@ -670,8 +784,41 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   return b;
 }
 
+asdr_batch_t *asdr_create_sharded(int n_channels, int n_shards, const int *devices) {
+  if (n_channels <= 0 || n_channels > (1 << 23)) { fail("n_channels must be in 1..8388608"); return nullptr; }
+  if (n_shards <= 0 || n_shards > 64 || n_shards > n_channels || !devices) { fail("n_shards must be in 1..min(64, n_channels), with one device ordinal per shard"); return nullptr; }
+  asdr_batch *b = new asdr_batch();
+  b->n = n_channels; b->device = ASDR_NO_DEVICE;
+  b->shard_first.resize((size_t)n_shards + 1);
+  for (int g = 0; g <= n_shards; g++) b->shard_first[g] = (int)(((long)n_channels * g) / n_shards);   // audiosdr_amd/sharding.py shard_range
+  for (int g = 0; g < n_shards; g++) {
+    asdr_batch *sh = asdr_create(b->shard_first[g + 1] - b->shard_first[g], devices[g]);
+    if (!sh) { const std::string e = g_err; asdr_destroy(b); fail("shard " + std::to_string(g) + ": " + e); return nullptr; }
+    b->shards.push_back(sh);
+  }
+  b->k = b->shards[0]->k;
+  return b;
+}
+int asdr_n_shards(const asdr_batch_t *b) { return b ? (is_sharded(b) ? (int)b->shards.size() : 1) : 0; }
+asdr_batch_t *asdr_shard(asdr_batch_t *b, int shard) {
+  if (!b) return nullptr;
+  if (!is_sharded(b)) return shard == 0 ? b : nullptr;
+  return (shard >= 0 && shard < (int)b->shards.size()) ? b->shards[shard] : nullptr;
+}
+int asdr_shard_first_channel(const asdr_batch_t *b, int shard) {
+  if (!b) return -1;
+  if (!is_sharded(b)) return shard == 0 ? 0 : (shard == 1 ? b->n : -1);
+  return (shard >= 0 && shard <= (int)b->shards.size()) ? b->shard_first[shard] : -1;   // shard == n_shards: the total
+}
+int asdr_shard_device(const asdr_batch_t *b, int shard) {
+  if (!b) return ASDR_NO_DEVICE;
+  if (!is_sharded(b)) return b->device;
+  return (shard >= 0 && shard < (int)b->shards.size()) ? b->shards[shard]->device : ASDR_NO_DEVICE;
+}
+
 void asdr_destroy(asdr_batch_t *b) {
   if (!b) return;
+  if (is_sharded(b) || !b->shard_first.empty()) { for (asdr_batch *sh : b->shards) asdr_destroy(sh); delete b; return; }
   if (b->device == ASDR_NO_DEVICE) { delete b; return; }
   hipSetDevice(b->device);
   hipDeviceSynchronize();
@@ -679,6 +826,11 @@ void asdr_destroy(asdr_batch_t *b) {
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
                   b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap};
   for (void *p : ptrs) if (p) hipFree(p);
+  b->copy_pool.reset();
+  for (int i = 0; i < 3; i++) if (b->h_io[i]) hipHostFree(b->h_io[i]);
+  for (hipEvent_t e : b->ev_host) hipEventDestroy(e);
+  if (b->h2d_stream) hipStreamDestroy(b->h2d_stream);
+  if (b->d2h_stream) hipStreamDestroy(b->d2h_stream);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -693,8 +845,14 @@ void asdr_destroy(asdr_batch_t *b) {
 
 int asdr_n_channels(const asdr_batch_t *b) { return b ? b->n : 0; }
 
-int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
-                               long in_stride_blocks, long out_stride_blocks, void *stream_) {
+}  // extern "C"
+// One call, or one PART of a call: with parts > 1 only the waves [w part / parts, w (part + 1) / parts) of every sub-range of the
+// schedule are launched, and the batch's block counters advance with the last part.  The parts of a call touch disjoint channels
+// (every schedule slot is launched exactly once) and are enqueued on one stream: the overlapped host-pointer path (asdr_update)
+// starts part p as soon as the input rows of ITS channels have arrived and copies a channel range out as soon as the parts that
+// hold its channels are done.
+static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
+                              long in_stride_blocks, long out_stride_blocks, void *stream_, int part, int parts) {
   if (!b) return fail("null batch");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the signal path needs a HIP device");
   if (!dI || !dQ) return 0;  // missing-input guard, AudioSDR.cpp:48-56
@@ -709,12 +867,14 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // read-modify-written by every launch)
   // (The event is recorded now, on the previous call's stream -- behind everything that call enqueued there -- rather than after
   // every call: one packet less per launch for the common single-stream caller.)
-  if (b->ev_last_valid && stream != b->last_stream) {
+  if (part == 0 && b->ev_last_valid && stream != b->last_stream) {
     HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
     HIPCHK(hipStreamWaitEvent(stream, b->ev_last, 0));
   }
-  if (flush(b, stream) != 0) return -1;
-  if (apply_resets(b, stream) != 0) return -1;
+  if (part == 0) {
+    if (flush(b, stream) != 0) return -1;
+    if (apply_resets(b, stream) != 0) return -1;
+  }
   UpdateArgs a;
   fill_args(b, a);
   a.in_i = dI; a.in_q = dQ; a.out = dOut; a.n_blocks = n_blocks;
@@ -722,8 +882,8 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // Timing markers are opt-in: every event record is a packet the GPU's command processor handles between two kernels
   // (tools/launch_gap.py: 0.134 ms per back-to-back C2 call with a pair per call, 0.127 ms without).
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
-  else if (b->time_calls) { e0 = b->ev0; e1 = b->ev1; }
+  if (parts == 1 && b->tev_used + 2 <= b->tev.size()) { e0 = b->tev[b->tev_used]; e1 = b->tev[b->tev_used + 1]; b->tev_used += 2; }
+  else if (b->time_calls) { e0 = b->ev0; e1 = b->ev1; }   // (around all parts of a call)
   // Up to seven sub-ranges of the sorted schedule (the whole waves of 5 kernel kinds, the fused SAM kernel's general waves, the remainders).  They touch disjoint channels,
   // so they run CONCURRENTLY: the first on the caller's stream, the others on the batch's helper streams, forked behind an
   // event and joined before the call's end marker -- launched back to back on one stream the short ones (a handful of waves of
@@ -766,13 +926,23 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   // the state in front of it, and behind it the launches that put the state back and run the call on the in-kernel block loop if a
   // role's bounded wait fired (asdr_kernels.hip).  3 w + 1 workgroups must be co-resident: w <= stream_max_waves (occupancy query at
   // asdr_create, at most one workgroup per compute unit).
-  if (b->stream_pipeline && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN && subs[0].uniform &&
-      b->plain_uniform_ssb &&
+  // The transaction restores channel STATE, not the caller's buffers: when the output rows alias an input row (the reference's own
+  // convention -- blockI is overwritten, AudioSDR.cpp:158-165) role 3 has overwritten input blocks by the time a wait runs out and the
+  // re-run would read them.  Such calls keep the in-kernel block loop, which is in-place safe.
+  bool io_alias = false;
+  {
+    const uintptr_t in_bytes = ((uintptr_t)(b->n - 1) * (uintptr_t)in_stride_blocks + (uintptr_t)n_blocks) * ASDR_N * sizeof(int16_t);
+    const uintptr_t out_bytes = ((uintptr_t)(b->n - 1) * (uintptr_t)out_stride_blocks + (uintptr_t)n_blocks) * ASDR_N * sizeof(int16_t);
+    const uintptr_t o0 = (uintptr_t)dOut, o1 = o0 + out_bytes;
+    for (uintptr_t i0 : {(uintptr_t)dI, (uintptr_t)dQ}) io_alias = io_alias || (o0 < i0 + in_bytes && i0 < o1);
+  }
+  bool take_pipeline = parts == 1 && b->stream_pipeline && !io_alias && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN &&
+                       subs[0].uniform && b->plain_uniform_ssb &&
 #ifndef ASDR_TIMELINE   /* (the profiling build writes its timestamps through the taps buffer: tools/timeline.py stream) */
-      !b->taps_on &&
+                       !b->taps_on &&
 #endif
-      subs[0].slots / 8 <= b->stream_max_waves) {
-    const int w = subs[0].slots / 8;
+                       subs[0].slots / 8 <= b->stream_max_waves;
+  if (take_pipeline) {
     if (!b->d_xch_a) {   // first use: every buffer, or none (a failed allocation leaves the batch on the other launch forms)
       float *xa = nullptr, *xb = nullptr; uint32_t *prog = nullptr; LoEntry *ring = nullptr; void *snap = nullptr;
       const size_t n_prog = (size_t)(3 * ((b->n + 7) / 8) + 3);   // [.. + 1] = the error word, [.. + 2] = the recovery counter
@@ -782,12 +952,17 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
                 hipMalloc(&ring, ASDR_LO_RING * sizeof(LoEntry)) == hipSuccess &&
                 hipMalloc(&snap, (size_t)(((b->n + 7) / 8) * 8) * ASDR_SNAP_BYTES) == hipSuccess &&
                 hipMemsetAsync(prog, 0, n_prog * sizeof(uint32_t), stream) == hipSuccess;
-      if (!ok) {
+      if (!ok) {   // the batch stays on the other launch forms (asdr_stream_pipeline_alloc_failures() counts this)
         for (void *p : {(void *)xa, (void *)xb, (void *)prog, (void *)ring, snap}) if (p) hipFree(p);
-        return fail("streaming pipeline: out of device memory for its exchange rings");
+        (void)hipGetLastError();
+        b->stream_pipeline = false; b->stat_stream_alloc_failures++; take_pipeline = false;
+      } else {
+        b->d_xch_a = xa; b->d_xch_b = xb; b->d_stream_prog = prog; b->d_lo_ring = ring; b->d_stream_snap = snap;
       }
-      b->d_xch_a = xa; b->d_xch_b = xb; b->d_stream_prog = prog; b->d_lo_ring = ring; b->d_stream_snap = snap;
     }
+  }
+  if (take_pipeline) {
+    const int w = subs[0].slots / 8;
     HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));   // stream-ordered behind the previous launch
     a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
     a.direct_ch0 = -1;
@@ -823,7 +998,15 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   for (int i = 1; i < n_sub; i++) if (subs[i].slots > subs[main_sub].slots) main_sub = i;
   const int n_launch = per_block ? n_blocks : 1;
   float *const taps = a.taps;
-  if (e0) HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
+  if (e0 && part == 0) HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
+  // this part's waves of every sub-range
+  int part_lo[ASDR_KERNEL_KINDS + 2], part_n[ASDR_KERNEL_KINDS + 2], n_live = 0;
+  for (int i = 0; i < n_sub; i++) {
+    const long w = subs[i].slots / 8;
+    part_lo[i] = (int)(w * part / parts) * 8; part_n[i] = (int)(w * (part + 1) / parts) * 8 - part_lo[i];
+    n_live += part_n[i] > 0;
+  }
+  if (part_n[main_sub] == 0) for (int i = 0; i < n_sub; i++) if (part_n[i] > part_n[main_sub]) main_sub = i;
   for (int lb = 0; lb < n_launch; lb++) {
     if (per_block) {
       a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
@@ -832,27 +1015,32 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
       a.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
       a.taps = (lb == n_launch - 1) ? taps : nullptr;   // the taps are those of the call's last block
     }
-    if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
-    for (int i = 0, n_aux = 0; i < n_sub; i++) {
+    if (n_live > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
+    int n_aux = 0;
+    for (int i = 0; i < n_sub; i++) {
+      if (part_n[i] == 0) continue;
+      const int first = subs[i].first + part_lo[i];
       hipStream_t s = (i == main_sub) ? stream : b->aux[n_aux++];
       if (i != main_sub) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
-      a.sched = b->d_sched + subs[i].first; a.n_sched = subs[i].slots;
+      a.sched = b->d_sched + first; a.n_sched = part_n[i];
       a.direct_ch0 = -1;
+      a.lo_write = 1u;   // the first wave of every settings group fills the group's entry of the other half of the local-oscillator cache
       if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
         const SlotInfo &s0 = b->sched[subs[i].first];
-        a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo;
+        a.direct_ch0 = s0.ch + part_lo[i]; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo;
+        if (part_lo[i] > 0) a.lo_write = 0u;   // (a direct launch's wave 0 is the writer: only the part that holds the group's first wave)
       }
-      a.lo_write = 1u;   // the first wave of every settings group fills the group's entry of the other half of the local-oscillator cache
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM)   // this sub-range's tiles (1 KB per slot, 8 slots per tile)
-        a.xch_sam = b->d_xch_sam + (size_t)(subs[i].first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
+        a.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM_ALS)   // ... behind those of the SAM kind
-        a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + subs[i].first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
+        a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
       const int form = (als_split && subs[i].kind == ASDR_KERNEL_ALS_SMALL && subs[i].uniform) ? 2 : subs[i].uniform;
       if (asdr_launch_update(&a, subs[i].kind, form, s) != 0) return fail("update kernel launch failed");
       if (i != main_sub) HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
     }
-    for (int j = 0; j + 1 < n_sub; j++) HIPCHK(hipStreamWaitEvent(stream, b->ev_join[j], 0));   // behind the caller's stream's own launch
+    for (int j = 0; j < n_aux; j++) HIPCHK(hipStreamWaitEvent(stream, b->ev_join[j], 0));   // behind the caller's stream's own launch
   }
+  if (part + 1 < parts) return 0;   // the block counters advance with the call's last part
   if (e1) HIPCHK(hipEventRecord(e1, stream));
   b->ev_last_valid = true;
   b->ev_valid = (e0 != nullptr && e0 == b->ev0);
@@ -864,6 +1052,27 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
   return 0;
 }
 
+extern "C" {
+int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
+                               long in_stride_blocks, long out_stride_blocks, void *stream_) {
+  if (is_sharded(b)) {
+    // Device pointers belong to ONE device: a sharded batch takes them here only while all its shards live on that device (shards
+    // as independent sub-batches of one GPU: tests, or several schedules side by side); shard g then works on its rows of the
+    // caller's arrays.  Shards on several devices are driven through asdr_update (host rows) or shard by shard: asdr_shard().
+    if (!dI || !dQ) return 0;
+    if (!dOut) return fail("null output");
+    for (asdr_batch *sh : b->shards) if (sh->device != b->shards[0]->device || sh->device == ASDR_NO_DEVICE)
+      return fail("sharded batch over several devices: device pointers go to the shards (asdr_shard), host rows to asdr_update");
+    for (size_t g = 0; g < b->shards.size(); g++) {
+      const size_t f = (size_t)b->shard_first[g];
+      if (update_device_part(b->shards[g], dI + f * (size_t)in_stride_blocks * ASDR_N, dQ + f * (size_t)in_stride_blocks * ASDR_N,
+                             dOut + f * (size_t)out_stride_blocks * ASDR_N, n_blocks, in_stride_blocks, out_stride_blocks, stream_, 0, 1) != 0) return -1;
+    }
+    return 0;
+  }
+  return update_device_part(b, dI, dQ, dOut, n_blocks, in_stride_blocks, out_stride_blocks, stream_, 0, 1);
+}
+
 int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks, void *stream_) {
   return asdr_update_device_strided(b, dI, dQ, dOut, n_blocks, n_blocks, n_blocks, stream_);
 }
@@ -871,6 +1080,7 @@ int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, in
 // ---- capture sink: each channel's audio appended to one contiguous HBM row ---------------
 int asdr_capture_open(asdr_batch_t *b, long capacity_blocks) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_capture_open(sh_, capacity_blocks));   // one sink per shard, on the shard's device
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the capture sink lives in HBM");
   if (capacity_blocks <= 0 || capacity_blocks > 0x7fffffffL) return fail("bad capture capacity");
   HIPCHK(hipSetDevice(b->device));
@@ -883,18 +1093,29 @@ int asdr_capture_open(asdr_batch_t *b, long capacity_blocks) {
 
 int asdr_capture_close(asdr_batch_t *b) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_capture_close(sh_));
   if (b->d_capture) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b->d_capture)); }
   b->d_capture = nullptr; b->capture_cap = 0; b->capture_pos = 0;
   return 0;
 }
 
-long asdr_capture_capacity(const asdr_batch_t *b) { return b ? b->capture_cap : 0; }
-long asdr_capture_position(const asdr_batch_t *b) { return b ? b->capture_pos : 0; }
-int16_t *asdr_capture_device_ptr(asdr_batch_t *b) { return b ? b->d_capture : nullptr; }
-int asdr_capture_rewind(asdr_batch_t *b) { if (!b) return fail("null batch"); b->capture_pos = 0; return 0; }
+long asdr_capture_capacity(const asdr_batch_t *b) { return b ? (is_sharded(b) ? b->shards[0]->capture_cap : b->capture_cap) : 0; }
+long asdr_capture_position(const asdr_batch_t *b) { return b ? (is_sharded(b) ? b->shards[0]->capture_pos : b->capture_pos) : 0; }
+int16_t *asdr_capture_device_ptr(asdr_batch_t *b) { return (b && !is_sharded(b)) ? b->d_capture : nullptr; }   // sharded: per shard, asdr_shard()
+int asdr_capture_rewind(asdr_batch_t *b) { if (!b) return fail("null batch"); FOR_SHARDS(b, asdr_capture_rewind(sh_)); b->capture_pos = 0; return 0; }
 
 int asdr_capture_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int n_blocks, long in_stride_blocks, void *stream) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) {   // as asdr_update_device_strided: device pointers serve a sharded batch only while its shards share the device
+    if (!dI || !dQ) return 0;
+    for (asdr_batch *sh : b->shards) if (sh->device != b->shards[0]->device || sh->device == ASDR_NO_DEVICE)
+      return fail("sharded batch over several devices: device pointers go to the shards (asdr_shard)");
+    for (size_t g = 0; g < b->shards.size(); g++) {
+      const size_t f = (size_t)b->shard_first[g] * (size_t)in_stride_blocks * ASDR_N;
+      if (asdr_capture_update_device(b->shards[g], dI + f, dQ + f, n_blocks, in_stride_blocks, stream) != 0) return -1;
+    }
+    return 0;
+  }
   if (!b->d_capture) return fail("capture sink is not open");
   if (!dI || !dQ) return 0;   // missing input: nothing is transmitted, nothing is appended (AudioSDR.cpp:48-56)
   if (n_blocks <= 0) return 0;
@@ -907,6 +1128,7 @@ int asdr_capture_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t
 
 int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, int16_t *host_out) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) { asdr_batch *sh = shard_of(b, ch); if (!sh) return fail("bad channel"); return asdr_capture_read(sh, ch, first_block, n_blocks, host_out); }
   if (!b->d_capture) return fail("capture sink is not open");
   if (ch < 0 || ch >= b->n) return fail("bad channel");
   if (first_block < 0 || n_blocks < 0 || first_block + n_blocks > b->capture_pos) return fail("capture read beyond the write position");
@@ -919,12 +1141,65 @@ int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, 
   return 0;
 }
 
-int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
-  if (!b) return fail("null batch");
-  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the signal path needs a HIP device");
-  if (!I || !Q) return 0;
-  if (!out) return fail("null output");
-  if (n_blocks <= 0) return 0;
+}  // extern "C"
+// ---- the host-pointer entry point: overlapped ------------------------------------------------------------------------------
+// asdr_update() replaces N x update() fed from host-resident audio blocks (AudioSDR.cpp:46-47 receiveWritable, :158-167 transmit):
+// 768 bytes cross PCIe per channel-block (512 in, 256 out) and that, not the kernels, bounds the call -- 50 MB against 0.13 ms of
+// kernel time for BASELINE config 2.  Round 3 ran H2D -> kernels -> D2H serially out of pageable memory.  Now the batch is cut into
+// CHANNEL-RANGE chunks (state order within a channel is untouched) and three streams work on three chunks at once:
+//     H2D(k + 1)  ||  kernels(k)  ||  D2H(k - 1)            (PCIe is full duplex: the two copy directions overlap too)
+// The kernels of a call are launched as `parts` of every schedule sub-range (update_device_part); which part needs which input chunk,
+// and which output chunk is complete after which part, is read off the host's copy of the schedule, so any settings mix is correct
+// and a batch of one settings group (or of groups interleaved over the channel range) pipelines perfectly.
+// Caller buffers that are pinned (asdr_host_alloc / asdr_host_register, or any hipHostMalloc'ed / registered memory) are DMA targets
+// as they are; pageable buffers go through the batch's pinned staging area, copied by a few worker threads per chunk.
+namespace {
+
+bool is_pinned_host(const void *p) {   // registered / hipHostMalloc'ed memory the DMA engines can address as it is
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof at);
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // ordinary pageable memory is an error here
+  return at.type == hipMemoryTypeHost;
+}
+
+int host_parts(const asdr_batch *b, int n_blocks) {
+  if (b->host_chunks_forced > 0) return std::min(b->host_chunks_forced, std::max(1, b->n / 8));
+  const size_t row_bytes = (size_t)b->n * n_blocks * ASDR_N * sizeof(int16_t);   // one of I, Q, out
+  long k = (long)(row_bytes / ((size_t)2 << 20));                              // about 2 MB of I per chunk ...
+  k = std::min<long>(k, b->n / 2048);                                          // ... and at least 256 waves per part
+  return (int)std::max<long>(1, std::min<long>(k, 16));
+}
+
+void build_host_plan(asdr_batch *b, HostPlan &hp, int K) {
+  hp.K = K; hp.sched_gen = b->stat_sched_rebuilds;
+  hp.bound.resize(K + 1);
+  for (int j = 0; j <= K; j++) hp.bound[j] = (int)((long)b->n * j / K);
+  hp.need_in.assign(K, 0); hp.last_part.assign(K, 0);
+  auto chunk_of = [&](int ch) { int j = (int)((long)ch * K / b->n); while (j + 1 < K && ch >= hp.bound[j + 1]) j++; while (j > 0 && ch < hp.bound[j]) j--; return j; };
+  auto sub = [&](int first, int slots) {
+    const long w = slots / 8;
+    for (int p = 0; p < K; p++) {
+      const int lo = first + (int)(w * p / K) * 8, hi = first + (int)(w * (p + 1) / K) * 8;
+      for (int sl = lo; sl < hi; sl++) {
+        const int ch = b->sched[sl].ch;
+        if (ch >= b->n) continue;   // padding
+        const int j = chunk_of(ch);
+        if (j > hp.need_in[p]) hp.need_in[p] = j;
+        if (p > hp.last_part[j]) hp.last_part[j] = p;
+      }
+    }
+  };
+  // the same sub-ranges update_device_part launches (uniform and general part of every kernel kind, the remainders)
+  if (b->left_slots > 0) sub(b->left_first, b->left_slots);
+  for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
+    const int nu = b->kind_uniform_slots[k], nm = b->kind_slots[k] - nu;
+    if (nu > 0) sub(b->kind_first[k], nu);
+    if (nm > 0) sub(b->kind_first[k] + nu, nm);
+  }
+  for (int p = 1; p < K; p++) hp.need_in[p] = std::max(hp.need_in[p], hp.need_in[p - 1]);   // parts are enqueued in order on one stream
+}
+
+int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
   HIPCHK(hipSetDevice(b->device));
   const size_t count = (size_t)b->n * n_blocks * ASDR_N;
   if (count > b->io_cap) {
@@ -936,16 +1211,165 @@ int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *ou
     }
     b->io_cap = count;
   }
-  HIPCHK(hipMemcpyAsync(b->d_io[0], I, count * sizeof(int16_t), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_io[1], Q, count * sizeof(int16_t), hipMemcpyHostToDevice, b->stream));
-  if (asdr_update_device(b, b->d_io[0], b->d_io[1], b->d_io[2], n_blocks, b->stream) != 0) return -1;
-  HIPCHK(hipMemcpyAsync(out, b->d_io[2], count * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+  const bool pinned = is_pinned_host(I) && is_pinned_host(Q) && is_pinned_host(out);
+  if (!pinned && count > b->h_io_cap) {   // the pinned staging area, one row set per call
+    for (int i = 0; i < 3; i++) {
+      if (b->h_io[i]) HIPCHK(hipHostFree(b->h_io[i]));
+      b->h_io[i] = nullptr;
+      HIPCHK(hipHostMalloc((void **)&b->h_io[i], count * sizeof(int16_t), hipHostMallocPortable));
+    }
+    b->h_io_cap = count;
+  }
+  if (!b->h2d_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&b->h2d_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&b->d2h_stream, hipStreamNonBlocking));
+  }
+  // the schedule must exist before the plan can be read off it
+  if (b->ev_last_valid && b->stream != b->last_stream) {
+    HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
+    HIPCHK(hipStreamWaitEvent(b->stream, b->ev_last, 0));
+    b->last_stream = b->stream;
+  }
+  if (flush(b, b->stream) != 0) return -1;
+  const int K = host_parts(b, n_blocks);
+  HostPlan &hp = b->host_plan;
+  if (hp.K != K || hp.sched_gen != b->stat_sched_rebuilds || (int)hp.bound.size() != K + 1) build_host_plan(b, hp, K);
+  while ((int)b->ev_host.size() < 3 * K) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); b->ev_host.push_back(e); }
+  hipEvent_t *ev_in = b->ev_host.data(), *ev_k = ev_in + K, *ev_out = ev_k + K;
+  const size_t row = (size_t)n_blocks * ASDR_N;   // samples per channel row
+  const int16_t *srcI = pinned ? I : b->h_io[0], *srcQ = pinned ? Q : b->h_io[1];
+  int16_t *dstO = pinned ? out : b->h_io[2];
+  std::unique_ptr<CopyPool::Job> job;
+  if (!pinned) {
+    if (!b->copy_pool) {
+      const char *e = getenv("ASDR_HOST_COPY_THREADS");
+      int nt = e ? atoi(e) : 4;
+      b->copy_pool.reset(new CopyPool(std::max(1, std::min(nt, 32))));
+    }
+    job.reset(new CopyPool::Job(K));
+    job->copy_in = [=, &hp](int j) {
+      const size_t o = (size_t)hp.bound[j] * row, nsm = (size_t)(hp.bound[j + 1] - hp.bound[j]) * row;
+      memcpy(b->h_io[0] + o, I + o, nsm * sizeof(int16_t)); memcpy(b->h_io[1] + o, Q + o, nsm * sizeof(int16_t));
+    };
+    job->copy_out = [=, &hp](int j) {
+      const size_t o = (size_t)hp.bound[j] * row, nsm = (size_t)(hp.bound[j + 1] - hp.bound[j]) * row;
+      memcpy(out + o, b->h_io[2] + o, nsm * sizeof(int16_t));
+    };
+    b->copy_pool->start(job.get());
+  }
+  // The workers must be through with the job before this frame (and the job) goes away, also on an error path.
+  struct JobGuard {
+    CopyPool::Job *j;
+    ~JobGuard() {
+      if (!j) return;
+      for (int k = 0; k < j->n_chunks; k++) j->out_ready[k].store(1, std::memory_order_release);
+      while (j->workers_left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+  } guard{job.get()};
+  int rc = 0;
+  int next_part = 0, next_out = 0;
+  for (int j = 0; j < K && rc == 0; j++) {
+    const size_t o = (size_t)hp.bound[j] * row, nsm = (size_t)(hp.bound[j + 1] - hp.bound[j]) * row;
+    if (job) while (!job->in_done[j].load(std::memory_order_acquire)) std::this_thread::yield();
+    HIPCHK(hipMemcpyAsync(b->d_io[0] + o, srcI + o, nsm * sizeof(int16_t), hipMemcpyHostToDevice, b->h2d_stream));
+    HIPCHK(hipMemcpyAsync(b->d_io[1] + o, srcQ + o, nsm * sizeof(int16_t), hipMemcpyHostToDevice, b->h2d_stream));
+    HIPCHK(hipEventRecord(ev_in[j], b->h2d_stream));
+    // every kernel part whose channels have now arrived
+    for (; next_part < K && hp.need_in[next_part] <= j; next_part++) {
+      HIPCHK(hipStreamWaitEvent(b->stream, ev_in[hp.need_in[next_part]], 0));
+      if (update_device_part(b, b->d_io[0], b->d_io[1], b->d_io[2], n_blocks, n_blocks, n_blocks, b->stream, next_part, K) != 0) { rc = -1; break; }
+      HIPCHK(hipEventRecord(ev_k[next_part], b->stream));
+    }
+    // ... and every output chunk whose channels are all behind an enqueued part
+    for (; rc == 0 && next_out < K && hp.last_part[next_out] < next_part; next_out++) {
+      const size_t oo = (size_t)hp.bound[next_out] * row, no = (size_t)(hp.bound[next_out + 1] - hp.bound[next_out]) * row;
+      HIPCHK(hipStreamWaitEvent(b->d2h_stream, ev_k[hp.last_part[next_out]], 0));
+      HIPCHK(hipMemcpyAsync(dstO + oo, b->d_io[2] + oo, no * sizeof(int16_t), hipMemcpyDeviceToHost, b->d2h_stream));
+      HIPCHK(hipEventRecord(ev_out[next_out], b->d2h_stream));
+    }
+  }
+  if (rc != 0) return -1;
+  if (next_part != K || next_out != K) return fail("host path: internal error (a part or an output chunk was never enqueued)");
+  for (int j = 0; j < K; j++) {
+    HIPCHK(hipEventSynchronize(ev_out[j]));
+    if (job) job->out_ready[j].store(1, std::memory_order_release);
+  }
+  if (job) while (job->out_finished.load(std::memory_order_acquire) < K) std::this_thread::yield();
   HIPCHK(hipStreamSynchronize(b->stream));
+  b->stat_host_chunks = K; b->stat_host_pinned = pinned ? 1 : 0;
   return check_stream_error(b);
+}
+
+// asdr_update on a sharded batch: shard g's rows [shard_first[g], shard_first[g + 1]) of I, Q and out go through shard g's own
+// overlapped host path on its own device, one host thread per shard (the caller's thread takes shard 0); no collective, nothing
+// crosses between devices.  Errors of the worker threads come back as the call's error text.
+int sharded_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
+  if (!I || !Q) return 0;   // missing-input guard, AudioSDR.cpp:48-56
+  if (!out) return fail("null output");
+  if (n_blocks <= 0) return 0;
+  const size_t G = b->shards.size();
+  const size_t row = (size_t)n_blocks * ASDR_N;
+  std::vector<int> rc(G, 0);
+  std::vector<std::string> err(G);
+  auto run = [&](size_t g) {
+    const size_t o = (size_t)b->shard_first[g] * row;
+    rc[g] = asdr_update(b->shards[g], I + o, Q + o, out + o, n_blocks);
+    if (rc[g] != 0) err[g] = g_err;   // (thread-local: copied out for the caller's thread)
+  };
+  std::vector<std::thread> th;
+  for (size_t g = 1; g < G; g++) th.emplace_back(run, g);
+  run(0);
+  for (std::thread &t : th) t.join();
+  for (size_t g = 0; g < G; g++) if (rc[g] != 0) return fail("shard " + std::to_string(g) + ": " + err[g]);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
+  if (!b) return fail("null batch");
+  if (is_sharded(b)) return sharded_update(b, I, Q, out, n_blocks);
+  if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch (ASDR_NO_DEVICE): the signal path needs a HIP device");
+  if (!I || !Q) return 0;   // missing-input guard, AudioSDR.cpp:48-56
+  if (!out) return fail("null output");
+  if (n_blocks <= 0) return 0;
+  return host_update(b, I, Q, out, n_blocks);
+}
+
+void *asdr_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); fail("asdr_host_alloc: hipHostMalloc failed"); return nullptr; }
+  return p;
+}
+void asdr_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int asdr_host_register(void *p, size_t bytes) {
+  if (!p || !bytes) return fail("asdr_host_register: null buffer");
+  HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+  return 0;
+}
+int asdr_host_unregister(void *p) {
+  if (!p) return fail("asdr_host_unregister: null buffer");
+  HIPCHK(hipHostUnregister(p));
+  return 0;
+}
+int asdr_set_host_chunks(asdr_batch_t *b, int chunks) {
+  if (!b) return fail("null batch");
+  if (chunks < 0 || chunks > 4096) return fail("bad chunk count");
+  if (is_sharded(b)) { for (asdr_batch *s : b->shards) s->host_chunks_forced = chunks; return 0; }
+  b->host_chunks_forced = chunks;
+  return 0;
+}
+int asdr_host_path_info(asdr_batch_t *b, int out[2]) {
+  if (!b || !out) return fail("null argument");
+  const asdr_batch *s = is_sharded(b) ? b->shards[0] : b;
+  out[0] = s->stat_host_chunks; out[1] = s->stat_host_pinned;
+  return 0;
 }
 
 int asdr_synchronize(asdr_batch_t *b) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_synchronize(sh_));
   if (b->device == ASDR_NO_DEVICE) return 0;
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
@@ -954,6 +1378,7 @@ int asdr_synchronize(asdr_batch_t *b) {
 }
 
 float asdr_last_kernel_ms(asdr_batch_t *b) {
+  if (is_sharded(b)) { float mx = -1.0f; for (asdr_batch *sh : b->shards) mx = std::max(mx, asdr_last_kernel_ms(sh)); return mx; }   // the slowest shard
   if (!b || !b->ev_valid) return -1.0f;
   float ms = -1.0f;
   if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0f;
@@ -963,6 +1388,7 @@ float asdr_last_kernel_ms(asdr_batch_t *b) {
 
 int asdr_set_launch_timing(asdr_batch_t *b, int on) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_set_launch_timing(sh_, on));
   b->time_calls = on != 0;
   if (!on) b->ev_valid = false;
   return 0;
@@ -970,6 +1396,7 @@ int asdr_set_launch_timing(asdr_batch_t *b, int on) {
 
 int asdr_region_timing_begin(asdr_batch_t *b, void *stream_) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) return fail("region timing is per device: use the shard handles (asdr_shard)");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   b->region_stream = (hipStream_t)stream_;
@@ -980,6 +1407,7 @@ int asdr_region_timing_begin(asdr_batch_t *b, void *stream_) {
 
 int asdr_region_timing_end(asdr_batch_t *b, float *ms_total, long *n_calls) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) return fail("region timing is per device: use the shard handles (asdr_shard)");
   if (b->region_calls < 0) return fail("asdr_region_timing_end without asdr_region_timing_begin");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipEventRecord(b->rev1, b->region_stream));
@@ -994,6 +1422,7 @@ int asdr_region_timing_end(asdr_batch_t *b, float *ms_total, long *n_calls) {
 
 int asdr_kernel_timing_begin(asdr_batch_t *b, int max_launches) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) return fail("kernel timing is per device: use the shard handles (asdr_shard)");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
@@ -1004,6 +1433,7 @@ int asdr_kernel_timing_begin(asdr_batch_t *b, int max_launches) {
 
 int asdr_kernel_timing_end(asdr_batch_t *b, float *ms, int cap) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) return fail("kernel timing is per device: use the shard handles (asdr_shard)");
   const int n = (int)(b->tev_used / 2);
   for (int i = 0; i < n && i < cap; i++) {
     HIPCHK(hipEventSynchronize(b->tev[2 * i + 1]));
@@ -1164,6 +1594,14 @@ float asdr_getAMcarrierLevel(asdr_batch_t *b, int ch) { ChanSmall s; return read
 int asdr_read_status(asdr_batch_t *b, int32_t *agc_active, int32_t *nb_detected, int32_t *sam_locked, float *sam_frequency,
                      float *am_carrier) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) {   // every shard fills its channel range of the caller's arrays
+    for (size_t g = 0; g < b->shards.size(); g++) {
+      const int f = b->shard_first[g];
+      if (asdr_read_status(b->shards[g], agc_active ? agc_active + f : nullptr, nb_detected ? nb_detected + f : nullptr, sam_locked ? sam_locked + f : nullptr,
+                           sam_frequency ? sam_frequency + f : nullptr, am_carrier ? am_carrier + f : nullptr) != 0) return -1;
+    }
+    return 0;
+  }
   ChanSmall probe;
   if (read_small(b, 0, probe) != 0) return -1;  // synchronises + applies pending resets
   std::vector<ChanSmall> all(b->n);
@@ -1190,41 +1628,60 @@ unsigned int asdr_get_chain_constants(asdr_batch_t *b, int ch, float out[12]) {
   return c ? c->agc_hang_count : 0u;
 }
 
-long asdr_stream_pipeline_launches(asdr_batch_t *b) { return b ? b->stat_stream_launches : -1; }
+long asdr_stream_pipeline_launches(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_stream_launches; return t; }
+  return b ? b->stat_stream_launches : -1;
+}
 long asdr_stream_pipeline_recoveries(asdr_batch_t *b) {
   if (!b) return -1;
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) { const long r = asdr_stream_pipeline_recoveries(sh); if (r < 0) return -1; t += r; } return t; }
   if (b->device != ASDR_NO_DEVICE && b->stream_launched) { if (hipSetDevice(b->device) != hipSuccess || check_stream_error(b) != 0) return -1; }
   return b->stat_stream_recoveries;
 }
-int asdr_stream_pipeline_max_groups(asdr_batch_t *b) { return b ? b->stream_max_waves : -1; }
-int asdr_set_stream_pipeline(asdr_batch_t *b, int on) { if (!b) return fail("null batch"); b->stream_pipeline = on != 0; return 0; }
+long asdr_stream_pipeline_alloc_failures(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_stream_alloc_failures; return t; }
+  return b ? b->stat_stream_alloc_failures : -1;
+}
+int asdr_stream_pipeline_max_groups(asdr_batch_t *b) {   // (per shard: every shard is a launch of its own)
+  if (is_sharded(b)) { int m = 0x7fffffff; for (asdr_batch *sh : b->shards) m = std::min(m, sh->stream_max_waves); return m; }
+  return b ? b->stream_max_waves : -1;
+}
+int asdr_set_stream_pipeline(asdr_batch_t *b, int on) { if (!b) return fail("null batch"); FOR_SHARDS(b, asdr_set_stream_pipeline(sh_, on)); b->stream_pipeline = on != 0; return 0; }
 int asdr_set_als_launch_form(asdr_batch_t *b, int split_min_channels) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_set_als_launch_form(sh_, split_min_channels));
   b->als_split_min = split_min_channels > 0 ? split_min_channels : 0x7fffffff;
   b->sched_dirty = true;
   return 0;
 }
 int asdr_set_sam_launch_form(asdr_batch_t *b, int fused, int split_min_channels) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_set_sam_launch_form(sh_, fused, split_min_channels));
   b->sam_fused = fused != 0;
   b->sam_split_min = split_min_channels > 0 ? split_min_channels : ASDR_SAM_SPLIT_MIN_CHANNELS;
   b->sched_dirty = true;
   return 0;
 }
-int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups) {   // experiments: more than one pipeline workgroup per compute unit
+int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups) {
   if (!b) return fail("null batch");
-  if (groups < 0 || groups > 1024) return fail("bad group count");
+  FOR_SHARDS(b, asdr_debug_set_stream_max_groups(sh_, groups));
+  if (groups < 0 || groups > ASDR_STREAM_MAX_WAVES) return fail("bad group count");
+  // never beyond what the device holds at once (the occupancy query of asdr_create): more groups than resident workgroups cannot
+  // make progress and every call would sit out its 2^18 polls before the recovery launches run
+  if (b->stream_query_waves > 0 && groups > b->stream_query_waves) groups = b->stream_query_waves;
   b->stream_max_waves = groups;
   return 0;
 }
 int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_debug_set_stream_spin_limit(sh_, polls));
   b->stream_spin_limit = polls ? polls : ASDR_STREAM_SPIN_LIMIT;
   return 0;
 }
 
 int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_set_exact_unknown_mode(sh_, on));
   const bool want = on != 0;
   if (want && !b->exact_unknown_mode && b->device != ASDR_NO_DEVICE) {   // rows not kept meanwhile: silence until a block stores them again
     HIPCHK(hipSetDevice(b->device));
@@ -1234,10 +1691,21 @@ int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on) {
   b->exact_unknown_mode = want;
   return 0;
 }
-int asdr_get_exact_unknown_mode(asdr_batch_t *b) { return b ? (b->exact_unknown_mode ? 1 : 0) : -1; }
+int asdr_get_exact_unknown_mode(asdr_batch_t *b) { if (is_sharded(b)) b = b->shards[0]; return b ? (b->exact_unknown_mode ? 1 : 0) : -1; }
 
 int asdr_schedule_layout(asdr_batch_t *b, int out[8]) {
   if (!b || !out) return fail("null argument");
+  if (is_sharded(b)) {   // slots summed over the shards (each shard pads its own sub-ranges); kinds / launch forms: any shard's
+    int acc[8] = {0, 0, 0, 0, 0, 0, -1, 0};
+    for (asdr_batch *sh : b->shards) {
+      int o[8];
+      if (asdr_schedule_layout(sh, o) != 0) return -1;
+      for (int k = 0; k < 6; k++) acc[k] += o[k];
+      acc[6] = std::max(acc[6], o[6]); acc[7] |= o[7];
+    }
+    memcpy(out, acc, sizeof acc);
+    return 0;
+  }
   for (int k = 0; k < ASDR_KERNEL_KINDS; k++) out[k] = b->kind_slots[k];
   out[5] = b->left_slots; out[6] = b->left_slots ? b->left_kind : -1; out[7] = (b->sam_split ? 1 : 0) | (b->als_split ? 2 : 0);
   return 0;
@@ -1245,6 +1713,16 @@ int asdr_schedule_layout(asdr_batch_t *b, int out[8]) {
 
 int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
   if (!b) return fail("null batch");
+  if (is_sharded(b)) {   // rows refilled / waves / live tables summed over the shards, "rebuilt" if any shard rebuilt
+    long long acc[4] = {0, 0, 0, 0};
+    for (asdr_batch *sh : b->shards) {
+      long long st[4];
+      if (asdr_control_plane_flush(sh, st) != 0) return -1;
+      acc[0] += st[0]; acc[1] |= st[1]; acc[2] += st[2]; acc[3] += st[3];
+    }
+    if (stats) memcpy(stats, acc, sizeof acc);
+    return 0;
+  }
   if (b->device != ASDR_NO_DEVICE) return fail("asdr_control_plane_flush is for control-plane-only batches: a device batch flushes in update()");
   std::vector<int32_t> changed;
   bool bulk = false, rebuilt = false;
@@ -1264,6 +1742,7 @@ int asdr_control_plane_flush(asdr_batch_t *b, long long stats[4]) {
 
 int asdr_enable_taps(asdr_batch_t *b, int on) {
   if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_enable_taps(sh_, on));
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   if (on && !b->d_taps) {
@@ -1276,6 +1755,18 @@ int asdr_enable_taps(asdr_batch_t *b, int on) {
 }
 
 int asdr_read_taps(asdr_batch_t *b, float *dst) {
+  if (is_sharded(b)) {   // [tap][global channel][128] from the shards' [tap][local channel][128]
+    if (!dst) return fail("taps not enabled");
+    std::vector<float> tmp;
+    for (size_t g = 0; g < b->shards.size(); g++) {
+      asdr_batch *sh = b->shards[g];
+      tmp.resize((size_t)ASDR_N_TAPS * sh->n * ASDR_N);
+      if (asdr_read_taps(sh, tmp.data()) != 0) return -1;
+      for (int t = 0; t < ASDR_N_TAPS; t++)
+        memcpy(dst + ((size_t)t * b->n + b->shard_first[g]) * ASDR_N, tmp.data() + (size_t)t * sh->n * ASDR_N, (size_t)sh->n * ASDR_N * sizeof(float));
+    }
+    return 0;
+  }
   if (!b || !b->d_taps || !dst) return fail("taps not enabled");
   if (asdr_synchronize(b) != 0) return -1;
   HIPCHK(hipMemcpy(dst, b->d_taps, (size_t)ASDR_N_TAPS * b->n * ASDR_N * sizeof(float), hipMemcpyDeviceToHost));

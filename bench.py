@@ -23,10 +23,20 @@ Launching:
   A launcher whose WORLD_SIZE differs from --gpus is an error (exit 2), never a silently mislabelled line.
   --dry-run: no GPU and no HIP library: gloo backend, the timed loop is empty; checks the launch / reduce / JSON plumbing.
 
-Warm-up: the GPU's clocks need ~0.2 s of work to settle after idle (the first ~500 launches of C2 run ~3 % slower, a 20-step
-run right after start-up ~10 %).  `--settle S` (default 1500 for c2 / c4, 4 for c5) asks for at least S untimed steps in front of
-the timed region whatever `--warmup` says; the JSON's `warmup` is the number of untimed steps that REALLY preceded the timed
-region, `config.warmup_requested` what the command line asked for.  `--settle 0` honours `--warmup` to the letter.
+Warm-up: `--warmup W` untimed steps of the measured batch precede the K timed steps, exactly as asked (`warmup` in the JSON = W).
+The GPU's clocks need ~0.2 s of work to leave their idle state (a 20-step run right after start-up is ~10 % slow), so BEFORE the
+measured batch exists a scratch batch of the same configuration runs `--settle S` launches (default 1500 for c2 / c4, 4 for c5) and
+is destroyed: device pre-heating, not steps of the job -- reported as `config.clock_settle_launches_on_a_scratch_batch`; `--settle 0`
+switches it off.  Without `--warmup` the default is W = 20 (c5: 2).
+
+`h2d_d2h_inclusive` (c2, N = 1): the same job through the HOST-pointer entry point asdr_update(), the boundary the reference's own
+data path has (host-resident audio blocks: AudioSDR.cpp:46-47, 158-167) -- 768 bytes per channel-block cross PCIe, overlapped in
+channel-range chunks (H2D || kernels || D2H); measured after the headline region with the host's clock around synchronous calls on
+pinned caller buffers, with pageable buffers and with the overlap switched off beside it.  Never `value`.
+
+`--single-process` (with --gpus N): ONE process drives N GPUs through a sharded batch (asdr_create_sharded: shard g = channels
+[g*C/N, (g+1)*C/N) on GPU g, no collective), device-resident rows per shard, asynchronous calls on every shard's stream; the line
+says so in `config.launch`.  `--devices 0,0` puts the shards on the listed ordinals (several on one GPU: the test on a 1-GPU box).
 
 Prints ONE JSON line (rank 0).  `value` = samples processed by all ranks / max-over-ranks wall time.
 `roofline` is for the dominant kernel of the config: algorithmic bytes per step / the mean duration of a step
@@ -278,6 +288,119 @@ def robustness(np, torch, dev, local_rank, n_ch, stream, timed):
     return out
 
 
+PCIE_REF_GBS = 63.0   # PCIe 5.0 x16, one direction (the figure the round-3 review prices the 768 B per channel-block against)
+
+
+def host_path(np, local_rank, n_ch, calls=30):
+    """The C2 job through asdr_update() (host pointers): Msamples/s with the host's clock around `calls` synchronous calls, for pinned
+    caller buffers (the figure), pageable caller buffers (staged through the batch's pinned area by worker threads) and with the
+    overlap switched off (one chunk: H2D -> kernels -> D2H serially, round 3's behaviour)."""
+    import audiosdr_amd as A
+    from audiosdr_amd.synth import make_iq
+    uniq = max(8, n_ch // 16)
+    bI, bQ = make_iq(uniq, N_INPUT_BLOCKS, fc=6290.0, A=0.25)
+    reps = (n_ch + uniq - 1) // uniq
+    res = {}
+    pin = [A.host_alloc((n_ch, 1, BLOCK)) for _ in range(2 * N_INPUT_BLOCKS + 1)]
+    pag = [np.empty((n_ch, 1, BLOCK), np.int16) for _ in range(2 * N_INPUT_BLOCKS + 1)]
+    for bufs in (pin, pag):
+        for b in range(N_INPUT_BLOCKS):
+            bufs[2 * b][:] = np.tile(bI[:, b:b + 1], (reps, 1, 1))[:n_ch]
+            bufs[2 * b + 1][:] = np.tile(bQ[:, b:b + 1], (reps, 1, 1))[:n_ch]
+    for name, bufs, chunks, n_calls in (("pinned", pin, 0, calls), ("pageable", pag, 0, max(6, calls // 3)), ("pinned_no_overlap", pin, 1, max(6, calls // 3))):
+        batch = A.AudioSDRBatch(n_ch, device=local_rank)
+        configure_c2(batch)
+        batch.set_host_chunks(chunks)
+        for i in range(4):
+            batch.update_into(bufs[2 * (i % N_INPUT_BLOCKS)], bufs[2 * (i % N_INPUT_BLOCKS) + 1], bufs[-1])
+        t0 = time.perf_counter()
+        for i in range(n_calls):
+            batch.update_into(bufs[2 * (i % N_INPUT_BLOCKS)], bufs[2 * (i % N_INPUT_BLOCKS) + 1], bufs[-1])
+        dt = (time.perf_counter() - t0) / n_calls
+        info = batch.host_path_info()
+        res[name] = {"ms_per_call": round(dt * 1e3, 4), "Msamples_per_s": round(n_ch * BLOCK / dt / 1e6, 1),
+                     "pcie_GBps": round(768.0 * n_ch / dt / 1e9, 2), "chunks": info["chunks"], "calls_timed": n_calls}
+        batch.close()
+    for a in pin:
+        A.host_free(a)
+    p = res["pinned"]
+    return {"value": p["Msamples_per_s"], "unit": "Msamples/s", "ms_per_call": p["ms_per_call"], "pcie_GBps": p["pcie_GBps"],
+            "frac_of_63GBps": round(p["pcie_GBps"] / PCIE_REF_GBS, 3), "chunks": p["chunks"],
+            "bytes_per_channel_block": 768, "pageable": res["pageable"], "no_overlap": res["pinned_no_overlap"],
+            "method": "asdr_update() on %d channels x 1 block per call, caller buffers in page-locked host memory (asdr_host_alloc), "
+                      "host clock around %d synchronous calls after 4 untimed ones; pcie_GBps = 768 B x channels / time (both directions "
+                      "summed: 512 in + 256 out, which PCIe moves concurrently); `pageable`: ordinary numpy buffers staged by the "
+                      "library's copy threads; `no_overlap`: asdr_set_host_chunks(1)" % (n_ch, calls)}
+
+
+def main_single_process(args, cfg, settle_min, warm_req):
+    """One process, N GPUs: a sharded batch (asdr_create_sharded), per-shard device-resident rows, asynchronous calls on every shard."""
+    import numpy as np
+    import torch
+    import audiosdr_amd as A
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    G = len(devices)
+    if G != args.gpus:
+        sys.stderr.write("bench.py: --devices lists %d ordinals for --gpus %d\n" % (G, args.gpus)); sys.exit(2)
+    if args.config == "c5":
+        sys.stderr.write("bench.py: --single-process covers c2 and c4\n"); sys.exit(2)
+    total_ch = (args.channels or cfg["channels"]) * (G if (cfg["per_gpu"] or args.channels) else 1)
+    batch = A.AudioSDRBatch(total_ch, devices=devices)
+    if args.config == "c2":
+        configure_c2(batch)
+    else:
+        configure_c4(batch, lib=A.load_library(), channel0=0)
+    shards, bufs = [], []
+    for g in range(G):
+        lo, hi = batch.shard_range(g)
+        dev = torch.device("cuda", devices[g])
+        with torch.cuda.device(dev):
+            if args.config == "c2":
+                dI, dQ = tiled_input(np, torch, dev, hi - lo, N_INPUT_BLOCKS, (hi - lo) // 4, channel0=lo, fc=6290.0, A=0.25)
+            else:
+                dI, dQ = tiled_input(np, torch, dev, hi - lo, N_INPUT_BLOCKS, 3584, channel0=lo % 3584, fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15)
+            dOut = torch.empty((hi - lo, BLOCK), dtype=torch.int16, device=dev)
+            stream = torch.cuda.Stream(device=dev)
+        shards.append(batch.shard(g)); bufs.append((dI, dQ, dOut, stream))
+
+    def step(i):
+        b = i % N_INPUT_BLOCKS
+        for v, (dI, dQ, dOut, st) in zip(shards, bufs):
+            v.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, st.cuda_stream)
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    for i in range(max(settle_min, 0) + args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    wall = time.perf_counter() - t0
+    per_gpu_ms = wall / args.steps * 1e3
+    algo = cfg["algo"] * total_ch
+    ach = algo / G / (per_gpu_ms * 1e-3) / 1e9      # per GPU: each holds 1/G of the channels
+    out = {"metric": "Msamples/s through full SSB demod chain, batched 128-sample blocks",
+           "value": round(float(total_ch) * BLOCK * args.steps / wall / 1e6, 2), "unit": "Msamples/s", "n_gpus": G, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(per_gpu_ms, 5), "higher_is_better": True, "scaling": cfg["scaling"],
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s through ONE process and a sharded batch: %d channels in all, shard g on device %s" % (args.config, total_ch, devices),
+                      "name": args.config, "launch": "single process, asdr_create_sharded, asynchronous asdr_update_device on every shard's stream",
+                      "devices": devices, "warmup_requested": warm_req, "clock_settle_launches": settle_min, "channels_total": total_ch,
+                      "sharding": "channels, no collective", "unmeasured_on_multi_gpu_hardware": len(set(devices)) < G},
+           "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(per_gpu_ms, 5),
+                        "kernel_ms_method": "host clock around the timed steps (all shards' streams synchronised on both sides) / steps; per GPU when the shards are on different devices"}}
+    print(json.dumps(out), flush=True)
+    for v in shards:
+        v.close()
+    batch.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +414,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-robustness", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo, empty timed loop (tests the launch plumbing)")
+    ap.add_argument("--single-process", action="store_true", help="one process, N GPUs through a sharded batch (asdr_create_sharded)")
+    ap.add_argument("--devices", type=str, default=None, help="--single-process: comma-separated device ordinals, one per shard")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the h2d_d2h_inclusive measurement")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.steps is None:
@@ -298,9 +424,13 @@ def main():
     settle_min = cfg["settle"] if args.settle is None else args.settle
     warm_req = args.warmup
     if args.warmup is None:
-        args.warmup = settle_min
+        args.warmup = 2 if args.config == "c5" else 20
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.single_process:
+        if launched:
+            sys.stderr.write("bench.py: --single-process under a distributed launcher makes no sense\n"); sys.exit(2)
+        return main_single_process(args, cfg, settle_min, warm_req)
     if not launched and args.gpus > 1:
         sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
@@ -340,28 +470,20 @@ def main():
 
     batch = None
     stream = None
-    if not args.dry_run:
-        import audiosdr_amd as A
-        stream = torch.cuda.current_stream().cuda_stream
-        batch = A.AudioSDRBatch(n_ch, device=local_rank)
-        if args.config == "c2":
-            dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, channel0=ch0, fc=6290.0, A=0.25)
-            configure_c2(batch)
-        elif args.config == "c4":
-            # 3584 distinct input channels tiled over the shard (the input does not depend on the mode; the mode is (global channel) mod 7)
-            dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, 3584, channel0=ch0 % 3584, fc=6890.0 - 300, A=0.3, m=0.4,
-                                 f2=7500.0, a2=0.15)
-            configure_c4(batch, lib=A.load_library(), channel0=ch0)
-        else:
-            dI, dQ = tiled_input(np, torch, dev, n_ch, T, n_ch, channel0=ch0, per_block=False, fc=6890.0, A=0.02, noise=0.05)
-            configure_c5(batch)
-            batch.capture_open(T * 4)         # the sink is rewound every 4 calls: the bench keeps 4 calls' worth, not a whole slot
-        if args.config != "c5":
-            dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
 
-    def step(i):
-        if batch is None:
-            return
+    def make_batch():
+        import audiosdr_amd as A
+        b = A.AudioSDRBatch(n_ch, device=local_rank)
+        if args.config == "c2":
+            configure_c2(b)
+        elif args.config == "c4":
+            configure_c4(b, lib=A.load_library(), channel0=ch0)
+        else:
+            configure_c5(b)
+            b.capture_open(T * 4)         # the sink is rewound every 4 calls: the bench keeps 4 calls' worth, not a whole slot
+        return b
+
+    def _step(batch, i):
         if args.config == "c5":
             if batch.capture_position + T > batch.capture_capacity:
                 batch.capture_rewind()
@@ -369,6 +491,32 @@ def main():
         else:
             b = i % N_INPUT_BLOCKS
             batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, stream)
+
+    if not args.dry_run:
+        import audiosdr_amd as A
+        stream = torch.cuda.current_stream().cuda_stream
+        if args.config == "c2":
+            dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, channel0=ch0, fc=6290.0, A=0.25)
+        elif args.config == "c4":
+            # 3584 distinct input channels tiled over the shard (the input does not depend on the mode; the mode is (global channel) mod 7)
+            dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, 3584, channel0=ch0 % 3584, fc=6890.0 - 300, A=0.3, m=0.4,
+                                 f2=7500.0, a2=0.15)
+        else:
+            dI, dQ = tiled_input(np, torch, dev, n_ch, T, n_ch, channel0=ch0, per_block=False, fc=6890.0, A=0.02, noise=0.05)
+        if args.config != "c5":
+            dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
+        # clock settling on a scratch batch (module docstring): the measured batch then gets exactly --warmup steps
+        if settle_min > 0:
+            batch = make_batch()
+            for i in range(settle_min):
+                _step(batch, i)
+            torch.cuda.synchronize()
+            batch.close()
+        batch = make_batch()
+
+    def step(i):
+        if batch is not None:
+            _step(batch, i)
 
     def fence():
         if not args.dry_run:
@@ -378,8 +526,8 @@ def main():
         if not args.dry_run:
             torch.cuda.synchronize()
 
-    # untimed steps: what --warmup asks for, topped up to --settle (see the module docstring); reported as `warmup`
-    untimed = max(args.warmup, settle_min) if batch is not None else args.warmup
+    # untimed steps of the measured batch: exactly what --warmup asks for (the clocks were settled on a scratch batch above)
+    untimed = args.warmup
     for i in range(untimed):
         step(i)
     fence()
@@ -454,8 +602,7 @@ def main():
             "warmup": untimed, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "name": args.config,
-                       "warmup_requested": warm_req, "settle_steps_minimum": settle_min,
-                       "untimed_launches_before_the_timed_region": untimed,
+                       "warmup_requested": warm_req, "clock_settle_launches_on_a_scratch_batch": 0 if args.dry_run else settle_min,
                        "channels_per_gpu": n_ch, "channels_total": total_ch, "blocks_per_step": T, "block": BLOCK,
                        "sharding": "channels, no collective", "input": inputs},
             "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -475,11 +622,14 @@ def main():
                 out["config"]["times_real_time"] = round(T * BLOCK / 44100.0 / (k_ms * 1e-3), 1)
         if args.dry_run:
             out["dry_run"] = True
-        if world == 1 and args.config == "c2" and not args.no_robustness and not args.dry_run:
+        if world == 1 and args.config == "c2" and not args.dry_run and not (args.no_robustness and args.no_host_path):
             if batch is not None:
                 batch.close(); batch = None
             del dI, dQ
-            out["robustness"] = robustness(np, torch, dev, local_rank, n_ch, stream, 300)
+            if not args.no_host_path:
+                out["h2d_d2h_inclusive"] = host_path(np, local_rank, n_ch)
+            if not args.no_robustness:
+                out["robustness"] = robustness(np, torch, dev, local_rank, n_ch, stream, 300)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -20,6 +20,7 @@
 #ifndef ASDR_H_
 #define ASDR_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -51,6 +52,27 @@ void asdr_destroy(asdr_batch_t *b);
 const char *asdr_last_error(void);
 int asdr_n_channels(const asdr_batch_t *b);
 
+/* ---- sharded batches: replaces N x `AudioSDR sdr;` spread over the GPUs of one node (instances are independent,
+ * AudioSDR.h:75-81, AudioSDR.cpp:41-44).  Shard g of n_shards owns channels [g*C/n_shards, (g+1)*C/n_shards) -- state, parameters,
+ * schedule, streams and staging all live on devices[g] (ordinals may repeat: several shards on one GPU; ASDR_NO_DEVICE for every
+ * shard = a control-plane-only sharded batch).  The handle is an asdr_batch_t: EVERY entry point of this header takes it, with
+ * GLOBAL channel indices -- setters and getters are routed to the owner (ASDR_ALL fans out), status / tap / capture reads come back
+ * in global channel order -- so code written for one batch runs unchanged on eight GPUs.  There is no collective and nothing crosses
+ * between devices.
+ *   asdr_update              host rows of all channels: scattered to / gathered from the shards' overlapped host paths, one host
+ *                            thread per shard.
+ *   asdr_update_device*,     device pointers belong to one device: accepted while all shards live on the SAME device (each shard
+ *   asdr_capture_update_device  takes its rows of the caller's arrays); for shards on several devices drive each shard with its own
+ *                            device-local pointers and stream through asdr_shard(b, g) -- the calls are asynchronous, so one host
+ *                            thread can keep all GPUs busy.
+ *   asdr_region_timing_*, asdr_kernel_timing_*, asdr_capture_device_ptr   per device: through the shard handles.
+ * asdr_shard_first_channel(b, g) = first global channel of shard g (g == n_shards: the total).  A plain batch answers as one shard. */
+asdr_batch_t *asdr_create_sharded(int n_channels, int n_shards, const int *devices);
+int asdr_n_shards(const asdr_batch_t *b);
+asdr_batch_t *asdr_shard(asdr_batch_t *b, int shard);           /* owned by the sharded batch: never asdr_destroy() it */
+int asdr_shard_first_channel(const asdr_batch_t *b, int shard);
+int asdr_shard_device(const asdr_batch_t *b, int shard);
+
 /* ---- the hot path: replaces AudioSDR::update() (AudioSDR.cpp:39-168), called once per 128-sample
  * block per instance by the Teensy audio interrupt with two int16 blocks in (receiveWritable(0/1),
  * :46-47) and one mono int16 block out (transmit, :164-165).
@@ -65,6 +87,22 @@ int asdr_n_channels(const asdr_batch_t *b);
  * A NULL I or Q mirrors the reference's missing-input guard (AudioSDR.cpp:48-56): nothing is
  * processed, no state advances, out is untouched, return 0. */
 int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks);
+/* asdr_update() is the boundary the reference's data path has (host-resident audio blocks in, one out: AudioSDR.cpp:46-47, 158-167):
+ * 768 bytes cross PCIe per channel-block and that, not the kernels, bounds the call.  It is overlapped: the batch is cut into
+ * channel-range chunks and H2D(k + 1) || kernels(k) || D2H(k - 1) run on three streams (chunking is by channels, so the order of
+ * blocks within a channel is untouched and results are bit-identical to asdr_update_device).  Caller buffers that are PINNED are DMA
+ * targets as they are; pageable buffers go through a pinned staging area of the batch, copied by a few worker threads
+ * (ASDR_HOST_COPY_THREADS, default 4).  To pin:
+ *   asdr_host_alloc / asdr_host_free          page-locked host memory (hipHostMalloc, portable across devices)
+ *   asdr_host_register / asdr_host_unregister pin memory the caller already owns, in place (hipHostRegister); unregister before freeing it
+ *   asdr_set_host_chunks(b, k)                k > 0 forces k chunks (1 = no overlap: the round-3 behaviour, for comparison), 0 = from the call's size
+ *   asdr_host_path_info(b, out)               out[0] = chunks of the last asdr_update, out[1] = 1 if it used the caller's buffers directly */
+void *asdr_host_alloc(size_t bytes);
+void asdr_host_free(void *p);
+int asdr_host_register(void *p, size_t bytes);
+int asdr_host_unregister(void *p);
+int asdr_set_host_chunks(asdr_batch_t *b, int chunks);
+int asdr_host_path_info(asdr_batch_t *b, int out[2]);
 int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
                        void *stream);
 /* Same, with explicit row strides in blocks: I and Q rows are in_stride_blocks*128 samples apart, out rows
@@ -228,6 +266,12 @@ long asdr_stream_pipeline_launches(asdr_batch_t *b);
  * asdr_set_stream_pipeline(b, 0) opts a batch out of the pipeline altogether (default on; environment ASDR_NO_STREAM_PIPELINE=1
  * at asdr_create time = default off). */
 long asdr_stream_pipeline_recoveries(asdr_batch_t *b);
+/* The pipeline's exchange rings, progress counters and snapshot (about 9 KB per channel) are allocated at its first use.  If that
+ * allocation fails the batch opts itself out of the pipeline and keeps the in-kernel block loop -- the call still succeeds; this
+ * counts such events.  A call whose output rows overlap its input rows (in-place use, the reference's own convention:
+ * AudioSDR.cpp:158-165 writes the audio into blockI) never takes the pipeline either: its recovery restores channel state, not
+ * caller buffers. */
+long asdr_stream_pipeline_alloc_failures(asdr_batch_t *b);
 int asdr_stream_pipeline_max_groups(asdr_batch_t *b);
 int asdr_set_stream_pipeline(asdr_batch_t *b, int on);
 /* How a batch launches its SAM channels (bit-identical results): fused = 1 -> the fused 4-wave kernel always; otherwise the three
@@ -243,9 +287,10 @@ int asdr_set_als_launch_form(asdr_batch_t *b, int split_min_channels);
 /* Test hook: the number of polls after which a pipeline wait gives up (0 = the default, 2^18).  A tiny value injects timeouts, so
  * that the recovery path can be tested on an idle GPU. */
 int asdr_debug_set_stream_spin_limit(asdr_batch_t *b, unsigned int polls);
-/* Test / experiment hook: overrides the largest number of channel groups the pipeline takes (asdr_stream_pipeline_max_groups();
- * default from the occupancy query: one workgroup per compute unit).  Larger values put several pipeline workgroups on a compute
- * unit; results stay exact (a wait that runs out is recovered as described above). */
+/* Test / experiment hook: lowers the largest number of channel groups the pipeline takes (asdr_stream_pipeline_max_groups();
+ * default = what the occupancy query of asdr_create says the device holds at once: 512 on an MI355X).  Values beyond the query's
+ * answer are clamped to it -- more groups than resident workgroups cannot make progress and every call would sit out its 2^18
+ * polls before the recovery launches run. */
 int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups);
 /* The wave schedule as the last flush built it (the next update's launches; a control-plane-only batch: after
  * asdr_control_plane_flush), in schedule slots (8 per wave): out[0..4] = the sub-ranges of whole waves of one settings group by

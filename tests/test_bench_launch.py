@@ -54,14 +54,15 @@ def test_algorithmic_bytes_follow_survey_8d():
     assert abs(bench.C5_ALGO_BYTES_PER_BLOCK - (768 * 646 + 96 + 2 * 1688) / 646.0) < 1e-9
 
 
-def test_warmup_field_is_the_effective_number_of_untimed_steps():
-    """`warmup` in the JSON line = the untimed steps that really preceded the timed region; what the command line asked for is
-    config.warmup_requested.  (On a GPU run the settle minimum tops --warmup up; the dry run has no device to settle.)"""
+def test_warmup_field_is_exactly_what_the_command_line_asked_for():
+    """`warmup` in the JSON line = --warmup = the untimed steps of the measured batch (round 4: the clocks are settled on a scratch
+    batch before the measured one exists; the dry run has no device to settle and says 0)."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "3"],
                        capture_output=True, text=True, env=_env(), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert j["warmup"] == 3 and j["config"]["warmup_requested"] == 3 and j["config"]["settle_steps_minimum"] == 1500
+    assert j["warmup"] == 3 and j["steps"] == 2 and j["config"]["warmup_requested"] == 3
+    assert j["config"]["clock_settle_launches_on_a_scratch_batch"] == 0
 
 
 def test_gpus_1_dry_run_is_a_single_process_line():

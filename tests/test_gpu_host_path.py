@@ -1,0 +1,118 @@
+"""The host-pointer entry point asdr_update() (include/asdr.h; the boundary of the reference's data path: host-resident audio blocks,
+AudioSDR.cpp:46-47, 158-167) is overlapped in channel-range chunks -- H2D(k + 1) || kernels(k) || D2H(k - 1).  Chunking is by
+channels, so it must equal the device-pointer path bit for bit: for ragged chunk sizes, multi-block calls, settings mixes whose
+schedule is not in channel order (every kernel kind + remainders), pinned and pageable caller buffers."""
+import numpy as np
+import pytest
+
+from tests.helpers import Hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _mix(batch, n, kind):
+    if kind == "usb":
+        batch.setDemodMode(1); batch.enableAudioFilter()
+    elif kind == "c4":
+        for m in range(7):
+            for c in range(m, n, 7):
+                batch.setDemodMode(m, ch=c)
+        batch.enableALSfilter(); batch.setNoiseBlankerThresholdDb(10.0)
+    else:   # halves: consecutive channel ranges with different kernel kinds, a long ALS filter, a few odd channels
+        batch.setDemodMode(1); batch.enableAudioFilter()
+        for c in range(n // 2, n):
+            batch.setDemodMode(5, ch=c)
+        for c in range(n // 3, n // 3 + 50):
+            batch.enableALSfilter(ch=c); batch.setALSfilterParams(100, 0.3, 5, ch=c)
+        for c in (1, 77, n - 2):
+            batch.setDemodMode(4, ch=c); batch.setMute(1, ch=c)
+
+
+def _device_reference(gpu, n, kind, I, Q, calls):
+    hip = Hip()
+    b = gpu.AudioSDRBatch(n)
+    _mix(b, n, kind)
+    outs, pos = [], 0
+    for T in calls:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n * T * 256)
+        b.update_device(dI, dQ, dO, T)
+        b.synchronize()
+        outs.append(hip.download(dO, (n, T, 128), np.int16))
+        pos += T
+    st = b.read_status()
+    hip.free_all(); b.close()
+    return outs, st
+
+
+@pytest.mark.parametrize("kind,n,chunks", [("usb", 4104, 0), ("usb", 4104, 5), ("c4", 5003, 3), ("c4", 5003, 16), ("halves", 3001, 7), ("halves", 3001, 2)])
+def test_chunked_host_path_equals_the_device_path(gpu, kind, n, chunks):
+    from audiosdr_amd.synth import make_iq
+    calls = (1, 3, 1, 2)
+    total = sum(calls)
+    fc = 6890.0 - 600.0 + 25.0 * (np.arange(n) % 9)
+    I, Q = make_iq(n, total, fc=fc, A=0.25, m=0.3, noise=0.02, impulse_every=1500)
+    want, want_st = _device_reference(gpu, n, kind, I, Q, calls)
+    for pinned in (False, True):
+        b = gpu.AudioSDRBatch(n)
+        _mix(b, n, kind)
+        b.set_host_chunks(chunks)
+        pos = 0
+        for k, T in enumerate(calls):
+            if pinned:
+                hI, hQ, hO = (gpu.host_alloc((n, T, 128)) for _ in range(3))
+                hI[:] = I[:, pos:pos + T]; hQ[:] = Q[:, pos:pos + T]; hO[:] = 0x1111
+                b.update_into(hI, hQ, hO)
+                got = hO.copy()
+                for a in (hI, hQ, hO):
+                    gpu.host_free(a)
+            else:
+                got = b.update(I[:, pos:pos + T], Q[:, pos:pos + T])
+            info = b.host_path_info()
+            assert info["pinned"] == pinned
+            if chunks:
+                assert info["chunks"] == min(chunks, max(1, n // 8))
+            assert np.array_equal(got, want[k]), "call %d (%d blocks), pinned %s: %d samples differ" % (k, T, pinned, int((got != want[k]).sum()))
+            pos += T
+        st = b.read_status()
+        for key in st:
+            assert st[key].tobytes() == want_st[key].tobytes(), key
+        b.close()
+
+
+def test_default_chunking_of_a_large_call_and_registered_memory(gpu):
+    """A call large enough for the default plan to cut it (16,384 channels x 4 blocks = 16 MB per row set -> 8 chunks), on caller
+    memory pinned in place with asdr_host_register."""
+    from audiosdr_amd.synth import make_iq
+    import ctypes as C
+    n, T = 16384, 4
+    bI, bQ = make_iq(512, T, fc=6290.0, A=0.25, impulse_every=900)
+    I = np.ascontiguousarray(np.tile(bI, (n // 512, 1, 1))); Q = np.ascontiguousarray(np.tile(bQ, (n // 512, 1, 1)))
+    out = np.zeros_like(I)
+    L = gpu.load_library()
+    for a in (I, Q, out):
+        assert L.asdr_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0, L.asdr_last_error()
+    b = gpu.AudioSDRBatch(n)
+    b.setDemodMode(1); b.enableAudioFilter()
+    b.update_into(I, Q, out)
+    info = b.host_path_info()
+    assert info["pinned"] and info["chunks"] == 8, info
+    for a in (I, Q, out):
+        assert L.asdr_host_unregister(a.ctypes.data_as(C.c_void_p)) == 0
+    # all 512-channel tiles carry the same input and the same settings: identical audio; one tile against the device path
+    assert np.array_equal(out.reshape(n // 512, 512, T, 128), np.broadcast_to(out[:512], (n // 512, 512, T, 128)))
+    want, _ = _device_reference(gpu, 512, "usb", bI, bQ, (T,))
+    assert np.array_equal(out[:512], want[0])
+    b.close()
+
+
+def test_missing_input_guard_and_errors_on_the_host_path(gpu):
+    b = gpu.AudioSDRBatch(16)
+    L = gpu.load_library()
+    out = np.full((16, 1, 128), 7, np.int16)
+    import ctypes as C
+    p = C.POINTER(C.c_int16)
+    assert L.asdr_update(b._h, None, out.ctypes.data_as(p), out.ctypes.data_as(p), 1) == 0      # AudioSDR.cpp:48-56: nothing happens
+    assert (out == 7).all()
+    assert L.asdr_update(b._h, out.ctypes.data_as(p), out.ctypes.data_as(p), None, 1) != 0
+    b.close()

@@ -319,6 +319,38 @@ def test_block_pipeline_timeout_is_recovered_in_stream(gpu, ao, limit):
     hip.free_all(); batch.close()
 
 
+def test_in_place_calls_never_take_the_pipeline(gpu, ao):
+    """The pipeline's recovery restores channel state, not caller buffers: a call whose output rows alias its I rows (the reference's
+    own convention, AudioSDR.cpp:158-165: the audio is written into blockI) keeps the in-kernel block loop -- also with injected
+    timeouts pending -- and is exact; the same batch takes the pipeline again for a call with separate buffers."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, T = 64, 20
+    I, Q = make_iq(n_ch, 3 * T, fc=6290.0, A=0.25, noise=0.02, impulse_every=611)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0)])
+    batch.debug_set_stream_spin_limit(1)                        # any pipeline launch would time out and be recovered
+    hip = Hip()
+    want = [orcs[c].update(I[c], Q[c]).reshape(3 * T, 128) for c in range(n_ch)]
+    for k, alias in enumerate(("I", "Q")):
+        dI, dQ = hip.upload(I[:, k * T:(k + 1) * T]), hip.upload(Q[:, k * T:(k + 1) * T])
+        dO = dI if alias == "I" else dQ
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            assert np.array_equal(got[c], want[c][k * T:(k + 1) * T]), (alias, c)
+    assert batch.stream_pipeline_launches() == 0 and batch.stream_pipeline_recoveries() == 0
+    batch.debug_set_stream_spin_limit(0)
+    dI, dQ, dO = hip.upload(I[:, 2 * T:]), hip.upload(Q[:, 2 * T:]), hip.malloc(n_ch * T * 256)
+    batch.update_device(dI, dQ, dO, T)
+    batch.synchronize()
+    got = hip.download(dO, (n_ch, T, 128), np.int16)
+    for c in range(n_ch):
+        assert np.array_equal(got[c], want[c][2 * T:]), c
+    assert batch.stream_pipeline_launches() == 1 and batch.stream_pipeline_alloc_failures() == 0
+    _compare_status(batch, orcs)
+    hip.free_all(); batch.close()
+
+
 def test_launch_form_switches_per_batch(gpu, ao):
     """asdr_set_stream_pipeline / asdr_set_sam_launch_form: the launch forms are properties of a batch (their defaults come from
     the environment when the batch is created), so two batches of one process can differ -- and every form is bit-exact."""

@@ -20,8 +20,8 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
 bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc" > "$OUT/pmc.log" 2>&1
-bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c3" "tools/bench_configs.py c3: SAM, 262144 channels x 1 block per launch" python3 $ROOT/tools/bench_configs.py c3 > "$OUT/pmc_c3.log" 2>&1
-bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c4" "tools/bench_configs.py c4: mixed modes + ALS, 131072 channels x 1 block per launch" python3 $ROOT/tools/bench_configs.py c4 > "$OUT/pmc_c4.log" 2>&1
+bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c3" "tools/bench_configs.py c3: SAM, 262144 channels x 1 block per launch" python3 "$ROOT/tools/bench_configs.py" c3 > "$OUT/pmc_c3.log" 2>&1
+bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c4" "tools/bench_configs.py c4: mixed modes + ALS, 131072 channels x 1 block per launch" python3 "$ROOT/tools/bench_configs.py" c4 > "$OUT/pmc_c4.log" 2>&1
 python3 tools/bench_configs.py c1 c2 c2s c3 c4 c5 > "$OUT/configs_1gpu.jsonl" 2> "$OUT/configs.err"
 python3 bench.py --config c4 --no-cpu-baseline --steps 300 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 bench.py --config c5 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
