@@ -6,7 +6,7 @@ include/asdr.h).  This package is only a thin ctypes mirror of that ABI whose cl
 reads like reference usage.  There is no CPU fallback: if the library or a HIP device is
 missing, construction raises.
 """
-from .binding import (AGCfast, AGCmedium, AGCoff, AGCslow, ALL, AMmode, BLOCK, CW_LSBmode, CW_USBmode, LSBmode, SAMmode,
+from .binding import (STREAM_BATCH, AGCfast, AGCmedium, AGCoff, AGCslow, ALL, AMmode, BLOCK, CW_LSBmode, CW_USBmode, LSBmode, SAMmode,
                       TAPS, USBmode, WSPRmode, AudioSDRBatch, AsdrError, audio2100, audio2300, audio2500, audio2700,
                       audio2900, audio3100, audio3300, audioAM, audioBypass, audioCW, audioWSPR, library_path,
                       library_sha256, load_library, host_alloc, host_free)

@@ -10,6 +10,7 @@ import numpy as np
 
 BLOCK = 128
 ALL = -1
+STREAM_BATCH = (1 << 64) - 1     # ASDR_STREAM_BATCH ((void *)-1): the batch's own streams (include/asdr.h)
 LSBmode, USBmode, CW_LSBmode, CW_USBmode, AMmode, SAMmode, WSPRmode = range(7)       # AudioSDR.h:44-50
 (audioAM, audioCW, audioWSPR, audio2100, audio2300, audio2500, audio2700, audio2900, audio3100, audio3300,
  audioBypass) = range(11)                                                             # AudioSDR.h:56-66
@@ -59,7 +60,7 @@ EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read",
             "asdr_create_sharded", "asdr_n_shards", "asdr_shard", "asdr_shard_first_channel", "asdr_shard_device",
             "asdr_host_alloc", "asdr_host_free", "asdr_host_register", "asdr_host_unregister", "asdr_set_host_chunks",
-            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures"] +
+            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures", "asdr_set_launch_split", "asdr_order_after", "asdr_order_before", "asdr_lane_calls", "asdr_set_lanes"] +
            ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
 
 _lib = None
@@ -151,6 +152,11 @@ def load_library(path=None):
         L.asdr_set_host_chunks.argtypes = [vp, _i]; L.asdr_set_host_chunks.restype = _i
         L.asdr_host_path_info.argtypes = [vp, C.POINTER(C.c_int)]; L.asdr_host_path_info.restype = _i
         L.asdr_stream_pipeline_alloc_failures.argtypes = [vp]; L.asdr_stream_pipeline_alloc_failures.restype = C.c_long
+        L.asdr_set_launch_split.argtypes = [vp, _i, _i]; L.asdr_set_launch_split.restype = _i
+        L.asdr_order_after.argtypes = [vp, vp]; L.asdr_order_after.restype = _i
+        L.asdr_order_before.argtypes = [vp, vp]; L.asdr_order_before.restype = _i
+        L.asdr_lane_calls.argtypes = [vp]; L.asdr_lane_calls.restype = C.c_long
+        L.asdr_set_lanes.argtypes = [vp, _i, _i]; L.asdr_set_lanes.restype = _i
     if path is None:
         _lib = L
     return L
@@ -199,6 +205,21 @@ class AudioSDRBatch:
 
     def shard_range(self, g):
         return int(self._L.asdr_shard_first_channel(self._h, int(g))), int(self._L.asdr_shard_first_channel(self._h, int(g) + 1))
+
+    def order_after(self, stream):
+        self._chk(self._L.asdr_order_after(self._h, C.c_void_p(stream)))
+
+    def order_before(self, stream):
+        self._chk(self._L.asdr_order_before(self._h, C.c_void_p(stream)))
+
+    def lane_calls(self):
+        return int(self._L.asdr_lane_calls(self._h))
+
+    def set_lanes(self, on=True, min_waves=0):
+        self._chk(self._L.asdr_set_lanes(self._h, 1 if on else 0, int(min_waves)))
+
+    def set_launch_split(self, pieces, min_waves=0):
+        self._chk(self._L.asdr_set_launch_split(self._h, int(pieces), int(min_waves)))
 
     def set_host_chunks(self, chunks):
         self._chk(self._L.asdr_set_host_chunks(self._h, int(chunks)))

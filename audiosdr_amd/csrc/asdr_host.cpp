@@ -168,7 +168,8 @@ struct HostPlan { int K = 1; std::vector<int> bound, need_in, last_part; long sc
 
 }  // namespace
 
-#define ASDR_AUX_STREAMS (ASDR_KERNEL_KINDS + 1)   /* every sub-range but the first runs on a helper stream */
+#define ASDR_LANES 2   /* (three streams share a hardware queue with something else on this part: 0.18 ms; four are no better than two) */
+#define ASDR_AUX_STREAMS (ASDR_KERNEL_KINDS + 1 + 8)   /* every sub-range but the first runs on a helper stream; a large sub-range may be split over several (launch_split) */
 struct asdr_batch {
   int n = 0, device = 0;
   hipStream_t stream = nullptr;  // used by the host-pointer entry point and by getters
@@ -218,6 +219,19 @@ struct asdr_batch {
   HostPlan host_plan;
   std::unique_ptr<CopyPool> copy_pool;
   int host_chunks_forced = 0;            // asdr_set_host_chunks: 0 = chosen from the call's size
+  // LANES: a batch whose schedule is ONE settings group of consecutive channels (C2, C5 ...) may run its two halves on two streams of
+  // its own that never wait for each other -- half A of block k + 1 starts when half A of block k is done, while half B of block k
+  // still drains its last waves (kernels of one stream run strictly one after the other, each with a tail in which the GPU runs
+  // empty: 0.121 -> 0.111 ms per C2 step, tools/split_probe.py).  Inside a multi-block call (which joins at its end) always; from
+  // call to call only for calls on ASDR_STREAM_BATCH, whose contract leaves the ordering against other streams to the caller.
+  hipStream_t lane[ASDR_LANES] = {};
+  hipEvent_t ev_lane[ASDR_LANES] = {};
+  bool lanes_pending = false;            // the lanes hold launches that nothing has been ordered behind yet
+  bool last_was_lanes = false;           // the previous call ran on the lanes (asdr_update_device on ASDR_STREAM_BATCH)
+  int lanes_min_waves = 1024;            // smallest sub-range that is run as lanes
+  bool lanes_enabled = true;
+  long stat_lane_calls = 0;
+  int launch_split = 1, launch_split_min_waves = 2048;   // asdr_set_launch_split: a sub-range of at least that many waves is launched as `launch_split` kernels on as many streams
   int stat_host_chunks = 0, stat_host_pinned = 0;   // what the last asdr_update did (asdr_host_path_info)
   // A SHARDED batch (asdr_create_sharded) owns no channels itself: shard g holds channels [shard_first[g], shard_first[g + 1]) on
   // its own device with its own state, schedule and streams; every entry point of the C ABI routes global channel indices to the
@@ -651,12 +665,28 @@ const Chan *get(asdr_batch *&b, int ch) {
   return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr;
 }
 
+bool needs_flush(const asdr_batch *b) {
+  return b->all_dirty || !b->dirty.empty() || b->sched_dirty || b->agc_pool_dirty || b->reset_pending || b->agc_refs_changed;
+}
+// everything the lanes hold so far happens before whatever is enqueued on `stream` from now on
+int lanes_join_into(asdr_batch *b, hipStream_t stream) {
+  for (int l = 0; l < ASDR_LANES; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(stream, b->ev_lane[l], 0)); }
+  return 0;
+}
+// host-side: every launch of the batch so far is complete
+int sync_all(asdr_batch *b) {
+  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->lanes_pending) { for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamSynchronize(b->lane[l])); b->lanes_pending = false; }
+  return 0;
+}
+
 // The streaming pipeline's recovery counter (a wave gave up waiting for its neighbour role, the call was re-run on the in-kernel
 // block loop from the snapshot: asdr_kernels.hip "the pipeline as a transaction"): read back at the host's synchronisation points
 // (asdr_synchronize, asdr_update, the status / capture readers).  Results are exact either way; this is only a statistic.
 int check_stream_error(asdr_batch *b) {
   if (!b->stream_launched || !b->d_stream_prog) return 0;
-  HIPCHK(hipStreamSynchronize(b->last_stream));
+  if (sync_all(b) != 0) return -1;
   uint32_t *word = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1, v[2] = {0, 0};
   HIPCHK(hipMemcpy(v, word, sizeof v, hipMemcpyDeviceToHost));
   b->stream_launched = false;
@@ -670,8 +700,7 @@ int read_small(asdr_batch *b, int ch, ChanSmall &s) {
   if (is_sharded(b)) b = shard_of(b, ch);
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if (sync_all(b) != 0) return -1;
   if (check_stream_error(b) != 0) return -1;
   if (apply_resets(b, b->stream) != 0) return -1;
   HIPCHK(hipMemcpy(&s, b->d_small + ch, sizeof s, hipMemcpyDeviceToHost));
@@ -700,6 +729,8 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
   b->sam_split_min = getenv("ASDR_SAM_SPLIT_MIN") ? atoi(getenv("ASDR_SAM_SPLIT_MIN")) : ASDR_SAM_SPLIT_MIN_CHANNELS;
   b->stream_pipeline = getenv("ASDR_NO_STREAM_PIPELINE") == nullptr;
   b->als_split_min = getenv("ASDR_ALS_SPLIT_MIN") ? atoi(getenv("ASDR_ALS_SPLIT_MIN")) : 0x7fffffff;
+  if (getenv("ASDR_LAUNCH_SPLIT")) b->launch_split = std::max(1, std::min(atoi(getenv("ASDR_LAUNCH_SPLIT")), 8));
+  if (getenv("ASDR_LAUNCH_SPLIT_MIN_WAVES")) b->launch_split_min_waves = std::max(8, atoi(getenv("ASDR_LAUNCH_SPLIT_MIN_WAVES")));
   const size_t rows = (size_t)n_channels + 1;
   if (device != ASDR_NO_DEVICE) {
     int ndev = 0;
@@ -720,8 +751,13 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     if (ok && hipMemset(b->d_audio_prev, 0, rows * 128 * sizeof(float)) != hipSuccess) ok = false;
     alloc((void **)&b->d_sched, (rows + 32) * sizeof(SlotInfo));   // three sub-ranges, each padded to a whole wave
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
-    alloc((void **)&b->d_lo, 2 * ASDR_LO_ENTRIES * sizeof(LoEntry));
-    if (ok && hipMemset(b->d_lo, 0xFF, 2 * ASDR_LO_ENTRIES * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
+    alloc((void **)&b->d_lo, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry));   // + one set per lane: a lane's readers only ever see its own writer
+    if (ok && hipMemset(b->d_lo, 0xFF, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
+    for (int i = 0; i < ASDR_LANES && ok; i++) {
+      if (hipStreamCreateWithFlags(&b->lane[i], hipStreamNonBlocking) != hipSuccess) ok = false;
+      if (ok && hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
+    }
+    b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
     if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
@@ -839,6 +875,7 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->ev_last) hipEventDestroy(b->ev_last);
   if (b->ev_fork) hipEventDestroy(b->ev_fork);
   for (int i = 0; i < ASDR_AUX_STREAMS; i++) { if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]); if (b->aux[i]) hipStreamDestroy(b->aux[i]); }
+  for (int i = 0; i < ASDR_LANES; i++) { if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]); if (b->lane[i]) hipStreamDestroy(b->lane[i]); }
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -861,17 +898,33 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   if (in_stride_blocks < n_blocks || out_stride_blocks < n_blocks) return fail("row stride shorter than n_blocks");
   if (in_stride_blocks > 0x7fffffffL || out_stride_blocks > 0x7fffffffL) return fail("row stride too large");
   if ((((uintptr_t)dI | (uintptr_t)dQ | (uintptr_t)dOut) & 15u) != 0) return fail("I/Q/out device pointers must be 16-byte aligned");
-  hipStream_t stream = (hipStream_t)stream_;
+  const bool batch_stream = (stream_ == ASDR_STREAM_BATCH);
+  hipStream_t stream = batch_stream ? b->stream : (hipStream_t)stream_;
   HIPCHK(hipSetDevice(b->device));
+  // Lanes (see asdr_batch): decided from the schedule as it stands -- a call that has setters or resets to apply runs the ordinary
+  // way (it synchronises anyway), the next one is back on the lanes.
+  bool use_lanes = false;
+  if (parts == 1 && b->lanes_enabled && !needs_flush(b) && (batch_stream || n_blocks >= 2) && !b->taps_on && b->tev.empty() && !b->time_calls) {
+    int n_kinds = 0, kind = -1;
+    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) if (b->kind_slots[k] > 0) { n_kinds++; kind = k; }
+    use_lanes = n_kinds == 1 && b->left_slots == 0 && b->kind_uniform_slots[kind] == b->kind_slots[kind] && b->kind_direct[kind] &&
+                b->kind_slots[kind] / 8 >= b->lanes_min_waves &&
+                (batch_stream || b->kind_slots[kind] >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES || b->sam_split || b->als_split);   // (a strict call: only in its one-launch-per-block form)
+  }
+  if (!use_lanes && b->lanes_pending) {   // an ordinary call after calls on the lanes: behind them
+    if (needs_flush(b)) { if (sync_all(b) != 0) return -1; }   // (the flush rewrites rows the lanes' kernels read)
+    else { if (lanes_join_into(b, stream) != 0) return -1; b->lanes_pending = false; }
+    b->last_stream = stream; b->last_was_lanes = false;
+  }
   // one stream at a time per batch: a call on another stream first waits for the previous call's kernels (state in HBM is
   // read-modify-written by every launch)
   // (The event is recorded now, on the previous call's stream -- behind everything that call enqueued there -- rather than after
   // every call: one packet less per launch for the common single-stream caller.)
-  if (part == 0 && b->ev_last_valid && stream != b->last_stream) {
+  if (part == 0 && b->ev_last_valid && stream != b->last_stream && !(use_lanes && batch_stream)) {
     HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
     HIPCHK(hipStreamWaitEvent(stream, b->ev_last, 0));
   }
-  if (part == 0) {
+  if (part == 0 && !use_lanes) {
     if (flush(b, stream) != 0) return -1;
     if (apply_resets(b, stream) != 0) return -1;
   }
@@ -985,7 +1038,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     b->ev_last_valid = true;
     b->ev_valid = (e0 != nullptr && e0 == b->ev0);
     if (b->region_calls >= 0) b->region_calls++;
-    b->last_stream = stream;
+    b->last_stream = stream; b->last_was_lanes = false;
     b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
     b->als_phase = (b->als_phase + (uint32_t)n_blocks) & 1u;
     b->lo_parity ^= 1u;
@@ -994,19 +1047,71 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   // The largest sub-range runs on the caller's stream: back-to-back calls then follow each other there without a gap, the helper
   // streams' joins (shorter kernels) are already satisfied when it ends, and only their starts pay the fork event's latency
   // (C4: 28 us per call with the remainders' launch on the caller's stream).
-  int main_sub = 0;
-  for (int i = 1; i < n_sub; i++) if (subs[i].slots > subs[main_sub].slots) main_sub = i;
   const int n_launch = per_block ? n_blocks : 1;
   float *const taps = a.taps;
   if (e0 && part == 0) HIPCHK(hipEventRecord(e0, stream));   // timing marker: right before the first launch
-  // this part's waves of every sub-range
-  int part_lo[ASDR_KERNEL_KINDS + 2], part_n[ASDR_KERNEL_KINDS + 2], n_live = 0;
+  if (use_lanes) {
+    // fork: the lanes start behind the previous ordinary call (ASDR_STREAM_BATCH) / behind everything on the caller's stream so far
+    if (batch_stream) {
+      if (b->ev_last_valid && !b->last_was_lanes) {
+        HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
+        for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_last, 0));
+      }
+    } else {
+      HIPCHK(hipEventRecord(b->ev_fork, stream));
+      for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
+    }
+    const Sub &su = subs[0];
+    const SlotInfo &s0 = b->sched[su.first];
+    const long w = su.slots / 8;
+    for (int l = 0; l < ASDR_LANES; l++) {
+      const int lo = (int)(w * l / ASDR_LANES) * 8, cnt = (int)(w * (l + 1) / ASDR_LANES) * 8 - lo, first = su.first + lo;
+      UpdateArgs al = a;
+      al.sched = b->d_sched + first; al.n_sched = cnt;
+      al.direct_ch0 = s0.ch + lo; al.direct_mode = s0.mode; al.direct_flags = s0.flags; al.direct_lo = s0.lo;
+      al.lo_cache = b->d_lo + (size_t)(1 + l) * 2 * ASDR_LO_ENTRIES;   // this lane's own set: its wave 0 writes, its waves read
+      al.lo_write = 1u;
+      if (sam_split && su.kind == ASDR_KERNEL_SAM) al.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
+      if (sam_split && su.kind == ASDR_KERNEL_SAM_ALS) al.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
+      const int form = (als_split && su.kind == ASDR_KERNEL_ALS_SMALL) ? 2 : 1;
+      for (int lb = 0; lb < n_launch; lb++) {
+        if (per_block) {
+          al.in_i = dI + (size_t)lb * ASDR_N; al.in_q = dQ + (size_t)lb * ASDR_N; al.out = dOut + (size_t)lb * ASDR_N; al.n_blocks = 1;
+          al.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
+          al.als_phase = (b->als_phase + (uint32_t)lb) & 1u;
+          al.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
+        }
+        if (asdr_launch_update(&al, su.kind, form, b->lane[l]) != 0) return fail("update kernel launch failed");
+      }
+    }
+    if (!batch_stream) { if (lanes_join_into(b, stream) != 0) return -1; b->lanes_pending = false; b->last_was_lanes = false; b->last_stream = stream; }
+    else { b->lanes_pending = true; b->last_was_lanes = true; }
+    b->ev_last_valid = true; b->ev_valid = false; b->stat_lane_calls++;
+    if (b->region_calls >= 0) b->region_calls++;
+    b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
+    b->als_phase = (b->als_phase + (uint32_t)n_blocks) & 1u;
+    b->lo_parity ^= (uint32_t)(n_launch & 1);
+    return 0;
+  }
+  // This part's waves of every sub-range, as launch items.  A large item is cut into `launch_split` pieces on as many streams
+  // (asdr_set_launch_split): kernels of one stream run one after the other, each draining its last waves before the next starts;
+  // pieces on different streams fill each other's tails.
+  struct Item { int sub, first, slots; };
+  Item items[ASDR_AUX_STREAMS + 1]; int n_items = 0;
   for (int i = 0; i < n_sub; i++) {
     const long w = subs[i].slots / 8;
-    part_lo[i] = (int)(w * part / parts) * 8; part_n[i] = (int)(w * (part + 1) / parts) * 8 - part_lo[i];
-    n_live += part_n[i] > 0;
+    const int lo = (int)(w * part / parts) * 8, cnt = (int)(w * (part + 1) / parts) * 8 - lo;
+    if (cnt == 0) continue;
+    int pieces = 1;
+    if (b->launch_split > 1 && cnt / 8 >= b->launch_split_min_waves) pieces = std::min(b->launch_split, ASDR_AUX_STREAMS + 1 - n_items - (n_sub - 1 - i));
+    if (pieces < 1) pieces = 1;
+    for (int q = 0; q < pieces; q++) {
+      const int qlo = (int)((long)(cnt / 8) * q / pieces) * 8, qhi = (int)((long)(cnt / 8) * (q + 1) / pieces) * 8;
+      if (qhi > qlo && n_items < ASDR_AUX_STREAMS + 1) items[n_items++] = Item{i, subs[i].first + lo + qlo, qhi - qlo};
+    }
   }
-  if (part_n[main_sub] == 0) for (int i = 0; i < n_sub; i++) if (part_n[i] > part_n[main_sub]) main_sub = i;
+  int main_item = 0;
+  for (int i = 1; i < n_items; i++) if (items[i].slots > items[main_item].slots) main_item = i;
   for (int lb = 0; lb < n_launch; lb++) {
     if (per_block) {
       a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
@@ -1015,20 +1120,19 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
       a.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
       a.taps = (lb == n_launch - 1) ? taps : nullptr;   // the taps are those of the call's last block
     }
-    if (n_live > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
+    if (n_items > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
     int n_aux = 0;
-    for (int i = 0; i < n_sub; i++) {
-      if (part_n[i] == 0) continue;
-      const int first = subs[i].first + part_lo[i];
-      hipStream_t s = (i == main_sub) ? stream : b->aux[n_aux++];
-      if (i != main_sub) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
-      a.sched = b->d_sched + first; a.n_sched = part_n[i];
+    for (int it = 0; it < n_items; it++) {
+      const int i = items[it].sub, first = items[it].first;
+      hipStream_t s = (it == main_item) ? stream : b->aux[n_aux++];
+      if (it != main_item) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
+      a.sched = b->d_sched + first; a.n_sched = items[it].slots;
       a.direct_ch0 = -1;
       a.lo_write = 1u;   // the first wave of every settings group fills the group's entry of the other half of the local-oscillator cache
       if (subs[i].uniform && b->kind_direct[subs[i].kind]) {   // one key group of consecutive channels: no schedule reads in the waves
         const SlotInfo &s0 = b->sched[subs[i].first];
-        a.direct_ch0 = s0.ch + part_lo[i]; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo;
-        if (part_lo[i] > 0) a.lo_write = 0u;   // (a direct launch's wave 0 is the writer: only the part that holds the group's first wave)
+        a.direct_ch0 = s0.ch + (first - subs[i].first); a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo;
+        if (first != subs[i].first) a.lo_write = 0u;   // (a direct launch's wave 0 is the writer: only the piece that holds the group's first wave)
       }
       if (sam_split && subs[i].kind == ASDR_KERNEL_SAM)   // this sub-range's tiles (1 KB per slot, 8 slots per tile)
         a.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
@@ -1036,7 +1140,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
         a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
       const int form = (als_split && subs[i].kind == ASDR_KERNEL_ALS_SMALL && subs[i].uniform) ? 2 : subs[i].uniform;
       if (asdr_launch_update(&a, subs[i].kind, form, s) != 0) return fail("update kernel launch failed");
-      if (i != main_sub) HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
+      if (it != main_item) HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
     }
     for (int j = 0; j < n_aux; j++) HIPCHK(hipStreamWaitEvent(stream, b->ev_join[j], 0));   // behind the caller's stream's own launch
   }
@@ -1045,7 +1149,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   b->ev_last_valid = true;
   b->ev_valid = (e0 != nullptr && e0 == b->ev0);
   if (b->region_calls >= 0) b->region_calls++;
-  b->last_stream = stream;
+  b->last_stream = stream; b->last_was_lanes = false;
   b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
   b->als_phase = (b->als_phase + (uint32_t)n_blocks) & 1u;
   b->lo_parity ^= (uint32_t)(n_launch & 1);
@@ -1135,7 +1239,7 @@ int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, 
   if (n_blocks == 0) return 0;
   if (!host_out) return fail("null output");
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
+  if (sync_all(b) != 0) return -1;
   HIPCHK(hipMemcpy(host_out, b->d_capture + ((size_t)ch * b->capture_cap + first_block) * ASDR_N,
                    (size_t)n_blocks * ASDR_N * sizeof(int16_t), hipMemcpyDeviceToHost));
   return 0;
@@ -1353,6 +1457,51 @@ int asdr_host_unregister(void *p) {
   HIPCHK(hipHostUnregister(p));
   return 0;
 }
+int asdr_order_before(asdr_batch_t *b, void *stream_) {   // everything enqueued on `stream` from now on runs after the batch's calls so far
+  if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_order_before(sh_, stream_));
+  if (b->device == ASDR_NO_DEVICE) return 0;
+  if (stream_ == ASDR_STREAM_BATCH) return fail("asdr_order_before: name one of your own streams");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  if (b->lanes_pending && lanes_join_into(b, stream) != 0) return -1;
+  if (b->ev_last_valid && b->last_stream != stream && !b->last_was_lanes) {
+    HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
+    HIPCHK(hipStreamWaitEvent(stream, b->ev_last, 0));
+  }
+  return 0;
+}
+int asdr_order_after(asdr_batch_t *b, void *stream_) {   // the batch's calls on ASDR_STREAM_BATCH from now on run after everything enqueued on `stream` so far
+  if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_order_after(sh_, stream_));
+  if (b->device == ASDR_NO_DEVICE) return 0;
+  if (stream_ == ASDR_STREAM_BATCH) return fail("asdr_order_after: name one of your own streams");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipEventRecord(b->ev_fork, (hipStream_t)stream_));
+  for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
+  HIPCHK(hipStreamWaitEvent(b->stream, b->ev_fork, 0));
+  return 0;
+}
+long asdr_lane_calls(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_lane_calls; return t; }
+  return b ? b->stat_lane_calls : -1;
+}
+int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves) {
+  if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_set_lanes(sh_, on, min_waves));
+  if (b->device != ASDR_NO_DEVICE && b->lanes_pending) { HIPCHK(hipSetDevice(b->device)); if (sync_all(b) != 0) return -1; }
+  b->lanes_enabled = on != 0;
+  if (min_waves > 0) b->lanes_min_waves = std::max(2 * ASDR_LANES, min_waves);
+  return 0;
+}
+int asdr_set_launch_split(asdr_batch_t *b, int pieces, int min_waves) {
+  if (!b) return fail("null batch");
+  if (pieces < 1 || pieces > 8) return fail("launch split must be in 1..8");
+  FOR_SHARDS(b, asdr_set_launch_split(sh_, pieces, min_waves));
+  b->launch_split = pieces;
+  if (min_waves > 0) b->launch_split_min_waves = std::max(8, min_waves);
+  return 0;
+}
 int asdr_set_host_chunks(asdr_batch_t *b, int chunks) {
   if (!b) return fail("null batch");
   if (chunks < 0 || chunks > 4096) return fail("bad chunk count");
@@ -1372,8 +1521,7 @@ int asdr_synchronize(asdr_batch_t *b) {
   FOR_SHARDS(b, asdr_synchronize(sh_));
   if (b->device == ASDR_NO_DEVICE) return 0;
   HIPCHK(hipSetDevice(b->device));
-  HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if (sync_all(b) != 0) return -1;
   return check_stream_error(b);
 }
 
@@ -1399,7 +1547,13 @@ int asdr_region_timing_begin(asdr_batch_t *b, void *stream_) {
   if (is_sharded(b)) return fail("region timing is per device: use the shard handles (asdr_shard)");
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
-  b->region_stream = (hipStream_t)stream_;
+  if (stream_ == ASDR_STREAM_BATCH) {   // the batch's own lanes: the region starts / ends when BOTH are there (lane 0 waits for lane 1)
+    b->region_stream = b->lane[0];
+    HIPCHK(hipEventRecord(b->ev_lane[1], b->lane[1]));
+    HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[1], 0));
+  } else {
+    b->region_stream = (hipStream_t)stream_;
+  }
   HIPCHK(hipEventRecord(b->rev0, b->region_stream));
   b->region_calls = 0;
   return 0;
@@ -1410,6 +1564,14 @@ int asdr_region_timing_end(asdr_batch_t *b, float *ms_total, long *n_calls) {
   if (is_sharded(b)) return fail("region timing is per device: use the shard handles (asdr_shard)");
   if (b->region_calls < 0) return fail("asdr_region_timing_end without asdr_region_timing_begin");
   HIPCHK(hipSetDevice(b->device));
+  if (b->region_stream == b->lane[0]) {
+    if (!b->last_was_lanes && b->ev_last_valid) {   // the region's last call ran the ordinary way, on the batch's stream: behind that, too
+      HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
+      HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_last, 0));
+    }
+    HIPCHK(hipEventRecord(b->ev_lane[1], b->lane[1]));
+    HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[1], 0));
+  }
   HIPCHK(hipEventRecord(b->rev1, b->region_stream));
   HIPCHK(hipEventSynchronize(b->rev1));
   float ms = 0.0f;
@@ -1685,7 +1847,7 @@ int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on) {
   const bool want = on != 0;
   if (want && !b->exact_unknown_mode && b->device != ASDR_NO_DEVICE) {   // rows not kept meanwhile: silence until a block stores them again
     HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipStreamSynchronize(b->last_stream));
+    if (sync_all(b) != 0) return -1;
     HIPCHK(hipMemset(b->d_audio_prev, 0, ((size_t)b->n + 1) * 128 * sizeof(float)));
   }
   b->exact_unknown_mode = want;

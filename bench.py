@@ -6,7 +6,11 @@ Default workload (`--config c2`, weak scaling: channels shard embarrassingly, no
   USB demodulation, noise blanker on (default threshold 1.2), IF band-pass, complex mixer,
   257-tap Hilbert, audio IIR filter enabled (bw2700), AGC default, ALS off.
   int16 I/Q rows and the int16 audio rows are resident in HBM before the timed region.
-A "step" is one asdr_update_device() call = one pass of the hot path over the whole batch.
+A "step" is one asdr_update_device() call = one pass of the hot path over the whole batch.  The calls go to ASDR_STREAM_BATCH
+(include/asdr.h): the batch's own streams, ordered against the batch's other calls only -- a batch of one settings group then runs
+its two halves as two never-joined lanes, so that one launch's tail is filled by the next launch of the other half.  The same
+steps on a caller's stream (every call ordered behind the previous one as a whole) are timed right after the headline region and
+reported as `roofline.caller_stream_ordered` (`--caller-stream` makes that the headline instead).
 
 The other two BASELINE configs that need more than one GPU are selectable, so that the driver's one command covers them
 (strong scaling: the job is fixed, --gpus N ranks each take 1/N of its channels):
@@ -417,6 +421,8 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="one process, N GPUs through a sharded batch (asdr_create_sharded)")
     ap.add_argument("--devices", type=str, default=None, help="--single-process: comma-separated device ordinals, one per shard")
     ap.add_argument("--no-host-path", action="store_true", help="skip the h2d_d2h_inclusive measurement")
+    ap.add_argument("--caller-stream", action="store_true",
+                    help="launch on torch's current stream (strict stream order) instead of ASDR_STREAM_BATCH")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.steps is None:
@@ -494,7 +500,8 @@ def main():
 
     if not args.dry_run:
         import audiosdr_amd as A
-        stream = torch.cuda.current_stream().cuda_stream
+        caller_stream = torch.cuda.current_stream().cuda_stream
+        stream = caller_stream if args.caller_stream else A.STREAM_BATCH
         if args.config == "c2":
             dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, channel0=ch0, fc=6290.0, A=0.25)
         elif args.config == "c4":
@@ -548,10 +555,21 @@ def main():
     wall = t1 - t0
     k_ms = region_ms / max(1, region_calls) if batch is not None else 0.0
     pair_ms = None
+    ordered = None
+    lane_calls = batch.lane_calls() if batch is not None else 0
     if batch is not None and args.config == "c2":
+        if not args.caller_stream:   # the same steps in strict stream order, on a caller's stream
+            def cs_step(i):
+                b = i % N_INPUT_BLOCKS
+                batch.update_device(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, caller_stream)
+            ms_o = measure_region(batch, cs_step, caller_stream, 50, min(args.steps, 600))
+            ach_o = ALGO_BYTES_PER_BLOCK * n_ch / (ms_o * 1e-3) / 1e9
+            ordered = {"kernel_ms": round(ms_o, 5), "frac": round(ach_o / HBM_PEAK_GBS, 4), "Msamples_per_s": round(n_ch * BLOCK / ms_o / 1e3, 1),
+                       "what": "the same calls on a caller's stream: every call is ordered behind the whole previous call, one kernel "
+                               "per step, no lanes (one HIP-event pair around %d steps after 50 untimed ones)" % min(args.steps, 600)}
         batch.kernel_timing_begin(40)
         for i in range(40):
-            step(i)
+            batch.update_device(dI[i % N_INPUT_BLOCKS].data_ptr(), dQ[i % N_INPUT_BLOCKS].data_ptr(), dOut.data_ptr(), 1, caller_stream)
         pair_ms = float(np.mean(batch.kernel_timing_end(40)))
     if dist is not None:
         tw = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -609,6 +627,9 @@ def main():
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 5),
                          "kernel_ms_method": "one HIP-event pair on the launch stream around the %d timed steps / %d" % (args.steps, args.steps),
+                         "launch_stream": "caller's stream (strict stream order)" if args.caller_stream else
+                                          "ASDR_STREAM_BATCH: the batch's own streams; %d of the %d untimed + timed calls ran as two never-joined lanes (halves of the channel range)" % (lane_calls, untimed + args.steps),
+                         "caller_stream_ordered": ordered,
                          "kernel_ms_event_pair_per_launch": None if pair_ms is None else round(pair_ms, 5),
                          "algorithmic_bytes_per_channel_block": round(cfg["algo"], 1),
                          "algorithmic_bytes_per_launch": int(round(algo))},

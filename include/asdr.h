@@ -110,6 +110,25 @@ int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, in
  * per-channel audio row without repacking.  All three pointers must be 16-byte aligned. */
 int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
                                long in_stride_blocks, long out_stride_blocks, void *stream);
+/* `stream` = ASDR_STREAM_BATCH: the call runs on streams of the batch's own and is ordered ONLY against the batch's other calls
+ * (and against host-side synchronisation: asdr_synchronize, the status / capture readers).  Ordering against the caller's streams
+ * is the caller's, through
+ *   asdr_order_after(b, s)    the batch's later ASDR_STREAM_BATCH calls run after everything enqueued on s so far (inputs produced there)
+ *   asdr_order_before(b, s)   everything enqueued on s from now on runs after the batch's calls so far (results consumed there)
+ * What that buys: kernels of one stream run strictly one after the other, and each ends with a tail in which its last waves drain
+ * and the GPU runs empty.  A batch whose schedule is one settings group of consecutive channels (every channel configured alike:
+ * BASELINE configs 2 and 5) runs its two halves on two such streams ("lanes") that never wait for each other: half A of block k + 1
+ * starts when half A of block k is done, while half B of block k still drains -- 0.121 -> 0.111 ms per step of 65,536 channels
+ * (tools/split_probe.py).  On a caller's stream the same happens INSIDE a multi-block call of a large batch (issued as one launch per
+ * block and joined at its end); from call to call it cannot, because the caller may have enqueued anything in between.  Results are
+ * bit-identical either way (the halves touch disjoint channels; each lane has its own local-oscillator cache entries).
+ * asdr_lane_calls() = calls that ran on the lanes so far; asdr_set_lanes(b, on, min_waves) switches them off / moves the smallest
+ * batch (in waves of 8 channels, default 1024) that uses them; environment ASDR_NO_LANES=1 at asdr_create time = default off. */
+#define ASDR_STREAM_BATCH ((void *)(intptr_t)-1)
+int asdr_order_after(asdr_batch_t *b, void *stream);
+int asdr_order_before(asdr_batch_t *b, void *stream);
+long asdr_lane_calls(asdr_batch_t *b);
+int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves);
 int asdr_synchronize(asdr_batch_t *b);
 
 /* ---- capture sink (the continuous receive loop of EXTRAS/BareBonesWSPR/BareBonesWSPR.ino:
@@ -274,6 +293,12 @@ long asdr_stream_pipeline_recoveries(asdr_batch_t *b);
 long asdr_stream_pipeline_alloc_failures(asdr_batch_t *b);
 int asdr_stream_pipeline_max_groups(asdr_batch_t *b);
 int asdr_set_stream_pipeline(asdr_batch_t *b, int on);
+/* Large sub-ranges of the schedule as SEVERAL kernels on as many streams (bit-identical results: the pieces touch disjoint channels).
+ * Kernels of one stream run one after the other and each drains its last waves before the next may start; pieces on different streams
+ * fill each other's tails.  pieces = 1..8 (1 = one kernel per sub-range), min_waves = the smallest sub-range (in waves of 8 channels)
+ * that is cut (<= 0: keep the current value, default 2048).  Default at asdr_create time: ASDR_LAUNCH_SPLIT_DEFAULT, or the environment
+ * (ASDR_LAUNCH_SPLIT, ASDR_LAUNCH_SPLIT_MIN_WAVES). */
+int asdr_set_launch_split(asdr_batch_t *b, int pieces, int min_waves);
 /* How a batch launches its SAM channels (bit-identical results): fused = 1 -> the fused 4-wave kernel always; otherwise the three
  * launches pre | PLL | post from split_min_channels SAM channels on (<= 0: the default, 512).  Defaults at asdr_create time from
  * the environment (ASDR_SAM_FUSED, ASDR_SAM_SPLIT_MIN): comparison switches of the measurement tools. */

@@ -45,6 +45,7 @@ class Hip:
         h.hipStreamSynchronize.argtypes = [C.c_void_p]
         h.hipStreamDestroy.argtypes = [C.c_void_p]
         h.hipFree.argtypes = [C.c_void_p]
+        h.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         self._bufs = []
 
     def malloc(self, nbytes):
@@ -58,6 +59,10 @@ class Hip:
         p = self.malloc(arr.nbytes)
         assert self.h.hipMemcpy(p, arr.ctypes.data_as(self.C.c_void_p), arr.nbytes, 1) == 0
         return p
+
+    def copy_async(self, dst, src, nbytes, kind, stream):
+        """hipMemcpyAsync (kind 1 = H2D, 2 = D2H); host side must be pinned for the copy to be truly asynchronous."""
+        assert self.h.hipMemcpyAsync(dst, src, int(nbytes), kind, stream) == 0
 
     def fill(self, ptr, byte, nbytes):
         assert self.h.hipMemset(ptr, byte, nbytes) == 0

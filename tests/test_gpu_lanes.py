@@ -1,0 +1,128 @@
+"""Lanes (include/asdr.h, ASDR_STREAM_BATCH): a batch of one settings group runs its two halves on two streams of its own that never
+wait for each other -- from call to call on ASDR_STREAM_BATCH, inside a multi-block call on a caller's stream.  Same kernels, same
+channels, only the launch geometry differs: every output and every status word must equal the ordinary path's, whatever the
+sequence of lane calls, ordinary calls, setters (which take a batch off the lanes for one call, or for good when the schedule stops
+being one group), stream switches and host-side reads in between."""
+import numpy as np
+import pytest
+
+from tests.helpers import Hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile(a, n):
+    return np.ascontiguousarray(np.tile(a, ((n + a.shape[0] - 1) // a.shape[0], 1, 1))[:n])
+
+
+def _twin(gpu, n, mode, audio=True):
+    out = []
+    for lanes in (True, False):
+        b = gpu.AudioSDRBatch(n)
+        b.setDemodMode(mode)
+        if audio:
+            b.enableAudioFilter()
+        b.setNoiseBlankerThresholdDb(10.0)
+        b.set_lanes(lanes)
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize("mode,n", [(1, 16384 + 8), (4, 9000), (5, 8192)])
+def test_lane_calls_equal_ordinary_calls(gpu, ao, mode, n):
+    from audiosdr_amd.synth import make_iq
+    uniq, total = 96, 22
+    fc = 6890.0 - (600.0 if mode == 1 else 0.0) + 20.0 * (np.arange(uniq) % 5)
+    bI, bQ = make_iq(uniq, total, fc=fc, A=0.3, m=0.4 if mode != 1 else 0.0, noise=0.02, impulse_every=1700)
+    I, Q = _tile(bI, n), _tile(bQ, n)
+    hip = Hip()
+    s1, s2 = hip.stream(), hip.stream()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    A, B = _twin(gpu, n, mode)
+    dA, dB = hip.malloc(n * total * 256), hip.malloc(n * total * 256)
+    BATCH = gpu.STREAM_BATCH
+    pos = 0
+
+    def both(T, stream_a, stream_b=0):
+        nonlocal pos
+        off = pos * 256
+        A.update_device_strided(dI + off, dQ + off, dA + off, T, total, total, stream_a)
+        B.update_device_strided(dI + off, dQ + off, dB + off, T, total, total, stream_b)
+        pos += T
+
+    lane_calls = 0
+    both(1, BATCH)                     # the first call applies the construction's setters and resets: ordinary
+    both(1, BATCH); lane_calls += 1
+    both(1, BATCH); lane_calls += 1
+    both(1, s1, s1)                    # a caller's stream in between: ordered behind the lanes
+    both(3, BATCH); lane_calls += 1    # multi-block on the lanes
+    both(1, BATCH); lane_calls += 1
+    assert A.lane_calls() == lane_calls and B.lane_calls() == 0
+    for b in (A, B):
+        b.setOutputGain(0.7, ch=5)     # a parameter row changes: one ordinary call (it flushes), then the lanes again
+    both(1, BATCH)
+    both(2, BATCH); lane_calls += 1
+    both(4, s2, s2)                    # a multi-block call on a caller's stream: lanes inside it when it is large enough for one launch per block
+    if n >= 8192 or mode == 5:
+        lane_calls += 1
+    assert A.lane_calls() == lane_calls, (A.lane_calls(), lane_calls)
+    st = A.read_status()               # host-side read: synchronises the lanes
+    for b in (A, B):
+        b.setDemodMode(0, ch=n // 2)   # two settings groups from now on: no lanes
+    both(2, BATCH)
+    both(1, BATCH)
+    assert A.lane_calls() == lane_calls
+    for b in (A, B):
+        b.setDemodMode(mode, ch=n // 2)
+    both(1, BATCH)
+    both(2, BATCH); lane_calls += 1
+    assert A.lane_calls() == lane_calls and pos == total
+    A.synchronize(); B.synchronize()
+    wA = hip.download(dA, (n, total, 128), np.int16)
+    wB = hip.download(dB, (n, total, 128), np.int16)
+    assert np.array_equal(wA, wB), "%d samples differ" % int((wA != wB).sum())
+    sA, sB = A.read_status(), B.read_status()
+    for k in sA:
+        assert sA[k].tobytes() == sB[k].tobytes(), k
+    # ... and the ordinary path is the oracle's: three channels of the first tile, all blocks up to the LSB excursion
+    for c in (0, 5, 37):
+        o = ao.OracleSDR()
+        o.setDemodMode(mode); o.enableAudioFilter(); o.setNoiseBlankerThresholdDb(10.0)
+        w1 = o.update(bI[c, :8], bQ[c, :8]).reshape(8, 128)
+        if c == 5:
+            o.setOutputGain(0.7)
+        w2 = o.update(bI[c, 8:], bQ[c, 8:]).reshape(total - 8, 128)
+        assert np.array_equal(wA[c], np.concatenate([w1, w2])), c
+    hip.free_all(); A.close(); B.close()
+
+
+def test_ordering_against_a_callers_stream(gpu):
+    """asdr_order_after / asdr_order_before: input uploaded asynchronously on the caller's stream, result downloaded on it, the
+    batch's calls on ASDR_STREAM_BATCH in between -- repeated with fresh data each round into the SAME device buffers, so that a
+    missing ordering edge shows as a stale or torn block."""
+    from audiosdr_amd.synth import make_iq
+    n, rounds = 16384, 6
+    bI, bQ = make_iq(64, rounds, fc=6290.0, A=0.25, noise=0.02, impulse_every=900)
+    hip = Hip()
+    s = hip.stream()
+    A, B = _twin(gpu, n, 1)
+    hI, hQ, hO = (gpu.host_alloc((n, 1, 128)) for _ in range(3))
+    dI, dQ, dO = hip.malloc(n * 256), hip.malloc(n * 256), hip.malloc(n * 256)
+    got = []
+    for r in range(rounds):
+        hip.sync(s)                                           # (the host buffers are reused: the previous round's copies are done)
+        hI[:] = _tile(bI[:, r:r + 1], n); hQ[:] = _tile(bQ[:, r:r + 1], n)
+        hip.copy_async(dI, hI.ctypes.data, n * 256, 1, s); hip.copy_async(dQ, hQ.ctypes.data, n * 256, 1, s)
+        A.order_after(s)
+        A.update_device(dI, dQ, dO, 1, gpu.STREAM_BATCH)
+        A.order_before(s)
+        hip.copy_async(hO.ctypes.data, dO, n * 256, 2, s)
+        hip.sync(s)
+        got.append(hO.copy())
+    assert A.lane_calls() == rounds - 1
+    want = B.update(_tile(bI, n), _tile(bQ, n))
+    for r in range(rounds):
+        assert np.array_equal(got[r][:, 0], want[:, r]), r
+    for a in (hI, hQ, hO):
+        gpu.host_free(a)
+    hip.free_all(); A.close(); B.close()

@@ -157,7 +157,7 @@ def test_sharded_device_pointers_capture_and_shard_handles(gpu):
     hip = Hip()
     dI, dQ = hip.upload(I), hip.upload(Q)
     d1, d2, d3 = hip.malloc(n * nb * 256), hip.malloc(n * nb * 256), hip.malloc(n * nb * 256)
-    one.update_device(dI, dQ, d1, 4); one.update_device_strided(dI + 4 * 256, dQ + 4 * 256, d1 + 4 * 256, nb - 4, nb, nb)
+    one.update_device_strided(dI, dQ, d1, 4, nb, nb); one.update_device_strided(dI + 4 * 256, dQ + 4 * 256, d1 + 4 * 256, nb - 4, nb, nb)
     # (a) global device rows on the sharded handle (all shards on the device that owns the pointers)
     sh.update_device_strided(dI, dQ, d2, 4, nb, nb)
     # (b) then shard by shard, local rows, as a multi-GPU host would (asdr_shard): the remaining blocks
