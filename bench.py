@@ -512,14 +512,16 @@ def main():
             dI, dQ = tiled_input(np, torch, dev, n_ch, T, n_ch, channel0=ch0, per_block=False, fc=6890.0, A=0.02, noise=0.05)
         if args.config != "c5":
             dOut = torch.empty((n_ch, BLOCK), dtype=torch.int16, device=dev)
-        # clock settling on a scratch batch (module docstring): the measured batch then gets exactly --warmup steps
-        if settle_min > 0:
-            batch = make_batch()
-            for i in range(settle_min):
-                _step(batch, i)
-            torch.cuda.synchronize()
-            batch.close()
+        # Clock settling on a scratch batch (module docstring): the measured batch gets exactly --warmup steps.  The measured batch
+        # is built FIRST: creating a batch (350 MB of state for c2) idles the GPU for tens of milliseconds, after which the first ~100
+        # launches run 10-25 % slow while the clocks come back (tools/warmup_curve.py) -- the settle launches must run right up to
+        # the measured batch's first step.
         batch = make_batch()
+        scratch = None
+        if settle_min > 0:
+            scratch = make_batch()
+            for i in range(settle_min):
+                _step(scratch, i)
 
     def step(i):
         if batch is not None:
@@ -553,6 +555,8 @@ def main():
     fence()
     t1 = time.perf_counter()
     wall = t1 - t0
+    if not args.dry_run and scratch is not None:
+        scratch.close()
     k_ms = region_ms / max(1, region_calls) if batch is not None else 0.0
     pair_ms = None
     ordered = None

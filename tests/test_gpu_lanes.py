@@ -31,7 +31,7 @@ def _twin(gpu, n, mode, audio=True):
 @pytest.mark.parametrize("mode,n", [(1, 16384 + 8), (4, 9000), (5, 8192)])
 def test_lane_calls_equal_ordinary_calls(gpu, ao, mode, n):
     from audiosdr_amd.synth import make_iq
-    uniq, total = 96, 22
+    uniq, total = 96, 21
     fc = 6890.0 - (600.0 if mode == 1 else 0.0) + 20.0 * (np.arange(uniq) % 5)
     bI, bQ = make_iq(uniq, total, fc=fc, A=0.3, m=0.4 if mode != 1 else 0.0, noise=0.02, impulse_every=1700)
     I, Q = _tile(bI, n), _tile(bQ, n)
