@@ -224,8 +224,8 @@ struct asdr_batch {
   // still drains its last waves (kernels of one stream run strictly one after the other, each with a tail in which the GPU runs
   // empty: 0.121 -> 0.111 ms per C2 step, tools/split_probe.py).  Inside a multi-block call (which joins at its end) always; from
   // call to call only for calls on ASDR_STREAM_BATCH, whose contract leaves the ordering against other streams to the caller.
-  hipStream_t lane[ASDR_LANES] = {};
-  hipEvent_t ev_lane[ASDR_LANES] = {};
+  hipStream_t lane[ASDR_LANES + 1] = {};   // [ASDR_LANES] = the stream of the sub-ranges that are not cut (the remainders' few long-lived waves)
+  hipEvent_t ev_lane[ASDR_LANES + 1] = {};
   bool lanes_pending = false;            // the lanes hold launches that nothing has been ordered behind yet
   bool last_was_lanes = false;           // the previous call ran on the lanes (asdr_update_device on ASDR_STREAM_BATCH)
   int lanes_min_waves = 1024;            // smallest sub-range that is run as lanes
@@ -540,6 +540,19 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       }
       i = j;
     }
+    // lane 1's writers: in every uniform sub-range, the first wave of each settings group at or behind the start of lane 1's half
+    // (the launcher's split: waves [w l / ASDR_LANES, w (l + 1) / ASDR_LANES) of the sub-range)
+    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
+      const int w = b->kind_uniform_slots[k] / 8, mid = b->kind_first[k] + (int)((long)w * 1 / ASDR_LANES) * 8, end = b->kind_first[k] + b->kind_uniform_slots[k];
+      uint32_t seen = 0;   // entries (ids 1..8) that already have their lane-1 writer
+      for (int sl = mid; sl < end; sl += 8) {
+        const uint32_t id = b->sched[sl].lo & 0xFFu;
+        if (id == 0u || (seen >> id) & 1u) continue;
+        // (a group's waves are consecutive: the first one met behind `mid` is the group's first wave in lane 1)
+        seen |= 1u << id;
+        for (int t = 0; t < 8; t++) b->sched[sl + t].lo |= ASDR_LO_WRITER_LANE1;
+      }
+    }
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
       const SlotInfo *sl = b->sched.data() + b->kind_first[k];
       bool direct = b->kind_uniform_slots[k] > 0;
@@ -612,7 +625,7 @@ void fill_args(asdr_batch *b, UpdateArgs &a) {
   a.sched = b->d_sched; a.n_sched = 0; a.n_channels = b->n;   // the launcher sets the sub-range
   a.taps = b->taps_on ? b->d_taps : nullptr;
   a.nb_phase = b->nb_phase; a.als_phase = b->als_phase;
-  a.lo_cache = b->d_lo; a.lo_parity = b->lo_parity; a.lo_write = 0;
+  a.lo_cache = b->d_lo; a.lo_parity = b->lo_parity; a.lo_write = 0; a.lo_writer_bit = ASDR_LO_WRITER;
   a.k = b->k;
 }
 
@@ -670,14 +683,14 @@ bool needs_flush(const asdr_batch *b) {
 }
 // everything the lanes hold so far happens before whatever is enqueued on `stream` from now on
 int lanes_join_into(asdr_batch *b, hipStream_t stream) {
-  for (int l = 0; l < ASDR_LANES; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(stream, b->ev_lane[l], 0)); }
+  for (int l = 0; l < ASDR_LANES + 1; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(stream, b->ev_lane[l], 0)); }
   return 0;
 }
 // host-side: every launch of the batch so far is complete
 int sync_all(asdr_batch *b) {
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (b->lanes_pending) { for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamSynchronize(b->lane[l])); b->lanes_pending = false; }
+  if (b->lanes_pending) { for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamSynchronize(b->lane[l])); b->lanes_pending = false; }
   return 0;
 }
 
@@ -753,7 +766,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
     alloc((void **)&b->d_lo, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry));   // + one set per lane: a lane's readers only ever see its own writer
     if (ok && hipMemset(b->d_lo, 0xFF, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
-    for (int i = 0; i < ASDR_LANES && ok; i++) {
+    for (int i = 0; i < ASDR_LANES + 1 && ok; i++) {
       if (hipStreamCreateWithFlags(&b->lane[i], hipStreamNonBlocking) != hipSuccess) ok = false;
       if (ok && hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     }
@@ -875,7 +888,7 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->ev_last) hipEventDestroy(b->ev_last);
   if (b->ev_fork) hipEventDestroy(b->ev_fork);
   for (int i = 0; i < ASDR_AUX_STREAMS; i++) { if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]); if (b->aux[i]) hipStreamDestroy(b->aux[i]); }
-  for (int i = 0; i < ASDR_LANES; i++) { if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]); if (b->lane[i]) hipStreamDestroy(b->lane[i]); }
+  for (int i = 0; i < ASDR_LANES + 1; i++) { if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]); if (b->lane[i]) hipStreamDestroy(b->lane[i]); }
   if (b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -905,11 +918,11 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   // way (it synchronises anyway), the next one is back on the lanes.
   bool use_lanes = false;
   if (parts == 1 && b->lanes_enabled && !needs_flush(b) && (batch_stream || n_blocks >= 2) && !b->taps_on && b->tev.empty() && !b->time_calls) {
-    int n_kinds = 0, kind = -1;
-    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) if (b->kind_slots[k] > 0) { n_kinds++; kind = k; }
-    use_lanes = n_kinds == 1 && b->left_slots == 0 && b->kind_uniform_slots[kind] == b->kind_slots[kind] && b->kind_direct[kind] &&
-                b->kind_slots[kind] / 8 >= b->lanes_min_waves &&
-                (batch_stream || b->kind_slots[kind] >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES || b->sam_split || b->als_split);   // (a strict call: only in its one-launch-per-block form)
+    int total = b->left_slots;
+    for (int k = 0; k < ASDR_KERNEL_KINDS; k++) total += b->kind_slots[k];
+    use_lanes = total / 8 >= b->lanes_min_waves &&
+                (batch_stream || total >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES || (b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS] > 0) ||
+                 (b->als_split && b->kind_uniform_slots[ASDR_KERNEL_ALS_SMALL] > 0));   // (a strict call: only in its one-launch-per-block form)
   }
   if (!use_lanes && b->lanes_pending) {   // an ordinary call after calls on the lanes: behind them
     if (needs_flush(b)) { if (sync_all(b) != 0) return -1; }   // (the flush rewrites rows the lanes' kernels read)
@@ -1055,33 +1068,39 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     if (batch_stream) {
       if (b->ev_last_valid && !b->last_was_lanes) {
         HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
-        for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_last, 0));
+        for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_last, 0));
       }
     } else {
       HIPCHK(hipEventRecord(b->ev_fork, stream));
-      for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
+      for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
     }
-    const Sub &su = subs[0];
-    const SlotInfo &s0 = b->sched[su.first];
-    const long w = su.slots / 8;
-    for (int l = 0; l < ASDR_LANES; l++) {
-      const int lo = (int)(w * l / ASDR_LANES) * 8, cnt = (int)(w * (l + 1) / ASDR_LANES) * 8 - lo, first = su.first + lo;
-      UpdateArgs al = a;
-      al.sched = b->d_sched + first; al.n_sched = cnt;
-      al.direct_ch0 = s0.ch + lo; al.direct_mode = s0.mode; al.direct_flags = s0.flags; al.direct_lo = s0.lo;
-      al.lo_cache = b->d_lo + (size_t)(1 + l) * 2 * ASDR_LO_ENTRIES;   // this lane's own set: its wave 0 writes, its waves read
-      al.lo_write = 1u;
-      if (sam_split && su.kind == ASDR_KERNEL_SAM) al.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
-      if (sam_split && su.kind == ASDR_KERNEL_SAM_ALS) al.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
-      const int form = (als_split && su.kind == ASDR_KERNEL_ALS_SMALL) ? 2 : 1;
+    for (int l = 0; l < ASDR_LANES + 1; l++) {
       for (int lb = 0; lb < n_launch; lb++) {
-        if (per_block) {
-          al.in_i = dI + (size_t)lb * ASDR_N; al.in_q = dQ + (size_t)lb * ASDR_N; al.out = dOut + (size_t)lb * ASDR_N; al.n_blocks = 1;
-          al.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
-          al.als_phase = (b->als_phase + (uint32_t)lb) & 1u;
-          al.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
+        for (int i = 0; i < n_sub; i++) {   // this lane's half of every uniform sub-range, one kernel after the other on the lane's stream;
+          const Sub &su = subs[i];          // the general-kernel sub-ranges (the remainders: a few long-lived waves) whole, on the stream behind the lanes
+          const long w = su.slots / 8;
+          int lo = (int)(w * l / ASDR_LANES) * 8, cnt = (int)(w * (l + 1) / ASDR_LANES) * 8 - lo;
+          if (l == ASDR_LANES) { lo = 0; cnt = su.uniform ? 0 : su.slots; } else if (!su.uniform) cnt = 0;
+          const int first = su.first + lo;
+          if (cnt == 0) continue;
+          UpdateArgs al = a;
+          al.sched = b->d_sched + first; al.n_sched = cnt;
+          al.direct_ch0 = -1;
+          if (su.uniform && b->kind_direct[su.kind]) { const SlotInfo &s0 = b->sched[su.first]; al.direct_ch0 = s0.ch + lo; al.direct_mode = s0.mode; al.direct_flags = s0.flags; al.direct_lo = s0.lo; }
+          al.lo_cache = b->d_lo + (size_t)(1 + (l % ASDR_LANES)) * 2 * ASDR_LO_ENTRIES;   // this lane's own set: its writers fill it, its waves read it (general-kernel waves have no entry)
+          al.lo_write = 1u;
+          al.lo_writer_bit = (l == 0) ? ASDR_LO_WRITER : ASDR_LO_WRITER_LANE1;   // (a direct launch: its wave 0, under either name)
+          if (sam_split && su.kind == ASDR_KERNEL_SAM) al.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
+          if (sam_split && su.kind == ASDR_KERNEL_SAM_ALS) al.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
+          const int form = (als_split && su.kind == ASDR_KERNEL_ALS_SMALL && su.uniform) ? 2 : su.uniform;
+          if (per_block) {
+            al.in_i = dI + (size_t)lb * ASDR_N; al.in_q = dQ + (size_t)lb * ASDR_N; al.out = dOut + (size_t)lb * ASDR_N; al.n_blocks = 1;
+            al.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
+            al.als_phase = (b->als_phase + (uint32_t)lb) & 1u;
+            al.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
+          }
+          if (asdr_launch_update(&al, su.kind, form, b->lane[l]) != 0) return fail("update kernel launch failed");
         }
-        if (asdr_launch_update(&al, su.kind, form, b->lane[l]) != 0) return fail("update kernel launch failed");
       }
     }
     if (!batch_stream) { if (lanes_join_into(b, stream) != 0) return -1; b->lanes_pending = false; b->last_was_lanes = false; b->last_stream = stream; }
@@ -1478,7 +1497,7 @@ int asdr_order_after(asdr_batch_t *b, void *stream_) {   // the batch's calls on
   if (stream_ == ASDR_STREAM_BATCH) return fail("asdr_order_after: name one of your own streams");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipEventRecord(b->ev_fork, (hipStream_t)stream_));
-  for (int l = 0; l < ASDR_LANES; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
+  for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
   HIPCHK(hipStreamWaitEvent(b->stream, b->ev_fork, 0));
   return 0;
 }
@@ -1549,8 +1568,7 @@ int asdr_region_timing_begin(asdr_batch_t *b, void *stream_) {
   HIPCHK(hipSetDevice(b->device));
   if (stream_ == ASDR_STREAM_BATCH) {   // the batch's own lanes: the region starts / ends when BOTH are there (lane 0 waits for lane 1)
     b->region_stream = b->lane[0];
-    HIPCHK(hipEventRecord(b->ev_lane[1], b->lane[1]));
-    HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[1], 0));
+    for (int l = 1; l < ASDR_LANES + 1; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[l], 0)); }
   } else {
     b->region_stream = (hipStream_t)stream_;
   }
@@ -1569,8 +1587,7 @@ int asdr_region_timing_end(asdr_batch_t *b, float *ms_total, long *n_calls) {
       HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
       HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_last, 0));
     }
-    HIPCHK(hipEventRecord(b->ev_lane[1], b->lane[1]));
-    HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[1], 0));
+    for (int l = 1; l < ASDR_LANES + 1; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[l], 0)); }
   }
   HIPCHK(hipEventRecord(b->rev1, b->region_stream));
   HIPCHK(hipEventSynchronize(b->rev1));

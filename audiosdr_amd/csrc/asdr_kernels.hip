@@ -973,7 +973,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   int4 slot = make_int4(a.n_channels, 0, 0, 0);
-  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, (int)((a.direct_lo & 0xFFu) | (wave_g == 0 ? ASDR_LO_WRITER : 0u)));
+  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, (int)((a.direct_lo & 0xFFu) | (wave_g == 0 ? a.lo_writer_bit : 0u)));
   else if (WAVES == 1 || wave_g * 8 < a.n_sched) slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
   else { const ChanParams *pd = a.params + a.n_channels; slot.y = (int)pd->mode; slot.z = (int)pd->flags; }   // padding wave of a multi-wave workgroup: dummy channel
   const int ch_ = slot.x;
@@ -2192,7 +2192,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     else { store_status_bits(ASDR_S_AGC_ACTIVE); sig_pending = (uint32_t)blk + 1u; }
     WAVE_SYNC();
     // The first wave of every settings group leaves the NEXT block's local-oscillator pairs in the group's entry of the other half (LoEntry).
-    if (a.lo_write && ROLE != 2 && (lo_slot & ASDR_LO_WRITER) && (lo_slot & 0xFFu) != 0u && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
+    if (a.lo_write && ROLE != 2 && (lo_slot & a.lo_writer_bit) && (lo_slot & 0xFFu) != 0u && blk == a.n_blocks - 1 && mix_uni && __all(mix_early)) {
       uint32_t lo_wi = ((a.lo_parity & 1u) ^ 1u) * ASDR_LO_ENTRIES + lo_e;
       asm volatile("" : "+v"(lo_wi));   // the entry's address is formed HERE (hoisted, it sits in a VGPR pair for the whole kernel)
       LoEntry *lo_wr = a.lo_cache + lo_wi;

@@ -1,4 +1,4 @@
-"""Lanes (include/asdr.h, ASDR_STREAM_BATCH): a batch of one settings group runs its two halves on two streams of its own that never
+"""Lanes (include/asdr.h, ASDR_STREAM_BATCH): a batch runs the two halves of every sub-range of its schedule on two streams of its own that never
 wait for each other -- from call to call on ASDR_STREAM_BATCH, inside a multi-block call on a caller's stream.  Same kernels, same
 channels, only the launch geometry differs: every output and every status word must equal the ordinary path's, whatever the
 sequence of lane calls, ordinary calls, setters (which take a batch off the lanes for one call, or for good when the schedule stops
@@ -68,9 +68,9 @@ def test_lane_calls_equal_ordinary_calls(gpu, ao, mode, n):
     assert A.lane_calls() == lane_calls, (A.lane_calls(), lane_calls)
     st = A.read_status()               # host-side read: synchronises the lanes
     for b in (A, B):
-        b.setDemodMode(0, ch=n // 2)   # two settings groups from now on: no lanes
+        b.setDemodMode(0, ch=n // 2)   # several settings groups from now on (a general-kernel remainder wave among them): still lanes
     both(2, BATCH)
-    both(1, BATCH)
+    both(1, BATCH); lane_calls += 1
     assert A.lane_calls() == lane_calls
     for b in (A, B):
         b.setDemodMode(mode, ch=n // 2)
@@ -125,4 +125,46 @@ def test_ordering_against_a_callers_stream(gpu):
         assert np.array_equal(got[r][:, 0], want[:, r]), r
     for a in (hI, hQ, hO):
         gpu.host_free(a)
+    hip.free_all(); A.close(); B.close()
+
+
+def test_lanes_on_a_mixed_schedule(gpu, ao):
+    """BASELINE config 4's mix (mode = channel mod 7, ALS notch, blanker at 10 dB): five kernel kinds' sub-ranges and the remainders,
+    each cut in two halves; lane 1 has its own local-oscillator cache writers.  Against the ordinary path on every channel and
+    against the oracle on two channels per mode."""
+    from audiosdr_amd.synth import make_iq
+    n, uniq, total = 12000 + 13, 7 * 16, 14
+    fc = 6890.0 - 300.0 + 15.0 * (np.arange(uniq) % 4)
+    bI, bQ = make_iq(uniq, total, fc=fc, A=0.3, m=0.4, noise=0.02, f2=fc + 610.0, a2=0.15, impulse_every=2100)
+    I, Q = _tile(bI, n), _tile(bQ, n)
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    pair = []
+    for lanes in (True, False):
+        b = gpu.AudioSDRBatch(n)
+        for m in range(7):
+            for c in range(m, n, 7):
+                b.setDemodMode(m, ch=c)
+        b.enableALSfilter(); b.setNoiseBlankerThresholdDb(10.0)
+        b.set_lanes(lanes)
+        pair.append(b)
+    A, B = pair
+    dA, dB = hip.malloc(n * total * 256), hip.malloc(n * total * 256)
+    pos = 0
+    for T, sa in ((1, gpu.STREAM_BATCH), (1, gpu.STREAM_BATCH), (3, gpu.STREAM_BATCH), (1, 0), (2, gpu.STREAM_BATCH), (4, 0), (1, gpu.STREAM_BATCH), (1, gpu.STREAM_BATCH)):
+        off = pos * 256
+        A.update_device_strided(dI + off, dQ + off, dA + off, T, total, total, sa)
+        B.update_device_strided(dI + off, dQ + off, dB + off, T, total, total, 0)
+        pos += T
+    assert pos == total and A.lane_calls() == 6 and B.lane_calls() == 0      # (the first call flushes; the 1-block call on stream 0 is ordinary)
+    A.synchronize(); B.synchronize()
+    wA, wB = hip.download(dA, (n, total, 128), np.int16), hip.download(dB, (n, total, 128), np.int16)
+    assert np.array_equal(wA, wB), "%d samples differ" % int((wA != wB).sum())
+    sA, sB = A.read_status(), B.read_status()
+    for k in sA:
+        assert sA[k].tobytes() == sB[k].tobytes(), k
+    for c in list(range(14)):                       # uniq is a multiple of 7: channel c of the tile has mode c mod 7
+        o = ao.OracleSDR()
+        o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
+        assert np.array_equal(wA[c], o.update(bI[c], bQ[c]).reshape(total, 128)), c
     hip.free_all(); A.close(); B.close()

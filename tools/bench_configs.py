@@ -51,7 +51,7 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
     # Steady state: the launches above are each preceded by an upload and followed by a download (the parity check needs the
     # outputs), so they start from an idle GPU -- ~15 % slower than back-to-back launches on resident buffers.  The same launch
     # repeated on the last resident input for >= 0.2 s, then timed with ONE event pair around the run (as bench.py does).
-    global STEADY_MS
+    global STEADY_MS, STEADY_BATCH_MS, LANE_CALLS
     one = max(1e-3, float(np.median(ms)))
     n_rep = int(min(4000, max(20, 250.0 / one)))
     for _ in range(n_rep):
@@ -62,10 +62,24 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
         batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
     total, calls = batch.region_timing_end()
     STEADY_MS = total / max(1, calls)
+    # ... and the same launches on the batch's own streams (ASDR_STREAM_BATCH: two never-joined lanes when the schedule is one group)
+    lc0 = batch.lane_calls()
+    batch.set_launch_timing(False)   # (an event pair around every call keeps it off the lanes)
+    for _ in range(n_rep):
+        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, A.STREAM_BATCH)
+    batch.synchronize()
+    batch.region_timing_begin(A.STREAM_BATCH)
+    for _ in range(n_rep):
+        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, A.STREAM_BATCH)
+    total, calls = batch.region_timing_end()
+    STEADY_BATCH_MS = total / max(1, calls)
+    LANE_CALLS = batch.lane_calls() - lc0
     return ms, np.concatenate(outs, axis=1)
 
 
 STEADY_MS = None
+STEADY_BATCH_MS = None
+LANE_CALLS = 0
 
 
 def check(configure, I, Q, got, channels):
@@ -85,6 +99,9 @@ def report(name, n_ch, T, ms, extra):
     if STEADY_MS is not None:   # back-to-back launches on resident buffers (see run_launches)
         out["steady_ms_per_launch"] = round(STEADY_MS, 5)
         out["steady_Msamples_per_s"] = round(n_ch * T * BLOCK / STEADY_MS / 1e3, 1)
+    if STEADY_BATCH_MS is not None:
+        out["steady_ms_per_launch_batch_stream"] = round(STEADY_BATCH_MS, 5)
+        out["lane_calls_in_that_run"] = LANE_CALLS
     out.update(extra)
     print(json.dumps(out), flush=True)
 
