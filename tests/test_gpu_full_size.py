@@ -261,3 +261,85 @@ def test_full_size_scattered_settings(gpu, ao):
         want = o.update(I[c % uniq], Q[c % uniq]).reshape(n_blk, BLOCK)
         assert np.array_equal(np.stack(got[c]), want), "channel %d (group %d)" % (c, grp[c])
     batch.close()
+
+
+def test_c4_whole_job_on_one_gpu(gpu, ao):
+    """BASELINE config 4 WHOLE on one GPU (what `bench.py --config c4` times at N = 1): 1,048,576 channels (the ABI's maximum),
+    mode = channel mod 7, ALS notch, blanker at 10 dB; 6 blocks: 4 on the batch's own streams (lanes: halves of every sub-range), one
+    on a caller's stream, and a final 2-block call.  Every channel equal to its duplicate (3,584 distinct inputs tiled, which keeps
+    the mode pattern: 3,584 = 7 x 512), two channels per mode bit-for-bit against the oracle -- from tiles at both ends of the batch,
+    i.e. from both lanes and across the 32-bit row-offset range."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, uniq, n_blk = 1048576, 3584, 6
+    I, Q = make_iq(uniq, n_blk, fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15, impulse_every=3000)
+    dI, dQ = _device_tiles(torch, I, Q, n_ch)
+    batch = gpu.AudioSDRBatch(n_ch)
+    L = gpu.load_library()
+    for c in range(n_ch):
+        L.asdr_setDemodMode(batch._h, c, c % 7)
+    batch.enableALSfilter(); batch.setNoiseBlankerThresholdDb(10.0)
+    dOut = torch.empty((n_ch, 2, BLOCK), dtype=torch.int16, device="cuda")
+    sample = list(range(14))
+    tiles = [0, 292]                                  # 292 * 3584 = 1,046,528: the last whole tile
+    got = {(c, t): [] for c in sample for t in tiles}
+
+    def collect(nb):
+        batch.synchronize()
+        for k in range(nb):
+            _assert_tiled(torch, dOut[:, k], uniq, "C4 whole job")
+            for (c, t) in got:
+                got[(c, t)].append(dOut[c + uniq * t, k].cpu().numpy().copy())
+
+    for b in range(4):
+        batch.update_device_strided(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, 1, 2, gpu.STREAM_BATCH if b != 2 else 0)
+        collect(1)
+    assert batch.lane_calls() == 2                    # (the first call flushes the setters; block 2 went to a caller's stream)
+    # the last two blocks as ONE two-block call (one launch per block inside it)
+    dI2 = torch.stack([dI[4], dI[5]], dim=1).contiguous(); dQ2 = torch.stack([dQ[4], dQ[5]], dim=1).contiguous()
+    batch.update_device(dI2.data_ptr(), dQ2.data_ptr(), dOut.data_ptr(), 2, 0)
+    collect(2)
+    for c in sample:
+        o = ao.OracleSDR()
+        o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
+        want = o.update(I[c], Q[c]).reshape(n_blk, BLOCK)
+        for t in tiles:
+            assert np.array_equal(np.stack(got[(c, t)]), want), "C4 channel %d of tile %d (mode %d)" % (c, t, c % 7)
+    batch.close()
+
+
+def test_c5_full_two_minute_slot(gpu, ao):
+    """BASELINE config 5, one GPU's share, the WHOLE 2-minute WSPR slot: 512 receivers x 41,344 blocks (BareBonesWSPR.ino:87-102,129
+    settings) streamed as 64 calls of 646 blocks into the capture sink (block pipeline), from a resident 646-block period whose
+    receivers differ in carrier offset and noise seed.  Four receivers' whole 5.3-million-sample capture rows bit-for-bit against the
+    oracle; the other rows through their checksums' distinctness (no two receivers carry the same audio) and the sink's bookkeeping."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, T, calls = 512, 646, 64
+
+    def cfg(s):
+        s.enableAGC(); s.setAGCmode(2); s.disableALSfilter(); s.disableNoiseBlanker(); s.setNoiseBlankerThresholdDb(10.0)
+        s.setInputGain(1.0); s.setOutputGain(0.5); s.setIQgainBalance(1.020); s.setAudioFilter(2); s.setDemodMode(6); s.setMute(0)
+
+    fc = 6890.0 - 5390.0 + 1500.0 + 1.4648 * (np.arange(n_ch) % 4)      # 4-FSK-like tone offsets (SURVEY.md 8d, C5)
+    I, Q = make_iq(n_ch, T, fc=fc, A=0.02, noise=0.05)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    batch = gpu.AudioSDRBatch(n_ch)
+    cfg(batch)
+    batch.capture_open(T * calls)
+    assert T * calls == 41344
+    for _ in range(calls):
+        batch.capture_update_device(dI.data_ptr(), dQ.data_ptr(), T, None, gpu.STREAM_BATCH)
+    batch.synchronize()
+    assert batch.capture_position == 41344 and batch.stream_pipeline_launches() == calls and batch.stream_pipeline_recoveries() == 0
+    for c in (0, 201, 511, 338):
+        o = ao.OracleSDR(); cfg(o)
+        want = o.update(np.tile(I[c], (calls, 1)), np.tile(Q[c], (calls, 1)))
+        assert np.array_equal(batch.capture_read(c).reshape(-1), want.reshape(-1)), "C5 receiver %d" % c
+    # every receiver's row is its own (different noise seeds): distinct checksums of the slot's last 64 blocks, every 37th receiver
+    sums = set()
+    for c in range(0, n_ch, 37):
+        row = batch.capture_read(c, first_block=41344 - 64, n_blocks=64)
+        sums.add(int(row.astype(np.int64).sum()) * 1000003 + int((row.astype(np.int64) ** 2).sum()))
+    assert len(sums) == len(range(0, n_ch, 37))
+    batch.close()
