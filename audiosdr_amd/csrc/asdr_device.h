@@ -113,8 +113,9 @@ typedef struct {
 } SlotInfo;
 #define ASDR_LO_ENTRIES 8        /* settings groups with an entry of their own (round 2: one entry, wave 0's group) */
 #define ASDR_LO_WRITER 0x100u
-#define ASDR_LO_WRITER_LANE1 0x200u   /* the group's first wave inside lane 1's half of its sub-range: the writer of lane 1's own set of entries
-                                        (asdr_host.cpp, lanes: the halves of a batch on two never-joined streams) */
+#define ASDR_LO_WRITER_LANE(l) (0x100u << (l))   /* lane l >= 1 (asdr_host.cpp, lanes: the pieces of a batch on never-joined streams): the group's
+                                                     first wave inside lane l's piece of its sub-range -- the writer of lane l's own set of entries
+                                                     (lane 0's writer is the group's first wave: ASDR_LO_WRITER); up to 8 lanes, bits 8..15 */
 
 /* Local-oscillator cache: the mixer's phase sequence and its sin/cos pairs depend only on (carried phase, increment).  When all
  * channels of wave 0 share one pair (receivers configured together), that wave also computes the NEXT block's 128 pairs and
@@ -154,7 +155,7 @@ typedef struct {
   LoEntry *lo_cache;      /* [2][ASDR_LO_ENTRIES] */
   uint32_t lo_parity;     /* half this launch reads; a settings group's first wave (SlotInfo.lo) fills its entry of the other half */
   uint32_t lo_write;      /* the launch may fill entries (off for the pipeline, whose oscillator role serves its own ring) */
-  uint32_t lo_writer_bit; /* which bit of SlotInfo.lo names this launch's writers: ASDR_LO_WRITER, or ASDR_LO_WRITER_LANE1 in lane 1's launches */
+  uint32_t lo_writer_bit; /* which bit of SlotInfo.lo names this launch's writers: ASDR_LO_WRITER, or ASDR_LO_WRITER_LANE(l) in lane l's launches */
   uint32_t direct_lo;     /* SlotInfo.lo of a direct_ch0 launch's single settings group (writer = its wave 0) */
   int32_t direct_ch0;     /* >= 0: the launched sub-range is ONE key group of consecutive channels direct_ch0, direct_ch0 + 1, ...:
                              slot i is channel direct_ch0 + i with direct_mode / direct_flags, and no wave has to load its

@@ -168,7 +168,7 @@ struct HostPlan { int K = 1; std::vector<int> bound, need_in, last_part; long sc
 
 }  // namespace
 
-#define ASDR_LANES 2   /* (three streams share a hardware queue with something else on this part: 0.18 ms; four are no better than two) */
+#define ASDR_LANES 8   /* most lanes a batch can run (asdr_batch::n_lanes of them are used) */
 #define ASDR_AUX_STREAMS (ASDR_KERNEL_KINDS + 1 + 8)   /* every sub-range but the first runs on a helper stream; a large sub-range may be split over several (launch_split) */
 struct asdr_batch {
   int n = 0, device = 0;
@@ -226,6 +226,10 @@ struct asdr_batch {
   // call to call only for calls on ASDR_STREAM_BATCH, whose contract leaves the ordering against other streams to the caller.
   hipStream_t lane[ASDR_LANES + 1] = {};   // [ASDR_LANES] = the stream of the sub-ranges that are not cut (the remainders' few long-lived waves)
   hipEvent_t ev_lane[ASDR_LANES + 1] = {};
+  int n_lanes = 2, n_lanes_sam = 4;      // lanes in use: 2 (C2: 0.1209 -> 0.1106 ms; 3 and 4 lanes: +0.5 %); schedules whose SAM channels run as
+                                         // pre | PLL | post launches take 4 (C3: 0.507 -> 0.465 ms: more PLL kernels, which leave issue slots free,
+                                         // beside pre / post kernels, which do not)
+  int sched_lanes = 2;                   // ... as the schedule was built for (the lanes' writer bits in SlotInfo.lo)
   bool lanes_pending = false;            // the lanes hold launches that nothing has been ordered behind yet
   bool last_was_lanes = false;           // the previous call ran on the lanes (asdr_update_device on ASDR_STREAM_BATCH)
   int lanes_min_waves = 1024;            // smallest sub-range that is run as lanes
@@ -247,6 +251,7 @@ struct asdr_batch {
   bool time_calls = false;       // asdr_set_launch_timing: an event pair around every call's launches (two more packets per call)
   hipEvent_t rev0 = nullptr, rev1 = nullptr;   // asdr_region_timing_begin / _end
   hipStream_t region_stream = nullptr;
+  bool region_on_lanes = false;  // asdr_region_timing_begin(b, ASDR_STREAM_BATCH)
   long region_calls = -1;        // update calls since asdr_region_timing_begin (-1: no region open)
   std::vector<hipEvent_t> tev;   // optional per-launch event pairs (asdr_kernel_timing_begin)
   size_t tev_used = 0;
@@ -540,17 +545,20 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
       }
       i = j;
     }
-    // lane 1's writers: in every uniform sub-range, the first wave of each settings group at or behind the start of lane 1's half
-    // (the launcher's split: waves [w l / ASDR_LANES, w (l + 1) / ASDR_LANES) of the sub-range)
+    // The lanes' writers: in every uniform sub-range, for lane l >= 1, the first wave of each settings group at or behind the start of
+    // lane l's piece (the launcher's split: waves [w l / n, w (l + 1) / n) of the sub-range) and inside it.
+    b->sched_lanes = (b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS] > 0) ? b->n_lanes_sam : b->n_lanes;
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
-      const int w = b->kind_uniform_slots[k] / 8, mid = b->kind_first[k] + (int)((long)w * 1 / ASDR_LANES) * 8, end = b->kind_first[k] + b->kind_uniform_slots[k];
-      uint32_t seen = 0;   // entries (ids 1..8) that already have their lane-1 writer
-      for (int sl = mid; sl < end; sl += 8) {
-        const uint32_t id = b->sched[sl].lo & 0xFFu;
-        if (id == 0u || (seen >> id) & 1u) continue;
-        // (a group's waves are consecutive: the first one met behind `mid` is the group's first wave in lane 1)
-        seen |= 1u << id;
-        for (int t = 0; t < 8; t++) b->sched[sl + t].lo |= ASDR_LO_WRITER_LANE1;
+      const long w = b->kind_uniform_slots[k] / 8;
+      for (int l = 1; l < b->sched_lanes; l++) {
+        const int lo = b->kind_first[k] + (int)(w * l / b->sched_lanes) * 8, hi = b->kind_first[k] + (int)(w * (l + 1) / b->sched_lanes) * 8;
+        uint32_t seen = 0;   // entries (ids 1..8) that already have their writer in this lane
+        for (int sl = lo; sl < hi; sl += 8) {
+          const uint32_t id = b->sched[sl].lo & 0xFFu;
+          if (id == 0u || (seen >> id) & 1u) continue;
+          seen |= 1u << id;   // (a group's waves are consecutive: the first one met is the group's first wave in this lane)
+          for (int t = 0; t < 8; t++) b->sched[sl + t].lo |= ASDR_LO_WRITER_LANE(l);
+        }
       }
     }
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
@@ -678,19 +686,49 @@ const Chan *get(asdr_batch *&b, int ch) {
   return (b && ch >= 0 && ch < b->n) ? &b->ch[ch] : nullptr;
 }
 
+// Helper streams (aux: concurrent sub-range launches of a call; lanes: never-joined pieces of a batch) come from ONE pool per device
+// and process, created at first use.  HIP maps the streams in use onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default): from
+// the fifth on, streams share a queue, and what shares a queue runs one after the other with barrier packets in between -- a batch
+// that owns 24 streams changes the mapping for every other stream of the process (C4's three concurrent sub-range launches: 0.345 ms
+// per step, 0.404 with nine unused lane streams created beside them; a single back-to-back kernel stream: 0.122 -> 0.152).  Sharing
+// a pool stream between batches only adds ordering nobody needs; it never breaks the ordering somebody does (a stream is in-order).
+constexpr int kPoolMax = 16;
+struct StreamPool { hipStream_t s[kPoolMax] = {}; int size = 0; std::mutex m; };
+StreamPool g_pool[16];
+hipStream_t pool_stream(int device, int i) {
+  if (device < 0 || device >= 16) return nullptr;
+  StreamPool &p = g_pool[device];
+  std::lock_guard<std::mutex> g(p.m);
+  if (p.size == 0) { const char *e = getenv("ASDR_STREAM_POOL"); p.size = e ? std::max(1, std::min(atoi(e), kPoolMax)) : 3; }
+  const int k = (i < 0) ? p.size - 1 : i % p.size;
+  if (!p.s[k] && hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p.s[k];
+}
+hipStream_t aux_stream(asdr_batch *b, int i) {
+  if (!b->aux[i]) b->aux[i] = pool_stream(b->device, i + 1);   // (+ 1: a lane call's pieces and an ordinary call's helpers start on different pool streams)
+  return b->aux[i];
+}
+hipStream_t lane_stream(asdr_batch *b, int l) {
+  if (!b->lane[l]) b->lane[l] = pool_stream(b->device, l);
+  return b->lane[l];
+}
 bool needs_flush(const asdr_batch *b) {
   return b->all_dirty || !b->dirty.empty() || b->sched_dirty || b->agc_pool_dirty || b->reset_pending || b->agc_refs_changed;
 }
 // everything the lanes hold so far happens before whatever is enqueued on `stream` from now on
 int lanes_join_into(asdr_batch *b, hipStream_t stream) {
-  for (int l = 0; l < ASDR_LANES + 1; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(stream, b->ev_lane[l], 0)); }
+  for (int i = 0; i <= b->sched_lanes; i++) {   // the lanes in use, and the stream of the uncut sub-ranges (a schedule change synchronises them all first)
+    const int l = (i == b->sched_lanes) ? ASDR_LANES : i;
+    if (!b->lane[l]) continue;   // never used
+    HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(stream, b->ev_lane[l], 0));
+  }
   return 0;
 }
 // host-side: every launch of the batch so far is complete
 int sync_all(asdr_batch *b) {
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (b->lanes_pending) { for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamSynchronize(b->lane[l])); b->lanes_pending = false; }
+  if (b->lanes_pending) { for (int l = 0; l < ASDR_LANES + 1; l++) if (b->lane[l]) HIPCHK(hipStreamSynchronize(b->lane[l])); b->lanes_pending = false; }
   return 0;
 }
 
@@ -766,22 +804,21 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
     alloc((void **)&b->d_lo, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry));   // + one set per lane: a lane's readers only ever see its own writer
     if (ok && hipMemset(b->d_lo, 0xFF, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
-    for (int i = 0; i < ASDR_LANES + 1 && ok; i++) {
-      if (hipStreamCreateWithFlags(&b->lane[i], hipStreamNonBlocking) != hipSuccess) ok = false;
-      if (ok && hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
-    }
+    for (int i = 0; i < ASDR_LANES + 1 && ok; i++)
+      if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
-    if (ok && hipStreamCreate(&b->stream) != hipSuccess) ok = false;
+    if (ok && (b->stream = pool_stream(device, -1)) == nullptr) ok = false;   // the pool's last stream (the lanes start at its first)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->rev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->rev1) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming) != hipSuccess) ok = false;
     if (ok && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess) ok = false;
-    for (int i = 0; i < ASDR_AUX_STREAMS && ok; i++) {
-      if (hipStreamCreateWithFlags(&b->aux[i], hipStreamNonBlocking) != hipSuccess) ok = false;
-      if (ok && hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess) ok = false;
-    }
+    // The helper streams (aux, lanes) are created at their first use: HIP maps streams onto a few hardware queues, and streams that
+    // share a queue run one after the other -- every stream a batch creates but never uses shifts that mapping for the ones it does
+    // use (C4's three concurrent sub-range launches: 0.345 ms per step, 0.404 with nine unused lane streams created beside them).
+    for (int i = 0; i < ASDR_AUX_STREAMS && ok; i++)
+      if (hipEventCreateWithFlags(&b->ev_join[i], hipEventDisableTiming) != hipSuccess) ok = false;
     if (ok && asdr_kernels_upload_tables() != 0) ok = false;
     if (ok) {
       // The pipeline's roles wait for each other: its 3 w workgroups must fit the device at once -- an occupancy query, not an
@@ -878,8 +915,6 @@ void asdr_destroy(asdr_batch_t *b) {
   b->copy_pool.reset();
   for (int i = 0; i < 3; i++) if (b->h_io[i]) hipHostFree(b->h_io[i]);
   for (hipEvent_t e : b->ev_host) hipEventDestroy(e);
-  if (b->h2d_stream) hipStreamDestroy(b->h2d_stream);
-  if (b->d2h_stream) hipStreamDestroy(b->d2h_stream);
   for (hipEvent_t e : b->tev) hipEventDestroy(e);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -887,9 +922,9 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->rev1) hipEventDestroy(b->rev1);
   if (b->ev_last) hipEventDestroy(b->ev_last);
   if (b->ev_fork) hipEventDestroy(b->ev_fork);
-  for (int i = 0; i < ASDR_AUX_STREAMS; i++) { if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]); if (b->aux[i]) hipStreamDestroy(b->aux[i]); }
-  for (int i = 0; i < ASDR_LANES + 1; i++) { if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]); if (b->lane[i]) hipStreamDestroy(b->lane[i]); }
-  if (b->stream) hipStreamDestroy(b->stream);
+  for (int i = 0; i < ASDR_AUX_STREAMS; i++) if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]);   // (the streams belong to the process-wide pool)
+  for (int i = 0; i < ASDR_LANES + 1; i++) if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]);
+  // (b->stream and the helper streams belong to the process-wide pool)
   delete b;
 }
 
@@ -1068,19 +1103,22 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     if (batch_stream) {
       if (b->ev_last_valid && !b->last_was_lanes) {
         HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
-        for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_last, 0));
+        for (int i = 0; i <= b->sched_lanes; i++) { hipStream_t ls = lane_stream(b, i == b->sched_lanes ? ASDR_LANES : i); if (!ls) return fail("stream creation failed"); HIPCHK(hipStreamWaitEvent(ls, b->ev_last, 0)); }
       }
     } else {
       HIPCHK(hipEventRecord(b->ev_fork, stream));
-      for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
+      for (int i = 0; i <= b->sched_lanes; i++) { hipStream_t ls = lane_stream(b, i == b->sched_lanes ? ASDR_LANES : i); if (!ls) return fail("stream creation failed"); HIPCHK(hipStreamWaitEvent(ls, b->ev_fork, 0)); }
     }
-    for (int l = 0; l < ASDR_LANES + 1; l++) {
+    const int NL = b->sched_lanes;
+    for (int l = 0; l <= NL; l++) {   // l == NL: the sub-ranges that are not cut, on the stream behind the lanes (lane[ASDR_LANES])
+      hipStream_t ls = lane_stream(b, (l == NL) ? ASDR_LANES : l);
+      if (!ls) return fail("stream creation failed");
       for (int lb = 0; lb < n_launch; lb++) {
         for (int i = 0; i < n_sub; i++) {   // this lane's half of every uniform sub-range, one kernel after the other on the lane's stream;
           const Sub &su = subs[i];          // the general-kernel sub-ranges (the remainders: a few long-lived waves) whole, on the stream behind the lanes
           const long w = su.slots / 8;
-          int lo = (int)(w * l / ASDR_LANES) * 8, cnt = (int)(w * (l + 1) / ASDR_LANES) * 8 - lo;
-          if (l == ASDR_LANES) { lo = 0; cnt = su.uniform ? 0 : su.slots; } else if (!su.uniform) cnt = 0;
+          int lo = (int)(w * l / NL) * 8, cnt = (int)(w * (l + 1) / NL) * 8 - lo;
+          if (l == NL) { lo = 0; cnt = su.uniform ? 0 : su.slots; } else if (!su.uniform) cnt = 0;
           const int first = su.first + lo;
           if (cnt == 0) continue;
           UpdateArgs al = a;
@@ -1089,7 +1127,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
           if (su.uniform && b->kind_direct[su.kind]) { const SlotInfo &s0 = b->sched[su.first]; al.direct_ch0 = s0.ch + lo; al.direct_mode = s0.mode; al.direct_flags = s0.flags; al.direct_lo = s0.lo; }
           al.lo_cache = b->d_lo + (size_t)(1 + (l % ASDR_LANES)) * 2 * ASDR_LO_ENTRIES;   // this lane's own set: its writers fill it, its waves read it (general-kernel waves have no entry)
           al.lo_write = 1u;
-          al.lo_writer_bit = (l == 0) ? ASDR_LO_WRITER : ASDR_LO_WRITER_LANE1;   // (a direct launch: its wave 0, under either name)
+          al.lo_writer_bit = ASDR_LO_WRITER_LANE(l % ASDR_LANES);   // (lane 0: ASDR_LO_WRITER; a direct launch: its wave 0, under any name)
           if (sam_split && su.kind == ASDR_KERNEL_SAM) al.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
           if (sam_split && su.kind == ASDR_KERNEL_SAM_ALS) al.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
           const int form = (als_split && su.kind == ASDR_KERNEL_ALS_SMALL && su.uniform) ? 2 : su.uniform;
@@ -1099,7 +1137,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
             al.als_phase = (b->als_phase + (uint32_t)lb) & 1u;
             al.lo_parity = b->lo_parity ^ (uint32_t)(lb & 1);
           }
-          if (asdr_launch_update(&al, su.kind, form, b->lane[l]) != 0) return fail("update kernel launch failed");
+          if (asdr_launch_update(&al, su.kind, form, ls) != 0) return fail("update kernel launch failed");
         }
       }
     }
@@ -1143,7 +1181,8 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     int n_aux = 0;
     for (int it = 0; it < n_items; it++) {
       const int i = items[it].sub, first = items[it].first;
-      hipStream_t s = (it == main_item) ? stream : b->aux[n_aux++];
+      hipStream_t s = (it == main_item) ? stream : aux_stream(b, n_aux++);
+      if (!s && it != main_item) return fail("stream creation failed");
       if (it != main_item) HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
       a.sched = b->d_sched + first; a.n_sched = items[it].slots;
       a.direct_ch0 = -1;
@@ -1343,9 +1382,9 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
     }
     b->h_io_cap = count;
   }
-  if (!b->h2d_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&b->h2d_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&b->d2h_stream, hipStreamNonBlocking));
+  if (!b->h2d_stream) {   // copies in on the pool's first stream, out on its second, kernels on its last (b->stream)
+    b->h2d_stream = pool_stream(b->device, 0); b->d2h_stream = pool_stream(b->device, 1);
+    if (!b->h2d_stream || !b->d2h_stream) return fail("stream creation failed");
   }
   // the schedule must exist before the plan can be read off it
   if (b->ev_last_valid && b->stream != b->last_stream) {
@@ -1497,7 +1536,7 @@ int asdr_order_after(asdr_batch_t *b, void *stream_) {   // the batch's calls on
   if (stream_ == ASDR_STREAM_BATCH) return fail("asdr_order_after: name one of your own streams");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipEventRecord(b->ev_fork, (hipStream_t)stream_));
-  for (int l = 0; l < ASDR_LANES + 1; l++) HIPCHK(hipStreamWaitEvent(b->lane[l], b->ev_fork, 0));
+  for (int l = 0; l < ASDR_LANES + 1; l++) if (b->lane[l] || l < b->sched_lanes || l == ASDR_LANES) { hipStream_t ls = lane_stream(b, l); if (!ls) return fail("stream creation failed"); HIPCHK(hipStreamWaitEvent(ls, b->ev_fork, 0)); }
   HIPCHK(hipStreamWaitEvent(b->stream, b->ev_fork, 0));
   return 0;
 }
@@ -1507,9 +1546,11 @@ long asdr_lane_calls(asdr_batch_t *b) {
 }
 int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves) {
   if (!b) return fail("null batch");
+  if (on < 0 || on > ASDR_LANES) return fail("lanes: 0 (off), 1 (on), or the number of lanes 2..8");
   FOR_SHARDS(b, asdr_set_lanes(sh_, on, min_waves));
   if (b->device != ASDR_NO_DEVICE && b->lanes_pending) { HIPCHK(hipSetDevice(b->device)); if (sync_all(b) != 0) return -1; }
   b->lanes_enabled = on != 0;
+  if (on >= 2) { b->n_lanes = on; b->n_lanes_sam = on; b->sched_dirty = true; }   // an explicit count, for every schedule (the writers' places follow it)
   if (min_waves > 0) b->lanes_min_waves = std::max(2 * ASDR_LANES, min_waves);
   return 0;
 }
@@ -1567,10 +1608,11 @@ int asdr_region_timing_begin(asdr_batch_t *b, void *stream_) {
   if (b->device == ASDR_NO_DEVICE) return fail("control-plane-only batch has no device state");
   HIPCHK(hipSetDevice(b->device));
   if (stream_ == ASDR_STREAM_BATCH) {   // the batch's own lanes: the region starts / ends when BOTH are there (lane 0 waits for lane 1)
-    b->region_stream = b->lane[0];
-    for (int l = 1; l < ASDR_LANES + 1; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[l], 0)); }
+    if (!lane_stream(b, 0)) return fail("stream creation failed");
+    b->region_stream = b->lane[0]; b->region_on_lanes = true;
+    for (int l = 1; l < ASDR_LANES + 1; l++) if (b->lane[l]) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[l], 0)); }
   } else {
-    b->region_stream = (hipStream_t)stream_;
+    b->region_stream = (hipStream_t)stream_; b->region_on_lanes = false;
   }
   HIPCHK(hipEventRecord(b->rev0, b->region_stream));
   b->region_calls = 0;
@@ -1582,12 +1624,12 @@ int asdr_region_timing_end(asdr_batch_t *b, float *ms_total, long *n_calls) {
   if (is_sharded(b)) return fail("region timing is per device: use the shard handles (asdr_shard)");
   if (b->region_calls < 0) return fail("asdr_region_timing_end without asdr_region_timing_begin");
   HIPCHK(hipSetDevice(b->device));
-  if (b->region_stream == b->lane[0]) {
+  if (b->region_on_lanes) {
     if (!b->last_was_lanes && b->ev_last_valid) {   // the region's last call ran the ordinary way, on the batch's stream: behind that, too
       HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
       HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_last, 0));
     }
-    for (int l = 1; l < ASDR_LANES + 1; l++) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[l], 0)); }
+    for (int l = 1; l < ASDR_LANES + 1; l++) if (b->lane[l]) { HIPCHK(hipEventRecord(b->ev_lane[l], b->lane[l])); HIPCHK(hipStreamWaitEvent(b->lane[0], b->ev_lane[l], 0)); }
   }
   HIPCHK(hipEventRecord(b->rev1, b->region_stream));
   HIPCHK(hipEventSynchronize(b->rev1));

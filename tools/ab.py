@@ -22,6 +22,8 @@ import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "audiosdr_amd", "variants")
+# AB_STREAM=batch: the calls go to ASDR_STREAM_BATCH (the batch's own streams: lanes) instead of the null stream
+STREAM = C.c_void_p((1 << 64) - 1) if os.environ.get("AB_STREAM") == "batch" else None
 
 
 def build(specs):
@@ -103,7 +105,7 @@ def run(workloads, rounds, n_rep):
             h = L.asdr_create(n_ch, 0)
 
             def step(i, L=L, h=h):
-                L.asdr_update_device(h, C.c_void_p(dI[i & 3].data_ptr()), C.c_void_p(dQ[i & 3].data_ptr()), C.c_void_p(dOut.data_ptr()), 1, None)
+                L.asdr_update_device(h, C.c_void_p(dI[i & 3].data_ptr()), C.c_void_p(dQ[i & 3].data_ptr()), C.c_void_p(dOut.data_ptr()), 1, STREAM)
             setup(L, h, wl, n_ch, step)
             libs[name] = (L, h, step)
         times = {k: [] for k in libs}
@@ -111,7 +113,7 @@ def run(workloads, rounds, n_rep):
             for name, (L, h, step) in libs.items():
                 for i in range(max(40, n_rep // 4)):
                     step(i)
-                L.asdr_region_timing_begin(h, None)
+                L.asdr_region_timing_begin(h, STREAM)
                 for i in range(n_rep):
                     step(i)
                 total, calls = C.c_float(0.0), C.c_long(0)
