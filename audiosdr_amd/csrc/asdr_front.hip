@@ -204,10 +204,18 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
   const int i0 = 16 * s8;
   const int chc = valid ? ch : 0;   // clamped: lanes of a padding channel read channel 0 and discard
   const float gain_i = a.gains[2 * chc], gain_q = a.gains[2 * chc + 1];
+  // Global rows are touched in whole 16-byte pieces with the 8 lanes of a channel on 8 ADJACENT pieces (one wave instruction reads or
+  // writes 128 contiguous bytes of each of its 8 rows), as in the update kernel: lanes on every second or eighth piece make every
+  // instruction touch every line of the rows (round 4: 0.0557 -> see profiles/README.md).  int16 rows: lane s8 owns samples
+  // kA + 64 h + j (h = 0, 1; j < 8); float rows: pieces s8 + 8 q.
+  const int kA = 8 * s8;
   {
-    const float4 *h = reinterpret_cast<const float4 *>(a.hist + (size_t)chc * 256 + 32 * s8);
+    const float4 *h = reinterpret_cast<const float4 *>(a.hist + (size_t)chc * 256) + s8;
+    float4 t[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) reinterpret_cast<float4 *>(w + 32 * s8)[q] = h[q];
+    for (int q = 0; q < 8; ++q) t[q] = h[8 * q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) reinterpret_cast<float4 *>(w)[s8 + 8 * q] = t[q];
   }
 
   // Delay line in LDS: sample x[m] of the reference's 384-sample window (two carried blocks + the newest) at w[m - 1], m = 1..383
@@ -219,11 +227,11 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
       Raw8 r0, r1;
       r0.v = r1.v = make_int4(0, 0, 0, 0);
       if (valid) {
-        const int4 *p = reinterpret_cast<const int4 *>(a.in + ((size_t)ch * a.in_stride + blk) * ASDR_N + i0);
-        r0.v = p[0]; r1.v = p[1];
+        const int4 *p = reinterpret_cast<const int4 *>(a.in + ((size_t)ch * a.in_stride + blk) * ASDR_N + kA);
+        r0.v = p[0]; r1.v = p[8];   // int4 #8 = 64 samples on
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { w[255 + i0 + j] = unit_scale(r0.s[j]); w[255 + i0 + 8 + j] = unit_scale(r1.s[j]); }
+      for (int j = 0; j < 8; ++j) { w[255 + kA + j] = unit_scale(r0.s[j]); w[255 + 64 + kA + j] = unit_scale(r1.s[j]); }
     }
     WAVE_SYNC();
     // this lane's 16 outputs i0 + 2e, i0 + 2e + 1 (e = 0..7) as 8 packed pairs: AudioIQgenerator.cpp:60-76, taps c_iq_taps
@@ -231,24 +239,37 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
     hilbert_fir_rows<0, 8>(w, i0 >> 1, acc2, c_iq_taps);
-    if (valid) {   // .cpp:78-82: (int16_t)(float * 32767.0 * gain) in binary64; v_cvt_i32_f64 saturates like the ARM target
-      int vi[16], vq[16];
+    // The FIR owns 16 contiguous outputs per lane, the global rows 8-sample pieces: the Q row is handed over through LDS -- in the
+    // words of the oldest block (x[1..128] at w[0..127]), which no FIR read needs any more once every lane is through.  (Word 127 =
+    // x[128] is the first delayed I sample: the I pieces are read before the hand-over.)
+    float ivr[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float iv = w[127 + i0 + j];          // x[128 + i0 + j]: the input delayed by one block
-        const float qv = acc2[j >> 1][j & 1];
-        vi[j] = (int)(((double)iv * 32767.0) * (double)gain_i);
-        vq[j] = (int)(((double)qv * 32767.0) * (double)gain_q);
-      }
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ivr[8 * h + j] = w[127 + 64 * h + kA + j];   // x[128 + k]: the input delayed by one block
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4 *>(w + i0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
+    WAVE_SYNC();
+    if (valid) {   // .cpp:78-82: (int16_t)(float * 32767.0 * gain) in binary64; v_cvt_i32_f64 saturates like the ARM target
       Raw8 oi[2], oq[2];   // (int16_t) keeps the low half, like the reference's cast
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        oi[h].v = make_int4(pack16(vi[8 * h], vi[8 * h + 1]), pack16(vi[8 * h + 2], vi[8 * h + 3]), pack16(vi[8 * h + 4], vi[8 * h + 5]), pack16(vi[8 * h + 6], vi[8 * h + 7]));
-        oq[h].v = make_int4(pack16(vq[8 * h], vq[8 * h + 1]), pack16(vq[8 * h + 2], vq[8 * h + 3]), pack16(vq[8 * h + 4], vq[8 * h + 5]), pack16(vq[8 * h + 6], vq[8 * h + 7]));
+        int vi[8], vq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float iv = ivr[8 * h + j];
+          const float qv = w[64 * h + kA + j];
+          vi[j] = (int)(((double)iv * 32767.0) * (double)gain_i);
+          vq[j] = (int)(((double)qv * 32767.0) * (double)gain_q);
+        }
+        oi[h].v = make_int4(pack16(vi[0], vi[1]), pack16(vi[2], vi[3]), pack16(vi[4], vi[5]), pack16(vi[6], vi[7]));
+        oq[h].v = make_int4(pack16(vq[0], vq[1]), pack16(vq[2], vq[3]), pack16(vq[4], vq[5]), pack16(vq[6], vq[7]));
       }
-      const size_t oo = ((size_t)ch * a.out_stride + blk) * ASDR_N + i0;
+      const size_t oo = ((size_t)ch * a.out_stride + blk) * ASDR_N + kA;
       int4 *po = reinterpret_cast<int4 *>(a.out_i + oo), *pq = reinterpret_cast<int4 *>(a.out_q + oo);
-      po[0] = oi[0].v; po[1] = oi[1].v; pq[0] = oq[0].v; pq[1] = oq[1].v;
+      po[0] = oi[0].v; po[8] = oi[1].v; pq[0] = oq[0].v; pq[8] = oq[1].v;
     }
     WAVE_SYNC();
     // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383] (word 383 is padding);
@@ -263,9 +284,9 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
     }
   }
   if (valid) {
-    float4 *h = reinterpret_cast<float4 *>(a.hist + (size_t)ch * 256 + 32 * s8);
+    float4 *h = reinterpret_cast<float4 *>(a.hist + (size_t)ch * 256) + s8;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) h[q] = reinterpret_cast<const float4 *>(w + 32 * s8)[q];
+    for (int q = 0; q < 8; ++q) h[8 * q] = reinterpret_cast<const float4 *>(w)[s8 + 8 * q];
   }
 }
 

@@ -87,8 +87,14 @@ def main():
         wi, wq = og[c].update(I[c, :T])
         ok = ok and np.array_equal(gi[c].reshape(-1), wi) and np.array_equal(gq[c].reshape(-1), wq)
     ms = med(g, lambda: g.update_device(dI.data_ptr(), dOi.data_ptr(), dOq.data_ptr(), T, S, S))
+    # The generator is bound by its FIR, not by HBM: 128 outputs x 64 folded taps x (subtract, multiply, add) = 24,576 separately
+    # rounded FP32 operations per channel-block (no FMA: parity with AudioIQgenerator.cpp:60-76), against the vector unit's
+    # 157.3 TFLOP/s / 2 = 78.6 T operations/s without FMA (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD counts an FMA as two).
+    tops = n_ch * T * 24576 / (ms * 1e-3) / 1e12
     line("AudioIQgenerator (257-tap Hilbert)", n_ch, T, ms, 768, ok,
-         {"state_bytes_per_launch_per_channel": 2048})
+         {"state_bytes_per_launch_per_channel": 2048,
+          "roofline_valu": {"bound": "valu", "achieved": round(tops, 2), "peak": 78.6, "unit": "T FP32 operations/s (no FMA)", "frac": round(tops / 78.6, 4),
+                            "operations_per_channel_block": 24576}})
     g.close()
 
     # ---- grabber (two blocks -> 256 interleaved complex samples)
