@@ -39,6 +39,9 @@
 #ifndef ASDR_STREAM_MIN_BLOCKS
 #define ASDR_STREAM_MIN_BLOCKS 8
 #endif
+#ifndef ASDR_STREAM_SIDE_WAVES
+#define ASDR_STREAM_SIDE_WAVES 64   /* waves of other kernel kinds / remainders a pipeline call may carry beside it (on the in-kernel block loop) */
+#endif
 extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream);
 extern "C" int asdr_stream_capacity(int device, int *compute_units);
 extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int restore, hipStream_t stream);
@@ -1037,12 +1040,17 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     const uintptr_t o0 = (uintptr_t)dOut, o1 = o0 + out_bytes;
     for (uintptr_t i0 : {(uintptr_t)dI, (uintptr_t)dQ}) io_alias = io_alias || (o0 < i0 + in_bytes && i0 < o1);
   }
-  bool take_pipeline = parts == 1 && b->stream_pipeline && !io_alias && n_blocks >= ASDR_STREAM_MIN_BLOCKS && n_sub == 1 && subs[0].kind == ASDR_KERNEL_PLAIN &&
-                       subs[0].uniform && b->plain_uniform_ssb &&
+  // The pipeline takes the plain kind's uniform waves (SSB-class and AM groups).  What else the schedule holds -- the remainders' general
+  // waves, a few SAM or ALS channels among 4,000 receivers -- no longer disqualifies the call (round 3: n_sub == 1): while those
+  // sub-ranges are small they run the same call on the in-kernel block loop beside the pipeline, on helper streams.
+  int pipe_sub = -1, other_waves = 0;
+  for (int i = 0; i < n_sub; i++) { if (subs[i].kind == ASDR_KERNEL_PLAIN && subs[i].uniform) pipe_sub = i; else other_waves += subs[i].slots / 8; }
+  bool take_pipeline = parts == 1 && b->stream_pipeline && !io_alias && n_blocks >= ASDR_STREAM_MIN_BLOCKS && pipe_sub >= 0 && b->plain_uniform_ssb &&
+                       other_waves <= ASDR_STREAM_SIDE_WAVES && !sam_split && !als_split &&
 #ifndef ASDR_TIMELINE   /* (the profiling build writes its timestamps through the taps buffer: tools/timeline.py stream) */
                        !b->taps_on &&
 #endif
-                       subs[0].slots / 8 <= b->stream_max_waves;
+                       subs[pipe_sub].slots / 8 <= b->stream_max_waves;
   if (take_pipeline) {
     if (!b->d_xch_a) {   // first use: every buffer, or none (a failed allocation leaves the batch on the other launch forms)
       float *xa = nullptr, *xb = nullptr; uint32_t *prog = nullptr; LoEntry *ring = nullptr; void *snap = nullptr;
@@ -1063,11 +1071,13 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     }
   }
   if (take_pipeline) {
-    const int w = subs[0].slots / 8;
+    const UpdateArgs a_side = a;   // (for the sub-ranges beside the pipeline: before the pipeline's own fields are set)
+    const int w = subs[pipe_sub].slots / 8;
     HIPCHK(hipMemsetAsync(b->d_stream_prog, 0, (size_t)(3 * w + 1) * sizeof(uint32_t), stream));   // stream-ordered behind the previous launch
-    a.sched = b->d_sched + subs[0].first; a.n_sched = subs[0].slots;
+    if (n_sub > 1) HIPCHK(hipEventRecord(b->ev_fork, stream));
+    a.sched = b->d_sched + subs[pipe_sub].first; a.n_sched = subs[pipe_sub].slots;
     a.direct_ch0 = -1;
-    if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo; }
+    if (b->kind_direct[ASDR_KERNEL_PLAIN]) { const SlotInfo &s0 = b->sched[subs[pipe_sub].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo; }
     a.lo_write = 0u;
     a.xch_a = b->d_xch_a; a.xch_b = b->d_xch_b; a.xch_c = b->d_xch_b + (size_t)(b->n + 1) * ASDR_STREAM_DEPTH * ASDR_N; a.stream_prog = b->d_stream_prog; a.stream_err = b->d_stream_prog + 3 * ((b->n + 7) / 8) + 1;
     a.stream_waves = w; a.lo_ring = b->d_lo_ring; a.stream_spin_limit = b->stream_spin_limit;
@@ -1081,6 +1091,21 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
       if (asdr_launch_update(&f, ASDR_KERNEL_PLAIN, 1, stream) != 0) return fail("stream fallback launch failed");
     }
     if (asdr_launch_stream_ack(a.stream_err, stream) != 0) return fail("stream acknowledge launch failed");
+    {   // the other sub-ranges: the whole call on the in-kernel block loop, each on a helper stream beside the pipeline
+      int n_aux = 0;
+      for (int i = 0; i < n_sub; i++) {
+        if (i == pipe_sub) continue;
+        hipStream_t s = aux_stream(b, n_aux++);
+        if (!s) return fail("stream creation failed");
+        HIPCHK(hipStreamWaitEvent(s, b->ev_fork, 0));
+        UpdateArgs o = a_side;
+        o.sched = b->d_sched + subs[i].first; o.n_sched = subs[i].slots; o.direct_ch0 = -1; o.lo_write = 1u;
+        if (subs[i].uniform && b->kind_direct[subs[i].kind]) { const SlotInfo &s0 = b->sched[subs[i].first]; o.direct_ch0 = s0.ch; o.direct_mode = s0.mode; o.direct_flags = s0.flags; o.direct_lo = s0.lo; }
+        if (asdr_launch_update(&o, subs[i].kind, subs[i].uniform, s) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
+      }
+      for (int j = 0; j < n_aux; j++) HIPCHK(hipStreamWaitEvent(stream, b->ev_join[j], 0));
+    }
     if (e1) HIPCHK(hipEventRecord(e1, stream));
     b->stream_launched = true; b->stat_stream_launches++;
     b->ev_last_valid = true;

@@ -164,23 +164,28 @@ def test_block_pipeline_key_groups(gpu, ao):
 
 
 def test_block_pipeline_is_not_used_where_it_does_not_apply(gpu, ao):
-    """A SAM channel group (its PLL is a 128-step chain per block: no role set), an ALS filter, stage taps, a ragged channel count or
-    a short call keep the block-by-block path (same results either way)."""
+    """A SAM channel group (its PLL is a 128-step chain per block: no role set), an ALS filter, stage taps or a short call keep the
+    block-by-block path (same results either way).  A ragged channel count no longer does (round 4): the 7 whole waves of 61 USB
+    channels take the pipeline, the 5 left over run the call on the in-kernel block loop beside it."""
     from audiosdr_amd.synth import make_iq
     T = 12
-    for n_ch, setters, taps in ((64, [S("setDemodMode", 5)], False), (64, [S("setDemodMode", 4), S("enableALSfilter")], False),
-                                (64, [S("setDemodMode", 1)], True), (61, [S("setDemodMode", 1)], False)):
-        I, Q = make_iq(n_ch, T, fc=6290.0, A=0.25)
+    for n_ch, setters, taps, expect in ((64, [S("setDemodMode", 5)], False, 0), (64, [S("setDemodMode", 4), S("enableALSfilter")], False, 0),
+                                        (64, [S("setDemodMode", 1)], True, 0), (61, [S("setDemodMode", 1)], False, 1)):
+        I, Q = make_iq(n_ch, T + 4, fc=6290.0, A=0.25)
         batch, orcs = _mk(gpu, ao, n_ch, setters)
         if taps:
             batch.enable_taps(True)
         hip = Hip()
-        dI, dQ = hip.upload(I), hip.upload(Q)
-        dO = hip.malloc(n_ch * T * 256)
+        dI, dQ = hip.upload(I[:, :T]), hip.upload(Q[:, :T])
+        dI2, dQ2 = hip.upload(I[:, T:]), hip.upload(Q[:, T:])
+        dO, dO2 = hip.malloc(n_ch * T * 256), hip.malloc(n_ch * 4 * 256)
         batch.update_device(dI, dQ, dO, T)
-        batch.update_device(dI, dQ, dO, 4)          # short call (state continues; only the launch count matters here)
+        batch.update_device(dI2, dQ2, dO2, 4)       # short call: never the pipeline
         batch.synchronize()
-        assert batch.stream_pipeline_launches() == 0
+        assert batch.stream_pipeline_launches() == expect
+        got = np.concatenate([hip.download(dO, (n_ch, T, 128), np.int16), hip.download(dO2, (n_ch, 4, 128), np.int16)], axis=1)
+        for c in range(0, n_ch, 7 if expect == 0 else 1):
+            assert np.array_equal(got[c], orcs[c].update(I[c], Q[c]).reshape(T + 4, 128)), (n_ch, c)
         hip.free_all(); batch.close()
 
 
@@ -315,6 +320,44 @@ def test_block_pipeline_timeout_is_recovered_in_stream(gpu, ao, limit):
                 want = orcs[c].update(I[c, :total], Q[c, :total]).reshape(total, 128)
                 orcs[c]._want = want
             assert np.array_equal(got[c], orcs[c]._want[p0:p0 + T]), "call at block %d (%d blocks), ch %d" % (p0, T, c)
+    _compare_status(batch, orcs)
+    hip.free_all(); batch.close()
+
+
+@pytest.mark.parametrize("limit", [0, 1])
+def test_block_pipeline_with_odd_channels_beside_it(gpu, ao, limit):
+    """A small batch whose schedule is NOT one sub-range still takes the pipeline for its uniform SSB / AM waves: 200 USB receivers
+    with an AM one, a SAM one, one with the ALS filter and one with other AGC settings among them -- the odd channels (a SAM and an
+    ALS wave's worth of general-kernel remainders) run the same call on the in-kernel block loop beside the pipeline.  Every channel,
+    every block and the status words against the oracle; with the poll limit at 1 the pipeline part is recovered in stream while the
+    side launches are untouched."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 204, (20, 1, 9)
+    total = sum(plan)
+    fc = 6290.0 + 15.0 * (np.arange(n_ch) % 3)
+    I, Q = make_iq(n_ch, total, fc=fc, A=0.25, m=0.3, noise=0.02, impulse_every=1300)
+    setters = [S("setDemodMode", 1), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0),
+               S("setDemodMode", 4, sel=lambda c: c == 77), S("setDemodMode", 5, sel=lambda c: c == 130),
+               S("enableALSfilter", sel=lambda c: c == 5), S("setAGCthreshold", -40.0, sel=lambda c: c == 190)]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    batch.debug_set_stream_spin_limit(limit)
+    hip = Hip()
+    outs, pos = [], 0
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        outs.append((dO, pos, T)); pos += T
+    batch.synchronize()
+    assert batch.stream_pipeline_launches() == 2                     # the 20- and the 9-block call
+    assert (batch.stream_pipeline_recoveries() >= 1) == (limit == 1)
+    lay = batch.schedule_layout()
+    assert lay["plain"] >= 192 and lay["remainders"] > 0
+    want = [orcs[c].update(I[c], Q[c]).reshape(total, 128) for c in range(n_ch)]
+    for dO, p0, T in outs:
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            assert np.array_equal(got[c], want[c][p0:p0 + T]), "call at block %d, ch %d" % (p0, c)
     _compare_status(batch, orcs)
     hip.free_all(); batch.close()
 
