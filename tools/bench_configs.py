@@ -62,7 +62,10 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
         batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
     total, calls = batch.region_timing_end()
     STEADY_MS = total / max(1, calls)
-    # ... and the same launches on the batch's own streams (ASDR_STREAM_BATCH: two never-joined lanes when the schedule is one group)
+    # ... and the same launches on the batch's own streams (ASDR_STREAM_BATCH: the pieces of every sub-range on never-joined lanes)
+    if os.environ.get("BENCH_CONFIGS_NO_LANES"):   # (counter passes: one launch form per kernel name)
+        STEADY_BATCH_MS = None
+        return ms, np.concatenate(outs, axis=1)
     lc0 = batch.lane_calls()
     batch.set_launch_timing(False)   # (an event pair around every call keeps it off the lanes)
     for _ in range(n_rep):

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 PMC passes (one counter group per pass: MI355X_MICROARCH.md, PMC slots) of one command, summarised per kernel.  (GPU box.)
 #   bash tools/prof_pmc2.sh <out dir under the repo> [workload label] [command ...]
-# Default command: bench.py's C2 (the kernel asdr_update_kernel); the C3 / C4 passes use tools/bench_configs.py c3 / c4.
+# Default command: bench.py's C2 on a caller's stream (ONE launch of asdr_update_kernel per step, so that the per-launch medians are per-step
+# figures; on ASDR_STREAM_BATCH a step is two half-size launches in flight together); the C3 / C4 passes use tools/bench_configs.py c3 / c4.
 # Never combined with a trace domain other than --kernel-trace (gpurun refuses that), program named directly after `--`.
 set -u
 OUT=${1:-gpurun_out/pmc2}
@@ -9,7 +10,7 @@ LABEL=${2:-"bench.py C2, 65536 channels x 1 block per launch"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ $# -ge 2 ]; then shift 2; else shift $#; fi
 # the command stays an array, so a repository path with spaces survives; the program itself follows `--` (python3 <script>)
-if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python3 "$ROOT/bench.py" --steps 40 --warmup 10 --settle 0 --no-cpu-baseline --no-robustness); fi
+if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python3 "$ROOT/bench.py" --steps 40 --warmup 10 --settle 0 --no-cpu-baseline --no-robustness --no-host-path --caller-stream); fi
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 p() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$n" -- "${CMD[@]}" > "$ROOT/$OUT/$n.log" 2>&1; }
