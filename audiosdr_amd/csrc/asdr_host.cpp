@@ -550,7 +550,10 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     }
     // The lanes' writers: in every uniform sub-range, for lane l >= 1, the first wave of each settings group at or behind the start of
     // lane l's piece (the launcher's split: waves [w l / n, w (l + 1) / n) of the sub-range) and inside it.
-    b->sched_lanes = (b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS] > 0) ? b->n_lanes_sam : b->n_lanes;
+    {   // 4 lanes when the pre | PLL | post launches are most of the work (C3: 0.505 -> 0.456 ms), 2 otherwise (C4, a seventh SAM: 0.345 / 0.37-0.43)
+      const int sam_slots_ = b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS];
+      b->sched_lanes = (b->sam_split && 2 * sam_slots_ >= pos) ? b->n_lanes_sam : b->n_lanes;
+    }
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
       const long w = b->kind_uniform_slots[k] / 8;
       for (int l = 1; l < b->sched_lanes; l++) {
@@ -810,7 +813,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     for (int i = 0; i < ASDR_LANES + 1 && ok; i++)
       if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
-    if (ok && (b->stream = pool_stream(device, -1)) == nullptr) ok = false;   // the pool's last stream (the lanes start at its first)
+    if (ok && (b->stream = pool_stream(device, 0)) == nullptr) ok = false;   // the pool's first stream (= lane 0: a batch runs on the lanes or on its own stream, never both at once)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->rev0) != hipSuccess) ok = false;
@@ -1407,8 +1410,8 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
     }
     b->h_io_cap = count;
   }
-  if (!b->h2d_stream) {   // copies in on the pool's first stream, out on its second, kernels on its last (b->stream)
-    b->h2d_stream = pool_stream(b->device, 0); b->d2h_stream = pool_stream(b->device, 1);
+  if (!b->h2d_stream) {   // kernels on the pool's first stream (b->stream), copies in on its second, out on its third
+    b->h2d_stream = pool_stream(b->device, 1); b->d2h_stream = pool_stream(b->device, 2);
     if (!b->h2d_stream || !b->d2h_stream) return fail("stream creation failed");
   }
   // the schedule must exist before the plan can be read off it

@@ -29,13 +29,14 @@ for wl in wls:
     dI, dQ = bench.tiled_input(np, torch, dev, n_ch, 4, uniq, **sig)
     dOut = torch.empty((n_ch, 128), dtype=torch.int16, device=dev)
     cases = {}
-    for nl in (0, 2, 3, 4, 6, 8):
+    for nl in (-1, 0, 2, 3, 4, 6, 8):   # -1: the library's default for the schedule
         h = L.asdr_create(n_ch, 0)
 
         def step(i, h=h):
             L.asdr_update_device(h, C.c_void_p(dI[i & 3].data_ptr()), C.c_void_p(dQ[i & 3].data_ptr()), C.c_void_p(dOut.data_ptr()), 1, STREAM)
         ab.setup(L, h, wl, n_ch, step)
-        L.asdr_set_lanes(h, nl, 0)
+        if nl >= 0:
+            L.asdr_set_lanes(h, nl, 0)
         cases[nl] = (h, step)
     times = {k: [] for k in cases}
     for r in range(rounds + 1):
@@ -49,7 +50,7 @@ for wl in wls:
             L.asdr_region_timing_end(h, C.byref(total), C.byref(calls))
             if r > 0:
                 times[nl].append(total.value / max(1, calls.value))
-    print(json.dumps({"workload": wl, "channels": n_ch, "ms_per_step_by_lanes": {str(k): round(float(np.median(v)), 5) for k, v in times.items()}}), flush=True)
+    print(json.dumps({"workload": wl, "channels": n_ch, "ms_per_step_by_lanes": {("default" if k < 0 else str(k)): round(float(np.median(v)), 5) for k, v in times.items()}}), flush=True)
     for h, _ in cases.values():
         L.asdr_destroy(h)
     del dI, dQ, dOut
