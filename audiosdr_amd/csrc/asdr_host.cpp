@@ -1597,6 +1597,42 @@ int asdr_set_host_chunks(asdr_batch_t *b, int chunks) {
   b->host_chunks_forced = chunks;
   return 0;
 }
+// The chunk plan the overlapped host path would use for `chunks` chunks of this batch's current schedule (asdr_update, build_host_plan):
+// bound[0..chunks] = channel boundaries, need_in[p] = the last input chunk kernel part p waits for, last_part[j] = the kernel part after
+// which output chunk j is complete.  Host logic only: works on a control-plane-only batch after asdr_control_plane_flush (the tests'
+// handle on the plan's two promises -- no part runs before its channels have arrived, no chunk leaves before its channels are done).
+int asdr_debug_host_plan(asdr_batch_t *b, int chunks, int *bound, int *need_in, int *last_part) {
+  if (!b || is_sharded(b)) return fail("asdr_debug_host_plan: a plain batch");
+  if (chunks < 1 || chunks > b->n || b->sched_dirty) return fail("asdr_debug_host_plan: bad chunk count, or no schedule yet");
+  HostPlan hp;
+  build_host_plan(b, hp, chunks);
+  for (int j = 0; j <= chunks; j++) if (bound) bound[j] = hp.bound[j];
+  for (int j = 0; j < chunks; j++) { if (need_in) need_in[j] = hp.need_in[j]; if (last_part) last_part[j] = hp.last_part[j]; }
+  return 0;
+}
+// ... and the slots [first, first + count) of the schedule that kernel part `part` of `parts` launches, sub-range by sub-range:
+// out = up to 16 (first, count) pairs; returns the number of pairs.  (The same arithmetic as update_device_part.)
+int asdr_debug_part_slots(asdr_batch_t *b, int part, int parts, int *out) {
+  if (!b || is_sharded(b) || !out || parts < 1 || part < 0 || part >= parts || b->sched_dirty) return fail("asdr_debug_part_slots: bad argument");
+  int n = 0;
+  auto sub = [&](int first, int slots) {
+    const long w = slots / 8;
+    const int lo = (int)(w * part / parts) * 8, cnt = (int)(w * (part + 1) / parts) * 8 - lo;
+    if (cnt > 0 && n < 16) { out[2 * n] = first + lo; out[2 * n + 1] = cnt; n++; }
+  };
+  if (b->left_slots > 0) sub(b->left_first, b->left_slots);
+  for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
+    const int nu = b->kind_uniform_slots[k], nm = b->kind_slots[k] - nu;
+    if (nu > 0) sub(b->kind_first[k], nu);
+    if (nm > 0) sub(b->kind_first[k] + nu, nm);
+  }
+  return n;
+}
+int asdr_debug_schedule(asdr_batch_t *b, int *channels, int cap) {   // channel index of every schedule slot (n_channels = padding); returns the slot count
+  if (!b || is_sharded(b) || b->sched_dirty) return fail("asdr_debug_schedule: no schedule yet");
+  for (size_t i = 0; i < b->sched.size() && (int)i < cap; i++) channels[i] = b->sched[i].ch;
+  return (int)b->sched.size();
+}
 int asdr_host_path_info(asdr_batch_t *b, int out[2]) {
   if (!b || !out) return fail("null argument");
   const asdr_batch *s = is_sharded(b) ? b->shards[0] : b;

@@ -103,6 +103,13 @@ int asdr_host_register(void *p, size_t bytes);
 int asdr_host_unregister(void *p);
 int asdr_set_host_chunks(asdr_batch_t *b, int chunks);
 int asdr_host_path_info(asdr_batch_t *b, int out[2]);
+/* Test hooks (host logic only; they work on a control-plane-only batch after asdr_control_plane_flush): the chunk plan of the overlapped
+ * host path for `chunks` chunks -- bound[0..chunks] channel boundaries, need_in[p] = the last input chunk kernel part p waits for,
+ * last_part[j] = the part after which output chunk j is complete --, the schedule slots (first, count pairs, up to 16; returns their
+ * number) that part `part` of `parts` launches, and the channel of every schedule slot (returns the slot count; n_channels = padding). */
+int asdr_debug_host_plan(asdr_batch_t *b, int chunks, int *bound, int *need_in, int *last_part);
+int asdr_debug_part_slots(asdr_batch_t *b, int part, int parts, int *out);
+int asdr_debug_schedule(asdr_batch_t *b, int *channels, int cap);
 int asdr_update_device(asdr_batch_t *b, const int16_t *dI, const int16_t *dQ, int16_t *dOut, int n_blocks,
                        void *stream);
 /* Same, with explicit row strides in blocks: I and Q rows are in_stride_blocks*128 samples apart, out rows

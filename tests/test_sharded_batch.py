@@ -179,3 +179,76 @@ def test_sharded_device_pointers_capture_and_shard_handles(gpu):
     for c in (0, 267, 268, 700, n - 1):
         assert np.array_equal(one.capture_read(c), sh.capture_read(c)), c
     hip.free_all(); one.close(); sh.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The overlapped host path's chunk plan (asdr_update): host logic, checked without a device.
+@pytest.mark.parametrize("kind", ["one_group", "c4_mix", "halves", "scattered"])
+@pytest.mark.parametrize("chunks", [1, 2, 5, 16])
+def test_host_plan_never_runs_ahead_of_its_data(A, kind, chunks):
+    """For every settings mix and chunk count: (1) the kernel parts of a call launch every schedule slot exactly once; (2) every channel
+    a part touches lies in an input chunk <= need_in[part] (so its rows have arrived when the part starts: parts are enqueued in order
+    behind the event of chunk need_in[part]); (3) every channel of output chunk j is touched by a part <= last_part[j] (so the chunk
+    is complete when it is copied out); (4) for a batch of one settings group the plan is the perfect pipeline need_in[p] = p =
+    last_part[p]."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    n = 5003
+    b = A.AudioSDRBatch(n, device=-1)
+    L = A.load_library()
+    if kind == "one_group":
+        b.setDemodMode(1); b.enableAudioFilter()
+    elif kind == "c4_mix":
+        for c in range(n):
+            L.asdr_setDemodMode(b._h, c, c % 7)
+        b.enableALSfilter()
+    elif kind == "halves":
+        b.setDemodMode(1)
+        for c in range(n // 2, n):
+            L.asdr_setDemodMode(b._h, c, 5)
+        for c in range(100, 150):
+            b.enableALSfilter(ch=c); b.setALSfilterParams(100, 0.3, 5, ch=c)
+    else:
+        for c in range(n):
+            L.asdr_setDemodMode(b._h, c, int(rng.integers(0, 7)))
+            if rng.random() < 0.3:
+                L.asdr_enableALSfilter(b._h, c)
+            if rng.random() < 0.2:
+                L.asdr_enableAudioFilter(b._h, c)
+    b.control_plane_flush()
+    for name, at, rt in (("asdr_debug_host_plan", [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 3, C.c_int),
+                         ("asdr_debug_part_slots", [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)], C.c_int),
+                         ("asdr_debug_schedule", [C.c_void_p, C.POINTER(C.c_int), C.c_int], C.c_int)):
+        getattr(L, name).argtypes = at; getattr(L, name).restype = rt
+    K = chunks
+    bound, need_in, last_part = (C.c_int * (K + 1))(), (C.c_int * K)(), (C.c_int * K)()
+    assert L.asdr_debug_host_plan(b._h, K, bound, need_in, last_part) == 0, L.asdr_last_error()
+    bound, need_in, last_part = list(bound), list(need_in), list(last_part)
+    assert bound[0] == 0 and bound[-1] == n and all(bound[j] < bound[j + 1] for j in range(K))
+    sched = (C.c_int * (n + 64))()
+    n_slots = L.asdr_debug_schedule(b._h, sched, n + 64)
+    assert n <= n_slots <= n + 64
+    sched = np.array(sched[:n_slots])
+    chunk_of = np.searchsorted(np.array(bound[1:]), np.arange(n), side="right")          # channel -> chunk
+    seen = np.zeros(n_slots, dtype=int)
+    for p in range(K):
+        out = (C.c_int * 32)()
+        m = L.asdr_debug_part_slots(b._h, p, K, out)
+        assert m >= 0
+        for i in range(m):
+            first, cnt = out[2 * i], out[2 * i + 1]
+            assert first % 8 == 0 and cnt % 8 == 0
+            seen[first:first + cnt] += 1
+            chans = sched[first:first + cnt]
+            chans = chans[chans < n]
+            if len(chans):
+                assert chunk_of[chans].max() <= need_in[p], (p, int(chunk_of[chans].max()), need_in[p])      # (2)
+                for j in np.unique(chunk_of[chans]):
+                    assert last_part[j] >= p, (j, last_part[j], p)                                            # (3)
+    assert (seen == 1).all()                                                                                  # (1)
+    assert sorted(sched[sched < n].tolist()) == list(range(n))
+    assert all(need_in[p] <= need_in[p + 1] for p in range(K - 1))
+    if kind == "one_group":
+        # (8-channel waves: a part's last wave may reach into the next chunk by up to 7 channels, never further)
+        assert all(need_in[p] in (p, min(p + 1, K - 1)) for p in range(K)) and all(last_part[j] in (j, max(j - 1, 0), min(j + 1, K - 1)) for j in range(K))
+    b.close()
