@@ -418,7 +418,10 @@ void fill_params(const Chan &c, ChanParams &p) {
 // Wave scheduling: channels are grouped by kernel instantiation (plain / SAM / ALS) and, inside it, by (mode, enables, tables),
 // so that a wave's 8 channels take the same branches.  Rows of I/Q/out and of every state array are per channel, so the
 // grouping costs nothing in coalescing.
+int g_force_split = -1;   // EXPERIMENT (ASDR_FORCE_SPLIT=1): every channel without the ALS filter through the pre | (PLL) | post launches
 int kernel_kind(const ChanParams &p) {
+  if (g_force_split < 0) g_force_split = getenv("ASDR_FORCE_SPLIT") ? 1 : 0;
+  if (g_force_split && !(p.flags & ASDR_F_ALS_EN)) return ASDR_KERNEL_SAM;
   if (p.flags & ASDR_F_ALS_EN) {
     // a short filter on a channel that needs no PLL fits the plain instantiation's LDS rows (12 instead of 9 waves per CU)
     const bool small = p.als_m >= 0 && p.als_m <= 64 && p.als_delay >= 0 && p.als_delay + p.als_m <= 65;

@@ -2270,9 +2270,16 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pos
   asdr_update_body<ASDR_STRIDE, false, false, false, 1, 5>(a, lds);
 }
 // ... and their forms for waves of one schedule key (scalar mode / enable tests)
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre_kernel_uniform(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
-  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 4>(a, lds);
+// The pre role needs rows W0 and W1 only (input scale, blanker overlays, IF filter, tile transposition: all inside the first 256 words;
+// the phase row, the Hilbert history and the AGC overlay belong to the post role): 260-float rows (260 = 65 sixteen-byte slots == 1
+// mod 16, like 388: the 8 channels' rows start on different slots) = 8,320 B per wave -> 19 waves per CU by LDS, and at 126 VGPRs
+// FOUR waves per SIMD: the first instantiation of the chain at 16 waves per CU (round 4).
+#ifndef ASDR_PRE_STRIDE
+#define ASDR_PRE_STRIDE 260
+#endif
+extern "C" __global__ __launch_bounds__(64, 4) void asdr_sam_pre_kernel_uniform(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_PRE_STRIDE];
+  asdr_update_body<ASDR_PRE_STRIDE, false, false, true, 1, 4>(a, lds);
 }
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_kernel_uniform(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
