@@ -964,7 +964,10 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   if (parts == 1 && b->lanes_enabled && !needs_flush(b) && (batch_stream || n_blocks >= 2) && !b->taps_on && b->tev.empty() && !b->time_calls) {
     int total = b->left_slots;
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) total += b->kind_slots[k];
-    use_lanes = total / 8 >= b->lanes_min_waves &&
+    // (a call the block pipeline may take is not a lane call: the pipeline runs on `stream` and needs that stream's ordering)
+    const bool pipeline_candidate = b->stream_pipeline && n_blocks >= ASDR_STREAM_MIN_BLOCKS && b->plain_uniform_ssb &&
+                                    b->kind_uniform_slots[ASDR_KERNEL_PLAIN] > 0 && b->kind_uniform_slots[ASDR_KERNEL_PLAIN] / 8 <= b->stream_max_waves;
+    use_lanes = !pipeline_candidate && total / 8 >= b->lanes_min_waves &&
                 (batch_stream || total >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES || (b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS] > 0) ||
                  (b->als_split && b->kind_uniform_slots[ASDR_KERNEL_ALS_SMALL] > 0));   // (a strict call: only in its one-launch-per-block form)
   }
