@@ -813,6 +813,10 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     alloc((void **)&b->d_reset, rows * sizeof(uint32_t));
     alloc((void **)&b->d_lo, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry));   // + one set per lane: a lane's readers only ever see its own writer
     if (ok && hipMemset(b->d_lo, 0xFF, (1 + ASDR_LANES) * 2 * ASDR_LO_ENTRIES * sizeof(LoEntry)) != hipSuccess) ok = false;   // keys no phase can match
+    // hipMemset on device memory runs on the NULL stream and does not wait for itself on the host; the batch's kernels run on non-blocking
+    // streams, which the null stream does not order: without this the fills above can land AFTER a first kernel's stores (round 4's
+    // launch-form fuzz caught exactly that on the stage taps: one word of a tap row zeroed behind the kernel that had written it)
+    if (ok && hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
     for (int i = 0; i < ASDR_LANES + 1 && ok; i++)
       if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
@@ -1978,6 +1982,7 @@ int asdr_set_exact_unknown_mode(asdr_batch_t *b, int on) {
     HIPCHK(hipSetDevice(b->device));
     if (sync_all(b) != 0) return -1;
     HIPCHK(hipMemset(b->d_audio_prev, 0, ((size_t)b->n + 1) * 128 * sizeof(float)));
+    HIPCHK(hipStreamSynchronize(nullptr));   // (the fill runs on the null stream: see asdr_create)
   }
   b->exact_unknown_mode = want;
   return 0;
@@ -2040,6 +2045,7 @@ int asdr_enable_taps(asdr_batch_t *b, int on) {
     const size_t bytes = (size_t)ASDR_N_TAPS * b->n * ASDR_N * sizeof(float);
     HIPCHK(hipMalloc(&b->d_taps, bytes));
     HIPCHK(hipMemset(b->d_taps, 0, bytes));
+    HIPCHK(hipStreamSynchronize(nullptr));   // (the fill runs on the null stream: see asdr_create)
   }
   b->taps_on = on != 0;
   return 0;

@@ -57,9 +57,11 @@ def _seeds():
     return [1, 2, 3, 4, 5, 6, 7, 8]
 
 
-@pytest.mark.parametrize("seed", _seeds())
-def test_every_launch_form_equals_the_plain_one(gpu, ao, seed):
+def run_sequence(gpu, seed, sync_each=False, log=None):
+    """One random sequence; returns nothing, asserts equality.  sync_each: synchronise and compare after every call (the replay tool:
+    a seed that fails without and passes with it is an ordering bug between launch forms); log: a callable for one line per step."""
     from audiosdr_amd.synth import make_iq
+    log = log or (lambda *a: None)
     rng = np.random.default_rng(1000 + seed)
     # sizes around the thresholds: the pipeline (<= 512 groups), the lanes (>= 1024 waves), one launch per block (>= 1024 waves)
     n = int(rng.choice([40, 700, 4100, 8200 + int(rng.integers(0, 9)), 16384 + 5]))
@@ -77,11 +79,13 @@ def test_every_launch_form_equals_the_plain_one(gpu, ao, seed):
     subj.set_lanes(lanes, 64)                       # lanes from 64 waves on: also on the small sizes
     ops = _random_settings(rng, n, big_groups=bool(rng.integers(0, 2)))
     _apply(subj, ops); _apply(plain, ops)
+    log("n", n, "blocks", total, "shards", shards, "lanes", lanes, "settings", [(o[0], o[1], len(o[2])) for o in ops])
     hip = Hip()
     s1 = hip.stream()
     dI, dQ = hip.upload(I), hip.upload(Q)
+    dI2 = hip.upload(I)                             # the subject's own copy of the I rows: some calls write their audio over them (in place)
     dS, dP = hip.malloc(n * total * 256), hip.malloc(n * total * 256)
-    pos, host_rows = 0, {}
+    pos, host_rows, in_place, taps_on = 0, {}, [], False
     while pos < total:
         T = int(min(total - pos, rng.choice([1, 1, 1, 2, 3, 9, 12])))
         off = pos * 256
@@ -104,9 +108,20 @@ def test_every_launch_form_equals_the_plain_one(gpu, ao, seed):
                 subj.shard(g).update_device_strided(dI + o2, dQ + o2, dS + o2, T, total, total, gpu.STREAM_BATCH if form == "batch" else (s1 if form == "stream" else 0))
         else:
             st = gpu.STREAM_BATCH if (form == "batch" and shards == 1) else (s1 if form == "stream" else 0)
-            subj.update_device_strided(dI + off, dQ + off, dS + off, T, total, total, st)
+            if rng.random() < 0.25:                 # in place, the reference's own convention (the audio goes into blockI: AudioSDR.cpp:158-165)
+                subj.update_device_strided(dI2 + off, dQ + off, dI2 + off, T, total, total, st)
+                in_place.append((pos, T))
+            else:
+                subj.update_device_strided(dI + off, dQ + off, dS + off, T, total, total, st)
         for k in range(T):                          # the plain form: one block per call, one stream
             plain.update_device_strided(dI + off + k * 256, dQ + off + k * 256, dP + off + k * 256, 1, total, total, 0)
+        log("call at block", pos, "T", T, form, "in place" if (in_place and in_place[-1][0] == pos) else "", "taps" if taps_on else "",
+            "| pipeline launches", subj.stream_pipeline_launches(), "lane calls", subj.lane_calls())
+        if sync_each:
+            subj.synchronize(); plain.synchronize()
+            if taps_on:
+                tS, tP = subj.read_taps(), plain.read_taps()
+                log("   taps differ:", [k for k in tS if tS[k].tobytes() != tP[k].tobytes()])
         pos += T
         if rng.random() < 0.35:                     # setters between calls, by global channel index
             c = int(rng.integers(0, n))
@@ -115,15 +130,33 @@ def test_every_launch_form_equals_the_plain_one(gpu, ao, seed):
                           ("setMute", (int(rng.integers(0, 2)),))][int(rng.integers(0, 6))]
             for b in (subj, plain):
                 getattr(b, meth)(*args, ch=c)
+            log("   setter", meth, args, "ch", c)
         if rng.random() < 0.15:
             subj.read_status()                      # a host-side read in between (synchronises the lanes)
+        if rng.random() < 0.1:                      # stage taps on / off (while on: no lanes, no pipeline)
+            taps_on = not taps_on
+            subj.enable_taps(taps_on); plain.enable_taps(taps_on)
+            log("   taps", taps_on)
     subj.synchronize(); plain.synchronize()
     wS, wP = hip.download(dS, (n, total, 128), np.int16), hip.download(dP, (n, total, 128), np.int16)
     for p0, rows in host_rows.items():
         wS[:, p0:p0 + rows.shape[1]] = rows
+    if in_place:
+        wI = hip.download(dI2, (n, total, 128), np.int16)
+        for p0, T in in_place:
+            wS[:, p0:p0 + T] = wI[:, p0:p0 + T]
+    if taps_on:
+        tS, tP = subj.read_taps(), plain.read_taps()
+        for k in tS:
+            assert tS[k].tobytes() == tP[k].tobytes(), (seed, "tap", k)
     assert np.array_equal(wS, wP), "seed %d (n %d, %d shards, %d lanes): %d samples differ, first at %s" % (
         seed, n, shards, lanes, int((wS != wP).sum()), np.argwhere(wS != wP)[0].tolist())
     sS, sP = subj.read_status(), plain.read_status()
     for k in sS:
         assert sS[k].tobytes() == sP[k].tobytes(), (seed, k)
     hip.free_all(); subj.close(); plain.close()
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_every_launch_form_equals_the_plain_one(gpu, ao, seed):
+    run_sequence(gpu, seed)
