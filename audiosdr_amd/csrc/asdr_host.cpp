@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -130,24 +131,30 @@ float time_constant(float ms) {  // AudioSDR.cpp:448/553: exp(log(0.1) / (FS*ms/
 }  // namespace
 
 namespace {
-class CopyPool {   // a handful of threads that copy chunks between caller memory and the pinned staging area
+class CopyPool {   // a handful of threads that copy between caller memory and the pinned staging area, all of them on ONE chunk at a time
  public:
+  // A chunk is copied as `slices` slices, claimed one by one: every worker helps with the chunk the DMA waits for next (a whole chunk per
+  // worker left the first H2D waiting for one thread's 4 MB: 0.5 ms of a 1 ms call).  Waiting is a short sleep, not a spin: the box
+  // gives a process fewer threads than it shows, and spinning waiters take the cores the copying threads need.
   struct Job {
-    int n_chunks = 0;
-    std::function<void(int)> copy_in, copy_out;
-    std::vector<std::atomic<int>> in_done, out_ready;
+    int n_chunks = 0, slices = 1;
+    std::function<void(int, int, int)> copy_in, copy_out;   // (chunk, slice, slices)
+    std::vector<std::atomic<int>> in_done, out_ready;        // in_done[k] counts finished slices; out_ready[k]: the chunk's D2H is complete
     std::atomic<int> next_in{0}, next_out{0}, out_finished{0}, workers_left{0};
-    explicit Job(int k) : n_chunks(k), in_done(k), out_ready(k) { for (int i = 0; i < k; i++) { in_done[i].store(0); out_ready[i].store(0); } }
+    Job(int k, int sl) : n_chunks(k), slices(sl), in_done(k), out_ready(k) { for (int i = 0; i < k; i++) { in_done[i].store(0); out_ready[i].store(0); } }
   };
+  static void nap() { std::this_thread::sleep_for(std::chrono::microseconds(20)); }
   explicit CopyPool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); }); }
   ~CopyPool() { { std::lock_guard<std::mutex> g(m_); quit_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
   int threads() const { return (int)th_.size(); }
   void start(Job *j) { j->workers_left.store((int)th_.size()); { std::lock_guard<std::mutex> g(m_); job_ = j; gen_++; } cv_.notify_all(); }
   static void work(Job *j) {
-    for (int k; (k = j->next_in.fetch_add(1)) < j->n_chunks;) { j->copy_in(k); j->in_done[k].store(1, std::memory_order_release); }
-    for (int k; (k = j->next_out.fetch_add(1)) < j->n_chunks;) {
-      while (!j->out_ready[k].load(std::memory_order_acquire)) std::this_thread::yield();
-      j->copy_out(k); j->out_finished.fetch_add(1, std::memory_order_release);
+    const int n_tasks = j->n_chunks * j->slices;
+    for (int t; (t = j->next_in.fetch_add(1)) < n_tasks;) { const int k = t / j->slices; j->copy_in(k, t % j->slices, j->slices); j->in_done[k].fetch_add(1, std::memory_order_release); }
+    for (int t; (t = j->next_out.fetch_add(1)) < n_tasks;) {
+      const int k = t / j->slices;
+      while (!j->out_ready[k].load(std::memory_order_acquire)) nap();
+      j->copy_out(k, t % j->slices, j->slices); j->out_finished.fetch_add(1, std::memory_order_release);
     }
   }
  private:
@@ -1446,13 +1453,16 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
       int nt = e ? atoi(e) : 4;
       b->copy_pool.reset(new CopyPool(std::max(1, std::min(nt, 32))));
     }
-    job.reset(new CopyPool::Job(K));
-    job->copy_in = [=, &hp](int j) {
-      const size_t o = (size_t)hp.bound[j] * row, nsm = (size_t)(hp.bound[j + 1] - hp.bound[j]) * row;
+    job.reset(new CopyPool::Job(K, b->copy_pool->threads()));
+    // slice s of S of chunk j: the channels [c0 + n s / S, c0 + n (s + 1) / S) of its range
+    job->copy_in = [=, &hp](int j, int sl, int S) {
+      const size_t c0 = (size_t)hp.bound[j], nc = (size_t)(hp.bound[j + 1] - hp.bound[j]);
+      const size_t o = (c0 + nc * sl / S) * row, nsm = (nc * (sl + 1) / S - nc * sl / S) * row;
       memcpy(b->h_io[0] + o, I + o, nsm * sizeof(int16_t)); memcpy(b->h_io[1] + o, Q + o, nsm * sizeof(int16_t));
     };
-    job->copy_out = [=, &hp](int j) {
-      const size_t o = (size_t)hp.bound[j] * row, nsm = (size_t)(hp.bound[j + 1] - hp.bound[j]) * row;
+    job->copy_out = [=, &hp](int j, int sl, int S) {
+      const size_t c0 = (size_t)hp.bound[j], nc = (size_t)(hp.bound[j + 1] - hp.bound[j]);
+      const size_t o = (c0 + nc * sl / S) * row, nsm = (nc * (sl + 1) / S - nc * sl / S) * row;
       memcpy(out + o, b->h_io[2] + o, nsm * sizeof(int16_t));
     };
     b->copy_pool->start(job.get());
@@ -1463,14 +1473,14 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
     ~JobGuard() {
       if (!j) return;
       for (int k = 0; k < j->n_chunks; k++) j->out_ready[k].store(1, std::memory_order_release);
-      while (j->workers_left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      while (j->workers_left.load(std::memory_order_acquire) > 0) CopyPool::nap();
     }
   } guard{job.get()};
   int rc = 0;
   int next_part = 0, next_out = 0;
   for (int j = 0; j < K && rc == 0; j++) {
     const size_t o = (size_t)hp.bound[j] * row, nsm = (size_t)(hp.bound[j + 1] - hp.bound[j]) * row;
-    if (job) while (!job->in_done[j].load(std::memory_order_acquire)) std::this_thread::yield();
+    if (job) while (job->in_done[j].load(std::memory_order_acquire) < job->slices) std::this_thread::yield();   // (the enqueuing thread is the one the DMA waits for: it may spin)
     HIPCHK(hipMemcpyAsync(b->d_io[0] + o, srcI + o, nsm * sizeof(int16_t), hipMemcpyHostToDevice, b->h2d_stream));
     HIPCHK(hipMemcpyAsync(b->d_io[1] + o, srcQ + o, nsm * sizeof(int16_t), hipMemcpyHostToDevice, b->h2d_stream));
     HIPCHK(hipEventRecord(ev_in[j], b->h2d_stream));
@@ -1494,7 +1504,7 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
     HIPCHK(hipEventSynchronize(ev_out[j]));
     if (job) job->out_ready[j].store(1, std::memory_order_release);
   }
-  if (job) while (job->out_finished.load(std::memory_order_acquire) < K) std::this_thread::yield();
+  if (job) while (job->out_finished.load(std::memory_order_acquire) < K * job->slices) CopyPool::nap();
   HIPCHK(hipStreamSynchronize(b->stream));
   b->stat_host_chunks = K; b->stat_host_pinned = pinned ? 1 : 0;
   return check_stream_error(b);
