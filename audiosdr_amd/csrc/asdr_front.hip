@@ -15,12 +15,12 @@
 #define WAVE_SYNC() __syncthreads() /* workgroup == one wave: a wave barrier + LDS/VMEM waits */
 
 __constant__ float c_iq_taps[64];
-__constant__ float c_tw[64][2];
+__constant__ float c_cftw[128][2];   // CMSIS twiddleCoef_128 (cos, +sin): the detector's FFT is the reference's arm_cfft_f32
 __constant__ float c_tw256[128][2];
 
 extern "C" int asdr_front_upload_tables(void) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_iq_taps), asdr_iqgen_hilbert_taps, sizeof(asdr_iqgen_hilbert_taps)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(c_tw), asdr_fft128_tw, sizeof(asdr_fft128_tw)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_cftw), asdr_cfft128_tw, sizeof(asdr_cfft128_tw)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_tw256), asdr_fft256_tw, sizeof(asdr_fft256_tw)) != hipSuccess) return -1;
   return 0;
 }
@@ -41,16 +41,77 @@ __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (
 // AudioSDRpreProcessor: 16 lanes per channel (8 samples each; a DPP row is exactly one channel), 4 channels per wave.
 // Blocks of one call are processed in order because the detector may change the correction between blocks.
 // =====================================================================================================
+// One radix-8 butterfly of CMSIS-DSP arm_radix8_butterfly_f32 on points i1, i1 + n2, .., i1 + 7 n2 of X (oracle/asdr_front_oracle.c
+// cf_radix8, which is held bit for bit against the reference's Cortex-M4 object: tests/test_cmsis_object.py): TW = false is the
+// twiddle-free form (the first column of a stage / the last stage), TW = true multiplies outputs 2..8 by (co[k], si[k]) = tw[(k - 1) tws].
+// Every product and sum separately rounded, in the object's association.
+#define CF_C81 0.70710678118f
+template <bool TW>
+__device__ __forceinline__ void cf_radix8(float2 *X, int i1, int n2, const float2 *tw, int tws) {
+  const int i2 = i1 + n2, i3 = i2 + n2, i4 = i3 + n2, i5 = i4 + n2, i6 = i5 + n2, i7 = i6 + n2, i8 = i7 + n2;
+  const float2 x1 = X[i1], x2 = X[i2], x3 = X[i3], x4 = X[i4], x5 = X[i5], x6 = X[i6], x7 = X[i7], x8 = X[i8];
+  float r1, r2, r3, r4, r5, r6, r7, r8, t1, t2, s1, s2, s3, s4, s5, s6, s7, s8;
+  r1 = x1.x + x5.x; r5 = x1.x - x5.x;
+  r2 = x2.x + x6.x; r6 = x2.x - x6.x;
+  r3 = x3.x + x7.x; r7 = x3.x - x7.x;
+  r4 = x4.x + x8.x; r8 = x4.x - x8.x;
+  t1 = r1 - r3; r1 = r1 + r3; r3 = r2 - r4; r2 = r2 + r4;
+  if (!TW) {
+    float2 o1, o2, o3, o4, o5, o6, o7, o8;
+    o1.x = r1 + r2; o5.x = r1 - r2;
+    r1 = x1.y + x5.y; s5 = x1.y - x5.y;
+    r2 = x2.y + x6.y; s6 = x2.y - x6.y;
+    s3 = x3.y + x7.y; s7 = x3.y - x7.y;
+    r4 = x4.y + x8.y; s8 = x4.y - x8.y;
+    t2 = r1 - s3; r1 = r1 + s3; s3 = r2 - r4; r2 = r2 + r4;
+    o1.y = r1 + r2; o5.y = r1 - r2;
+    o3.x = t1 + s3; o7.x = t1 - s3; o3.y = t2 - r3; o7.y = t2 + r3;
+    r1 = (r6 - r8) * CF_C81; r6 = (r6 + r8) * CF_C81; r2 = (s6 - s8) * CF_C81; s6 = (s6 + s8) * CF_C81;
+    t1 = r5 - r1; r5 = r5 + r1; r8 = r7 - r6; r7 = r7 + r6;
+    t2 = s5 - r2; s5 = s5 + r2; s8 = s7 - s6; s7 = s7 + s6;
+    o2.x = r5 + s7; o8.x = r5 - s7; o6.x = t1 + s8; o4.x = t1 - s8;
+    o2.y = s5 - r7; o8.y = s5 + r7; o6.y = t2 - r8; o4.y = t2 + r8;
+    X[i1] = o1; X[i2] = o2; X[i3] = o3; X[i4] = o4; X[i5] = o5; X[i6] = o6; X[i7] = o7; X[i8] = o8;
+  } else {
+    float2 o1, o2, o3, o4, o5, o6, o7, o8;
+    float p1, p2, p3, p4;
+    o1.x = r1 + r2; r2 = r1 - r2;
+    s1 = x1.y + x5.y; s5 = x1.y - x5.y;
+    s2 = x2.y + x6.y; s6 = x2.y - x6.y;
+    s3 = x3.y + x7.y; s7 = x3.y - x7.y;
+    s4 = x4.y + x8.y; s8 = x4.y - x8.y;
+    t2 = s1 - s3; s1 = s1 + s3; s3 = s2 - s4; s2 = s2 + s4;
+    r1 = t1 + s3; t1 = t1 - s3;
+    o1.y = s1 + s2; s2 = s1 - s2;
+    s1 = t2 - r3; t2 = t2 + r3;
+    const float2 w2 = tw[tws], w3 = tw[2 * tws], w4 = tw[3 * tws], w5 = tw[4 * tws], w6 = tw[5 * tws], w7 = tw[6 * tws], w8 = tw[7 * tws];
+    p1 = w5.x * r2; p2 = w5.y * s2; p3 = w5.x * s2; p4 = w5.y * r2; o5.x = p1 + p2; o5.y = p3 - p4;
+    p1 = w3.x * r1; p2 = w3.y * s1; p3 = w3.x * s1; p4 = w3.y * r1; o3.x = p1 + p2; o3.y = p3 - p4;
+    p1 = w7.x * t1; p2 = w7.y * t2; p3 = w7.x * t2; p4 = w7.y * t1; o7.x = p1 + p2; o7.y = p3 - p4;
+    r1 = (r6 - r8) * CF_C81; r6 = (r6 + r8) * CF_C81; s1 = (s6 - s8) * CF_C81; s6 = (s6 + s8) * CF_C81;
+    t1 = r5 - r1; r5 = r5 + r1; r8 = r7 - r6; r7 = r7 + r6;
+    t2 = s5 - s1; s5 = s5 + s1; s8 = s7 - s6; s7 = s7 + s6;
+    r1 = r5 + s7; r5 = r5 - s7; r6 = t1 + s8; t1 = t1 - s8;
+    s1 = s5 - r7; s5 = s5 + r7; s6 = t2 - r8; t2 = t2 + r8;
+    p1 = w2.x * r1; p2 = w2.y * s1; p3 = w2.x * s1; p4 = w2.y * r1; o2.x = p1 + p2; o2.y = p3 - p4;
+    p1 = w8.x * r5; p2 = w8.y * s5; p3 = w8.x * s5; p4 = w8.y * r5; o8.x = p1 + p2; o8.y = p3 - p4;
+    p1 = w6.x * r6; p2 = w6.y * s6; p3 = w6.x * s6; p4 = w6.y * r6; o6.x = p1 + p2; o6.y = p3 - p4;
+    p1 = w4.x * t1; p2 = w4.y * t2; p3 = w4.x * t2; p4 = w4.y * t1; o4.x = p1 + p2; o4.y = p3 - p4;
+    X[i1] = o1; X[i2] = o2; X[i3] = o3; X[i4] = o4; X[i5] = o5; X[i6] = o6; X[i7] = o7; X[i8] = o8;
+  }
+}
+
 __device__ __forceinline__ int dpp_row_shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); }
 
 __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
   __shared__ float2 X[4][128];      // FFT work area, one row per channel of the wave
   __shared__ float P[4][132];       // line powers 0..127 (+ the reference's buffer[128] at [128])
-  __shared__ float2 TW[64];
+  __shared__ float2 TW[128];        // CMSIS twiddleCoef_128: (cos, +sin)(2 pi k / 128)
   const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
   const int ch = blockIdx.x * 4 + r;
   const bool valid = ch < a.n_channels;
-  TW[lane] = make_float2(c_tw[lane][0], c_tw[lane][1]);
+  TW[lane] = make_float2(c_cftw[lane][0], c_cftw[lane][1]);
+  TW[lane + 64] = make_float2(c_cftw[lane + 64][0], c_cftw[lane + 64][1]);
   asdr_pre_state_t st;
   if (valid) st = a.state[ch];      // every lane of the row keeps a copy; all of them update it identically
   else { st.correction = 0; st.saved_sample = 0; st.failure_count = 0; st.success_count = 0; st.auto_detect = 0; st.swap = 0;
@@ -58,7 +119,6 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
   int corr = st.correction, saved = st.saved_sample, fail = st.failure_count, succ = st.success_count;
   int autodet = valid ? st.auto_detect : 0;
   const int swap = st.swap;
-  const int brl = ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);   // bitrev4(l)
   WAVE_SYNC();
 
 #pragma unroll 1
@@ -96,41 +156,51 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
     // ---- skew detector, .cpp:82-122: image ratio of the strongest line of a 128-point FFT ---------------
     if (__any(autodet)) {
       if (autodet) {
-        // x[n] -> X[bitrev7(n)], n = 8l + j: bitrev7 = bitrev3(j) << 4 | bitrev4(l)
+        // the block as complex float32 in natural order (.cpp:88-91)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int brj = ((j & 1) << 2) | (j & 2) | ((j & 4) >> 2);
-          X[r][(brj << 4) | brl] = make_float2(unit_scale(xi[j]), unit_scale(xq[j]));
+        for (int j = 0; j < 8; ++j) X[r][8 * l + j] = make_float2(unit_scale(xi[j]), unit_scale(xq[j]));
+      }
+      WAVE_SYNC();
+      // arm_cfft_f32(&arm_cfft_sR_f32_len128, buffer, 0, 1) (.cpp:93), operation for operation (oracle ao_fft128 == the reference's
+      // Cortex-M4 objects, bit for bit).  (1) arm_cfft_radix8by2_f32: the quarters q, q + 32, q + 64, q + 96 -- 32 values of q, two per lane.
+      if (autodet) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = l + 16 * h;
+          const float2 t1 = X[r][q], t3 = X[r][q + 32], t2o = X[r][q + 64], t4o = X[r][q + 96], w = TW[q];
+          const float2 sum1 = make_float2(t1.x + t2o.x, t1.y + t2o.y), t2 = make_float2(t1.x - t2o.x, t1.y - t2o.y);
+          const float2 sum3 = make_float2(t3.x + t4o.x, t3.y + t4o.y), t4 = make_float2(t4o.x - t3.x, t4o.y - t3.y);
+          float m0 = t2.x * w.x, m1 = t2.y * w.y, m2 = t2.y * w.x, m3 = t2.x * w.y;
+          const float2 o2 = make_float2(m0 + m1, m2 - m3);
+          m0 = t4.x * w.y; m1 = t4.y * w.x; m2 = t4.y * w.y; m3 = t4.x * w.x;
+          const float2 o4 = make_float2(m0 - m1, m2 + m3);
+          X[r][q] = sum1; X[r][q + 32] = sum3; X[r][q + 64] = o2; X[r][q + 96] = o4;
         }
       }
       WAVE_SYNC();
-      // radix-2 decimation-in-time, 7 stages x 64 butterflies per channel, 4 per lane; arithmetic of ao_fft128
-#pragma unroll
-      for (int s = 1; s <= 7; ++s) {
-        const int h = 1 << (s - 1);
-        if (autodet) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int b = l + 16 * q;
-            const int j = b & (h - 1), k = (b >> (s - 1)) << s;
-            const float2 w = TW[j << (7 - s)];
-            const float2 u = X[r][k + j], v = X[r][k + j + h];
-            const float p0 = w.x * v.x, p1 = w.y * v.y, p2 = w.x * v.y, p3 = w.y * v.x;
-            const float tr = p0 - p1, ti = p2 + p3;
-            X[r][k + j] = make_float2(u.x + tr, u.y + ti);
-            X[r][k + j + h] = make_float2(u.x - tr, u.y - ti);
-          }
-        }
-        WAVE_SYNC();
+      // (2) arm_radix8_butterfly_f32(half, 64, twiddleCoef_128, 2) on both halves, stage 1 (n2 = 8): 16 butterflies, one per lane --
+      // column j = l & 7 of half l >> 3; column 0 is the twiddle-free form, column j uses tw[(k - 1) 2 j]
+      if (autodet) {
+        float2 *Xh = X[r] + 64 * (l >> 3);
+        const int j = l & 7;
+        if (j == 0) cf_radix8<false>(Xh, 0, 8, TW, 0);
+        else cf_radix8<true>(Xh, j, 8, TW, 2 * j);
       }
+      WAVE_SYNC();
+      // (3) stage 2 (n2 = 1): eight twiddle-free butterflies per half on consecutive points, one per lane
+      if (autodet) cf_radix8<false>(X[r] + 64 * (l >> 3), 8 * (l & 7), 1, TW, 0);
+      WAVE_SYNC();
       if (autodet) {              // arm_cmplx_mag_squared_f32, .cpp:94
+        // (4) arm_bitreversal_32 is a permutation: natural-order line k = 16 c + 2 b + a sits at position 64 a + 8 b + c; the powers
+        // (arm_cmplx_mag_squared_f32: re re + im im, also held against its object) are formed straight from there
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float2 x = X[r][8 * l + j];
+          const int k = 8 * l + j, pos = 64 * (k & 1) + 8 * ((k >> 1) & 7) + (k >> 4);
+          const float2 x = X[r][pos];
           const float p = x.x * x.x, q = x.y * x.y;
-          P[r][8 * l + j] = p + q;
+          P[r][k] = p + q;
         }
-        if (l == 0) P[r][128] = X[r][64].x;   // what the reference's buffer[128] holds after the in-place magnitude pass
+        if (l == 0) P[r][128] = X[r][4].x;   // line 64's real part (position 4): what the reference's buffer[128] holds after the in-place magnitude pass
       }
       WAVE_SYNC();
       if (autodet) {

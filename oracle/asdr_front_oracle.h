@@ -4,18 +4,16 @@
  * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import,
  * call, link or execute anything under oracle/; nothing under audiosdr_amd/ or include/ does.
  *
- * PARITY UNPINNED, as for asdr_oracle.h: the reference is Teensy/Arduino C++ and cannot be built or run in this
+ * PARITY UNPINNED as a whole, as for asdr_oracle.h: the reference is Teensy/Arduino C++ and cannot be built or run in this
  * image (no Teensy core, CMSIS-DSP only as ARM binaries there), and it ships no golden vectors.  Each function
- * below cites the reference file:line it restates.  One part cannot even be restated operation-for-operation:
- * the pre-processor's detector calls CMSIS-DSP `arm_cfft_f32(&arm_cfft_sR_f32_len128, buf, 0, 1)` (CMSIS-DSP as
- * bundled with the Teensy core, arm_math.h of CMSIS 4.5; a radix-8-by-2 decimation-in-frequency transform followed
- * by bit reversal), whose SOURCE is absent from /root/reference.  The detector here therefore uses this project's
- * own 128-point float32 FFT (ao_fft128, a radix-2 decimation-in-time transform whose arithmetic is defined below
- * and implemented identically on the GPU): same mathematical transform, rounding differs at the 1e-7 level, so the
- * power spectrum agrees with the reference's to float32 tolerance and the vote counters agree except for blocks
- * whose power ratios sit within that tolerance of a threshold.  Everything else (skew correction incl. the -1
- * branch's quirk, the summation ORDER of the line powers, thresholds, counters, swap; the IQ generator; the
- * grabber) is restated operation for operation.
+ * below cites the reference file:line it restates.  The two CMSIS-DSP functions the pre-processor's detector calls --
+ * `arm_cfft_f32(&arm_cfft_sR_f32_len128, buf, 0, 1)` and `arm_cmplx_mag_squared_f32` (AudioSDRpreProcessor.cpp:93-94) -- have no
+ * source in /root/reference, only Cortex-M4 objects inside libarm_cortexM4lf_math.a.  Until round 3 the detector here used this
+ * project's own radix-2 FFT (same transform, 1e-7 rounding differences: tolerance-only parity for the power spectrum).  From round
+ * 4 ao_fft128 restates the published CMSIS algorithm (radix-8-by-2 decimation in frequency + digit reversal) operation for operation
+ * and is PINNED AGAINST THE REFERENCE'S BINARY: tests/thumb_emu.py links and executes the objects, tests/test_cmsis_object.py holds
+ * ao_fft128 equal to them bit for bit.  Everything else (skew correction incl. the -1 branch's quirk, the summation ORDER of the line
+ * powers, thresholds, counters, swap; the IQ generator; the grabber) is restated operation for operation from the reference's source.
  */
 #ifndef ASDR_FRONT_ORACLE_H_
 #define ASDR_FRONT_ORACLE_H_
@@ -47,12 +45,11 @@ typedef struct {
 void ao_pre_get_state(const ao_pre_t *p, ao_pre_state_t *s);
 const float *ao_pre_power_spectrum(const ao_pre_t *p);                     /* 128 line powers of the last detector pass */
 
-/* this project's 128-point complex float32 FFT, in place on interleaved re/im:
- *   X[bitrev7(n)] = x[n];  for s = 1..7 (m = 2^s, h = m/2): for every k = 0, m, 2m, ... and j = 0..h-1:
- *     w = asdr_fft128_tw[j * (128/m)];  u = X[k+j];  v = X[k+j+h];
- *     t.re = w.re*v.re - w.im*v.im;  t.im = w.re*v.im + w.im*v.re;     (each product and the sum rounded: no FMA)
- *     X[k+j] = u + t;  X[k+j+h] = u - t;
- * Butterflies of one stage are independent, so any schedule gives the same bits. */
+/* The reference's 128-point complex float32 FFT -- CMSIS-DSP arm_cfft_f32, len 128, forward, bit-reversed to natural order -- in place
+ * on interleaved re/im (asdr_front_oracle.c spells the algorithm out): radix-2 DIF pass with twiddleCoef_128 over the quarters
+ * (q, q + 32, q + 64, q + 96), two 64-point radix-8 transforms (stage 1: column 0 twiddle-free, columns 1..7 with twiddles; stage 2:
+ * eight twiddle-free butterflies on consecutive points), digit reversal (line 16 c + 2 b + a <- position 64 a + 8 b + c).  Every
+ * product and sum separately rounded.  Butterflies of one stage are independent, so any schedule gives the same bits. */
 void ao_fft128(float *buf /* [256] */);
 
 /* ---- AudioIQgenerator (AudioIQgenerator.h:48-106, .cpp:33-87) ---- */

@@ -361,8 +361,15 @@ class OracleGrabber:
         return d
 
 
+def fft128_interleaved(buf):
+    """ao_fft128 on 256 float32 words (re, im interleaved), as the reference hands its buffer to arm_cfft_f32; returns the 256 words."""
+    b = np.ascontiguousarray(buf, dtype=np.float32).copy().reshape(256)
+    lib().ao_fft128(_fp(b))
+    return b
+
+
 def fft128(x):
-    """This project's float32 128-point FFT of a complex vector (see asdr_front_oracle.h)."""
+    """The reference's 128-point float32 FFT (CMSIS arm_cfft_f32 restated, asdr_front_oracle.h) of a complex vector."""
     buf = np.empty(256, dtype=np.float32)
     x = np.asarray(x)
     buf[0::2] = x.real.astype(np.float32); buf[1::2] = x.imag.astype(np.float32)

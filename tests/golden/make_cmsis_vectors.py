@@ -1,4 +1,5 @@
-"""Makes tests/golden/cmsis_biquad_vectors.npz: outputs of the REFERENCE'S OWN BINARY of CMSIS-DSP V1.4.5
+"""Makes tests/golden/cmsis_biquad_vectors.npz and cmsis_cfft128_vectors.npz: outputs of the REFERENCE'S OWN BINARIES of CMSIS-DSP V1.4.5
+`arm_cfft_f32` (128 points: arm_cfft_f32.o, arm_cfft_radix8_f32.o, arm_bitreversal2.o and their tables, linked by tests/thumb_emu.py) and
 `arm_biquad_cascade_df1_f32` (member arm_biquad_cascade_df1_f32.o of the reference's
 `ARM_MATH UPDATE/TeensyduinoArmMathUpdate/libarm_cortexM4lf_math.a`), executed instruction by instruction by tests/thumb_emu.py
 in this container (no ARM hardware or toolchain here).  The fixture holds data only: inputs (coefficients, state, samples) and the
@@ -32,6 +33,16 @@ def main():
     out["names"] = np.array(names)
     np.savez_compressed(C.GOLDEN, **out)
     print("wrote %s: %d cases" % (C.GOLDEN, len(names)))
+    # arm_cfft_f32 (128 points, forward, bit-reversed to natural order): the linked objects executed on the emulator
+    cpu, img = C.cfft_image()
+    out, names = {}, []
+    for i, (name, x) in enumerate(C.cfft_cases()):
+        names.append(name)
+        out["x_%d" % i] = np.asarray(x, np.float32)
+        out["y_bits_%d" % i] = C.run_cfft128(cpu, img, x).view(np.uint32)
+    out["names"] = np.array(names)
+    np.savez_compressed(C.GOLDEN_CFFT, **out)
+    print("wrote %s: %d cases" % (C.GOLDEN_CFFT, len(names)))
 
 
 if __name__ == "__main__":

@@ -23,6 +23,7 @@ from tests import thumb_emu as T
 
 ARCHIVE = "/root/reference/ARM_MATH UPDATE/TeensyduinoArmMathUpdate/libarm_cortexM4lf_math.a"
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cmsis_biquad_vectors.npz")
+GOLDEN_CFFT = os.path.join(os.path.dirname(__file__), "golden", "cmsis_cfft128_vectors.npz")
 needs_reference = pytest.mark.skipif(not os.path.exists(ARCHIVE), reason="the reference's CMSIS archive is not on this machine")
 
 CODE, INST, COEF, STATE, SRC, DST, SP = 0x100, 0x1000, 0x1100, 0x1400, 0x2000, 0x6000, 0xF000
@@ -174,3 +175,119 @@ def test_committed_vectors_are_what_the_object_computes():
     for i in (0, 7, len(g["names"]) - 3):
         y, st_after, _ = run_object(code, g["coefs_%d" % i], g["state_%d" % i], g["x_%d" % i])
         assert np.array_equal(_bits(y), g["y_bits_%d" % i]) and np.array_equal(_bits(st_after), g["state_after_bits_%d" % i])
+
+
+@needs_reference
+def test_cmplx_mag_squared_object():
+    """`arm_cmplx_mag_squared_f32` (the line powers of AudioSDRpreProcessor.cpp:94) from the same archive: 10
+    vmul.f32 + 5 vadd.f32, nothing fused (4x unrolled + tail), and executed it is re*re + im*im with every product and the sum
+    rounded separately -- the association the front oracle (oracle/asdr_front_oracle.c:79-81) and asdr_pre_kernel use."""
+    code, rel = T.load_function(ARCHIVE, "arm_cmplx_mag_squared_f32.o", "arm_cmplx_mag_squared_f32")
+    c = T.vfp_census(code)
+    assert rel == [] and c["vmul.f32"] == 10 and c["vadd.f32"] == 5 and c["fused"] == 0 and c["other"] == 0 and c["vsub.f32"] == 0, c
+    rng = np.random.default_rng(5)
+    for n in (128, 133, 3, 1):
+        x = np.concatenate([rng.standard_normal(2 * n - 2) * 10.0 ** rng.integers(-20, 20), [1e-30, 3e-31]]).astype(np.float32)
+        cpu = T.Cpu()
+        cpu.load_code(code, CODE)
+        cpu.write_f32(SRC, x)
+        cpu.call(CODE, [SRC, DST, n], SP)                      # (pSrc, pDst, numSamples)
+        got = cpu.read_f32(DST, n)
+        with np.errstate(all="ignore"):
+            re2 = (x[0::2] * x[0::2]).astype(np.float32); im2 = (x[1::2] * x[1::2]).astype(np.float32)
+            want = (re2 + im2).astype(np.float32)
+        assert np.array_equal(_bits(got), _bits(want)), n
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# arm_cfft_f32, 128 points: the FFT of AudioSDRpreProcessor's image detector (AudioSDRpreProcessor.cpp:93; SURVEY.md 8(f) row 2)
+def cfft_image():
+    """The reference's objects linked in one emulator image: arm_cfft_f32 -> arm_cfft_radix8by2_f32 -> arm_radix8_butterfly_f32,
+    arm_bitreversal_32, the instance arm_cfft_sR_f32_len128 and its tables (twiddleCoef_128, armBitRevIndexTable128)."""
+    cpu = T.Cpu(1 << 17)
+    img = T.Image(cpu)
+    img.add(ARCHIVE, "arm_cfft_f32.o", [".text.arm_cfft_f32", ".text.arm_cfft_radix8by2_f32", ".text.arm_cfft_radix8by4_f32"])
+    img.add(ARCHIVE, "arm_cfft_radix8_f32.o", [".text.arm_radix8_butterfly_f32"])
+    img.add(ARCHIVE, "arm_bitreversal2.o", [".text"])
+    img.add(ARCHIVE, "arm_common_tables.o", [".rodata.twiddleCoef_128", ".rodata.armBitRevIndexTable128"])
+    img.add(ARCHIVE, "arm_const_structs.o", [".rodata.arm_cfft_sR_f32_len128"])
+    img.link()
+    return cpu, img
+
+
+def run_cfft128(cpu, img, x):
+    """arm_cfft_f32(&arm_cfft_sR_f32_len128, x, ifftFlag 0, bitReverseFlag 1) on the emulator, as the reference calls it."""
+    buf, sp = 0x10000, 0x1F000
+    cpu.write_f32(buf, x)
+    cpu.call(img.sym["arm_cfft_f32"], [img.sym["arm_cfft_sR_f32_len128"], buf, 0, 1], sp, max_steps=5_000_000)
+    return cpu.read_f32(buf, 256)
+
+
+def cfft_cases():
+    rng = np.random.default_rng(20260411)
+    out = []
+    imp = np.zeros(256, np.float32); imp[2 * 5] = 1.0
+    out.append(("impulse", imp))
+    t = np.arange(128)
+    tone = np.empty(256, np.float32); tone[0::2] = np.cos(2 * np.pi * 20 * t / 128).astype(np.float32); tone[1::2] = np.sin(2 * np.pi * 20 * t / 128).astype(np.float32)
+    out.append(("tone_line20", tone))
+    for k in range(6):                                   # what the detector feeds it: int16 / 32767.0 (.cpp:89-90)
+        out.append(("int16_block%d" % k, (rng.integers(-32768, 32768, 256).astype(np.float64) / 32767.0).astype(np.float32)))
+    for k, scale in enumerate((1e-6, 1e-3, 1.0, 1e3)):
+        out.append(("gauss_%g" % scale, (rng.standard_normal(256) * scale).astype(np.float32)))
+    out.append(("denormal", (rng.standard_normal(256) * 1e-41).astype(np.float32)))
+    out.append(("zeros_signed", np.concatenate([np.zeros(128, np.float32), -np.zeros(128, np.float32)])))
+    return out
+
+
+@needs_reference
+def test_cfft128_objects_hold_no_fused_operations():
+    for member, sec in (("arm_cfft_f32.o", ".text.arm_cfft_radix8by2_f32"), ("arm_cfft_radix8_f32.o", ".text.arm_radix8_butterfly_f32")):
+        c = T.vfp_census(T.Elf32(T.ar_member(ARCHIVE, member)).section(sec))
+        assert c["fused"] == 0 and c["f64"] == 0 and c["vdiv.f32"] == 0, (sec, c)
+    c = T.vfp_census(T.Elf32(T.ar_member(ARCHIVE, "arm_cfft_radix8_f32.o")).section(".text.arm_radix8_butterfly_f32"))
+    assert (c["vmul.f32"], c["vadd.f32"], c["vsub.f32"]) == (36, 59, 59), c      # both butterfly forms: 4 + 32 products, 118 sums
+
+
+@needs_reference
+def test_executed_cfft128_equals_the_oracle_and_the_float64_fft():
+    cpu, img = cfft_image()
+    s = img.sym["arm_cfft_sR_f32_len128"]
+    assert (cpu.rd16(s), cpu.rd16(s + 12)) == (128, 208)                          # fftLen, bitRevLength (arm_const_structs)
+    for name, x in cfft_cases():
+        want = run_cfft128(cpu, img, x)
+        assert np.array_equal(_bits(ao.fft128_interleaved(x)), _bits(want)), name
+    # ... and it IS the discrete Fourier transform (float64 reference, 1e-6 of the largest line)
+    x = cfft_cases()[3][1]
+    y = run_cfft128(cpu, img, x)
+    ref = np.fft.fft(x[0::2].astype(np.float64) + 1j * x[1::2].astype(np.float64))
+    assert np.abs((y[0::2] + 1j * y[1::2]) - ref).max() < 1e-6 * np.abs(ref).max()
+    # a trace census of one transform: 776 products, 2,244 sums, nothing else in the VFP unit
+    cpu.trace.clear()
+    run_cfft128(cpu, img, x)
+    assert (cpu.trace.count("vmul.f32"), cpu.trace.count("vadd.f32"), cpu.trace.count("vsub.f32")) == (776, 1122, 1122)
+
+
+@needs_reference
+def test_twiddle_table_rule_gives_the_archives_table():
+    """asdr_cfft128_tw (tools/extract_front_tables.py: cos / sin rounded to 9 decimals, then to float32) == twiddleCoef_128 of the
+    reference's arm_common_tables.o, all 256 words; and the butterfly's constant C81 is the float32 of 0.70710678118."""
+    import struct
+    body = T.Elf32(T.ar_member(ARCHIVE, "arm_common_tables.o")).section(".rodata.twiddleCoef_128")
+    ref = np.frombuffer(body, dtype=np.float32)
+    k = np.arange(128)
+    mine = np.empty(256, np.float32)
+    mine[0::2] = [np.float32(round(float(np.cos(2 * np.pi * i / 128)), 9)) for i in k]
+    mine[1::2] = [np.float32(round(float(np.sin(2 * np.pi * i / 128)), 9)) for i in k]
+    assert np.array_equal(_bits(mine), _bits(ref))
+    code = T.Elf32(T.ar_member(ARCHIVE, "arm_cfft_radix8_f32.o")).section(".text.arm_radix8_butterfly_f32")
+    assert struct.pack("<f", np.float32(0.70710678118)) in code                   # the literal pool word 0x3f3504f3
+
+
+def test_committed_cfft128_vectors_from_the_reference_binary_equal_the_oracle():
+    """Runs everywhere (also on the GPU box): outputs of the reference's arm_cfft_f32 objects, emulated when the fixture was made."""
+    g = np.load(GOLDEN_CFFT)
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 12
+    for i, name in enumerate(names):
+        assert np.array_equal(_bits(ao.fft128_interleaved(g["x_%d" % i])), g["y_bits_%d" % i]), name

@@ -94,7 +94,7 @@ def test_pre_swap_after_correction(ao):
 
 
 def test_fft128_matches_float64_fft(ao):
-    """This project's float32 FFT (stand-in for CMSIS arm_cfft_f32, see asdr_front_oracle.h) vs numpy's float64 FFT."""
+    """ao_fft128 -- CMSIS arm_cfft_f32 restated (bit-exact against the reference's objects: tests/test_cmsis_object.py) -- vs numpy's float64 FFT."""
     rng = np.random.default_rng(7)
     for _ in range(5):
         x = (rng.standard_normal(128) + 1j * rng.standard_normal(128)).astype(np.complex64)

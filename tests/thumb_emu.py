@@ -106,6 +106,7 @@ class Cpu:
         self.s = np.zeros(32, dtype=np.uint32)
         self.mem = bytearray(mem_bytes)
         self.trace = []
+        self.it_conds = []     # conditions of the instructions still inside the current IT block
         self.hooks = {}        # code offset of a BL -> python callable(cpu) (an external call, e.g. memset)
         self.code_base = 0
         # symbolic shadow of the float dataflow: sx[i] = the expression register s<i> holds, built from the names given to memory
@@ -164,9 +165,9 @@ class Cpu:
         return res
 
     def _cond(self, cond):
-        if cond == 0: return self.z == 1      # EQ
-        if cond == 1: return self.z == 0      # NE
-        raise Unsupported("condition code %d" % cond)
+        n, z, c, v = self.n, self.z, self.c, self.v
+        return [z == 1, z == 0, c == 1, c == 0, n == 1, n == 0, v == 1, v == 0, c == 1 and z == 0, c == 0 or z == 1,
+                n == v, n != v, z == 0 and n == v, z == 1 or n != v, True][cond]
 
     def _branch(self, target):
         self.r[15] = target & ~1 if target < RETURN_ADDRESS else RETURN_ADDRESS
@@ -186,17 +187,52 @@ class Cpu:
     def step(self):
         pc = self.r[15]
         h = self.rd16(pc)
-        if (h >> 11) in (0b11101, 0b11110, 0b11111):
-            self.r[15] = pc + 4
+        wide = (h >> 11) in (0b11101, 0b11110, 0b11111)
+        self.r[15] = pc + (4 if wide else 2)
+        if self.it_conds:                      # inside an IT block: the instruction runs only if its condition holds
+            cond = self.it_conds.pop(0)
+            if not self._cond(cond):
+                self.trace.append("it-skipped")
+                return
+        if wide:
             self._exec32(pc, h, self.rd16(pc + 2))
         else:
-            self.r[15] = pc + 2
             self._exec16(pc, h)
 
     def _exec16(self, pc, h):
         r, t = self.r, self.trace
         if h == 0xBF00:
             t.append("nop")
+        elif (h & 0xFF00) == 0xBF00:                         # IT{x{y{z}}} firstcond, mask
+            first, mask = (h >> 4) & 15, h & 15
+            n = 4 - ((mask & -mask).bit_length() - 1)        # instructions in the block
+            conds = [first]
+            for k in range(1, n):
+                conds.append(first if ((mask >> (4 - k)) & 1) == (first & 1) else first ^ 1)
+            self.it_conds = conds; t.append("it")
+        elif (h & 0xFC00) == 0x1800:                         # ADDS / SUBS Rd, Rn, Rm
+            a, b = r[(h >> 3) & 7], r[(h >> 6) & 7]
+            r[h & 7] = self._flags_sub(a, b) if h & 0x0200 else self._flags_add(a, b); t.append("subs" if h & 0x0200 else "adds")
+        elif (h & 0xFC00) == 0x1C00:                         # ADDS / SUBS Rd, Rn, #imm3
+            a, b = r[(h >> 3) & 7], (h >> 6) & 7
+            r[h & 7] = self._flags_sub(a, b) if h & 0x0200 else self._flags_add(a, b); t.append("subs" if h & 0x0200 else "adds")
+        elif (h & 0xF800) == 0x2800:                         # CMP Rn, #imm8
+            self._flags_sub(r[(h >> 8) & 7], h & 0xFF); t.append("cmp")
+        elif (h & 0xFFC0) == 0x4280:                         # CMP Rn, Rm (low registers)
+            self._flags_sub(r[h & 7], r[(h >> 3) & 7]); t.append("cmp")
+        elif (h & 0xFF00) == 0x4500:                         # CMP Rn, Rm (high registers)
+            self._flags_sub(r[(h & 7) | ((h >> 4) & 8)], r[(h >> 3) & 15]); t.append("cmp")
+        elif (h & 0xF800) == 0x8800:                         # LDRH Rt, [Rn, #imm5*2]
+            r[h & 7] = self.rd16(r[(h >> 3) & 7] + ((h >> 6) & 31) * 2); t.append("ldrh")
+        elif (h & 0xF800) == 0x8000:                         # STRH Rt, [Rn, #imm5*2]
+            struct.pack_into("<H", self.mem, r[(h >> 3) & 7] + ((h >> 6) & 31) * 2, r[h & 7] & 0xFFFF); t.append("strh")
+        elif (h & 0xF800) == 0x9800:                         # LDR Rt, [sp, #imm8*4]
+            r[(h >> 8) & 7] = self.rd32(r[13] + (h & 0xFF) * 4); t.append("ldr")
+        elif (h & 0xF800) == 0x9000:                         # STR Rt, [sp, #imm8*4]
+            self.wr32(r[13] + (h & 0xFF) * 4, r[(h >> 8) & 7]); t.append("str")
+        elif (h & 0xFF00) == 0xB000:                         # ADD / SUB sp, #imm7*4
+            d = (h & 0x7F) * 4
+            r[13] = (r[13] - d if h & 0x80 else r[13] + d) & 0xFFFFFFFF; t.append("add-sp")
         elif (h & 0xF800) == 0x6800:                         # LDR Rt, [Rn, #imm5*4]
             r[h & 7] = self.rd32(r[(h >> 3) & 7] + ((h >> 6) & 31) * 4); t.append("ldr")
         elif (h & 0xF800) == 0x6000:                         # STR Rt, [Rn, #imm5*4]
@@ -216,6 +252,13 @@ class Cpu:
             rd = (h >> 8) & 7; r[rd] = self._flags_sub(r[rd], h & 0xFF); t.append("subs")
         elif (h & 0xF800) == 0x2000:                         # MOVS Rd, #imm8
             rd = (h >> 8) & 7; r[rd] = h & 0xFF; self.n, self.z = 0, int(r[rd] == 0); t.append("movs")
+        elif (h & 0xFF87) == 0x4700:                         # BX Rm
+            self._branch(r[(h >> 3) & 15]); t.append("bx")
+        elif (h & 0xF800) == 0x0800:                         # LSRS Rd, Rm, #imm5 (imm5 = 0 means 32)
+            sh = ((h >> 6) & 31) or 32; val = r[(h >> 3) & 7]
+            self.c = (val >> (sh - 1)) & 1
+            r[h & 7] = (val >> sh) if sh < 32 else 0
+            self.n, self.z = 0, int(r[h & 7] == 0); t.append("lsrs")
         elif (h & 0xF800) == 0x0000 and h != 0:              # LSLS Rd, Rm, #imm5
             sh = (h >> 6) & 31; val = r[(h >> 3) & 7]
             if sh: self.c = (val >> (32 - sh)) & 1
@@ -274,6 +317,7 @@ class Cpu:
             elif opc1 == 0x3 and op == 0: self._setf(sd, a + b); self._sym_op(sd, sn, sm, "+"); t.append("vadd.f32")
             elif opc1 == 0x3 and op == 1: self._setf(sd, a - b); self._sym_op(sd, sn, sm, "-"); t.append("vsub.f32")
             elif opc1 == 0xB and (h1 & 15) == 0 and (h2 >> 6) & 3 == 1: self.s[sd] = self.s[sm]; self.sx[sd] = self.sx[sm]; t.append("vmov.f32")
+            elif opc1 == 0xB and (h1 & 15) == 1 and (h2 >> 6) & 3 == 1: self.s[sd] = self.s[sm] ^ 0x80000000; self.sx[sd] = "(-%s)" % self.sx[sm]; t.append("vneg.f32")
             else:
                 fused = {0x0: "vmla/vmls", 0x1: "vnmla/vnmls", 0x9: "vfnma/vfnms", 0xA: "vfma/vfms", 0x8: "vdiv"}.get(opc1, "vfp-op")
                 t.append(fused)
@@ -281,7 +325,8 @@ class Cpu:
         elif (h1 & 0xFF30) == 0xED10 and (h2 & 0x0F00) == 0x0A00:   # VLDR Sd, [Rn, #+-imm8*4]
             sd = ((h2 >> 12) & 15) << 1 | (h1 >> 6) & 1
             off = (h2 & 0xFF) * 4
-            addr = r[h1 & 15] + (off if h1 >> 7 & 1 else -off)
+            base = ((pc + 4) & ~3) if (h1 & 15) == 15 else r[h1 & 15]     # (literal pool: Align(PC, 4))
+            addr = base + (off if h1 >> 7 & 1 else -off)
             self.s[sd] = self.rd32(addr); self._sym_load(sd, addr); t.append("vldr")
         elif (h1 & 0xFF30) == 0xED00 and (h2 & 0x0F00) == 0x0A00:   # VSTR Sd, [Rn, #+-imm8*4]
             sd = ((h2 >> 12) & 15) << 1 | (h1 >> 6) & 1
@@ -351,10 +396,52 @@ class Cpu:
             if S: off -= 1 << 21
             if self._cond(cond): self._branch(pc + 4 + off)
             t.append("bcond.w")
-        elif (h1 & 0xF800) == 0xF000 and (h2 & 0xD000) == 0xD000:    # BL (only as a hooked external call)
+        elif (h1 & 0xF800) == 0xF000 and (h2 & 0xD000) in (0xD000, 0x9000):    # BL / B.W: a hooked external call, or the linked target
             hook = self.hooks.get(pc - self.code_base)
-            if hook is None: raise Unsupported("BL without a hook at +0x%x" % (pc - self.code_base))
-            hook(self); t.append("bl")
+            if hook is not None:
+                hook(self); t.append("bl")
+            else:
+                S, J1, J2 = (h1 >> 10) & 1, (h2 >> 13) & 1, (h2 >> 11) & 1
+                I1, I2 = 1 - (J1 ^ S), 1 - (J2 ^ S)
+                off = (S << 24) | (I1 << 23) | (I2 << 22) | ((h1 & 0x3FF) << 12) | ((h2 & 0x7FF) << 1)
+                if S: off -= 1 << 25
+                if (h2 & 0xD000) == 0xD000: r[14] = (pc + 4) | 1
+                self._branch(pc + 4 + off); t.append("bl" if (h2 & 0xD000) == 0xD000 else "b.w")
+        elif (h1 & 0xFFF0) in (0xF8B0, 0xF8D0, 0xF8C0, 0xF8A0):      # LDRH.W / LDR.W / STR.W / STRH.W Rt, [Rn, #imm12]
+            addr, rt = r[h1 & 15] + (h2 & 0xFFF), (h2 >> 12) & 15
+            if (h1 & 0xFFF0) == 0xF8B0: r[rt] = self.rd16(addr); t.append("ldrh.w")
+            elif (h1 & 0xFFF0) == 0xF8D0:
+                val = self.rd32(addr)
+                if rt == 15: self._branch(val)
+                else: r[rt] = val
+                t.append("ldr.w")
+            elif (h1 & 0xFFF0) == 0xF8C0: self.wr32(addr, r[rt]); t.append("str.w")
+            else: struct.pack_into("<H", self.mem, addr, r[rt] & 0xFFFF); t.append("strh.w")
+        elif (h1 & 0xFFF0) in (0xF830, 0xF850, 0xF840, 0xF820) and (h2 & 0x0800):   # ... [Rn, #-imm8] / pre- / post-indexed (T4)
+            P, U, W = (h2 >> 10) & 1, (h2 >> 9) & 1, (h2 >> 8) & 1
+            rn, rt, imm = h1 & 15, (h2 >> 12) & 15, h2 & 0xFF
+            off_addr = r[rn] + (imm if U else -imm)
+            addr = off_addr if P else r[rn]
+            if (h1 & 0xFFF0) == 0xF830: r[rt] = self.rd16(addr); t.append("ldrh.w")
+            elif (h1 & 0xFFF0) == 0xF850: r[rt] = self.rd32(addr); t.append("ldr.w")
+            elif (h1 & 0xFFF0) == 0xF840: self.wr32(addr, r[rt]); t.append("str.w")
+            else: struct.pack_into("<H", self.mem, addr, r[rt] & 0xFFFF); t.append("strh.w")
+            if W: r[rn] = off_addr & 0xFFFFFFFF
+        elif (h1 & 0xFBE0) == 0xF1A0 and (h2 & 0x8000) == 0:         # SUB{S}.W Rd, Rn, #const
+            imm = self._thumb_imm((h1 >> 10) & 1, (h2 >> 12) & 7, h2 & 0xFF)
+            rd = (h2 >> 8) & 15
+            if h1 & 0x10: r[rd] = self._flags_sub(r[h1 & 15], imm)
+            else: r[rd] = (r[h1 & 15] - imm) & 0xFFFFFFFF
+            t.append("sub.w")
+        elif (h1 & 0xFBEF) == 0xF04F and (h2 & 0x8000) == 0:         # MOV{S}.W Rd, #const
+            imm = self._thumb_imm((h1 >> 10) & 1, (h2 >> 12) & 7, h2 & 0xFF)
+            r[(h2 >> 8) & 15] = imm
+            if h1 & 0x10: self.n, self.z = imm >> 31, int(imm == 0)
+            t.append("mov.w")
+        elif h1 == 0xFA1F and (h2 & 0xF0C0) == 0xF080:               # UXTH.W Rd, Rm{, ROR #}
+            rot = ((h2 >> 4) & 3) * 8
+            val = r[h2 & 15]
+            r[(h2 >> 8) & 15] = ((val >> rot) | (val << (32 - rot))) & 0xFFFF; t.append("uxth")
         else:
             raise Unsupported("32-bit %04x %04x at +0x%x" % (h1, h2, pc - self.code_base))
 
@@ -393,3 +480,52 @@ def load_function(archive, member, function):
         raise ValueError("not an ARM object")
     sec = ".text." + function
     return elf.section(sec), elf.relocations(sec)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a minimal static linker: sections of several archive members in one memory image, R_ARM_THM_CALL / _JUMP24 / _ABS32 resolved
+class Image:
+    """Places `.text.*` / `.rodata.*` sections of archive members in a Cpu's memory and resolves the relocations between them, so
+    that a function can call the functions and read the tables it was compiled against (arm_cfft_f32 -> arm_cfft_radix8by2_f32 ->
+    arm_radix8_butterfly_f32, arm_bitreversal_32; arm_cfft_sR_f32_len128 -> twiddleCoef_128, armBitRevIndexTable128)."""
+
+    def __init__(self, cpu, base=0x1000):
+        self.cpu, self.at, self.sym, self._pending = cpu, base, {}, []
+        cpu.code_base = 0
+
+    def add(self, archive, member, sections):
+        elf = Elf32(ar_member(archive, member))
+        placed = {}
+        for sec in sections:
+            body = elf.section(sec)
+            self.at = (self.at + 15) & ~15
+            self.cpu.mem[self.at:self.at + len(body)] = body
+            placed[elf.names.index(sec)] = self.at
+            self._pending.append((elf, sec, self.at))
+            self.at += len(body)
+        for name, value, size, info, shndx in elf.symbols():
+            if name and shndx in placed and ((info & 15) in (1, 2) or (info >> 4) == 1):   # OBJECT / FUNC, or any global (assembly labels have no type)
+                self.sym[name] = placed[shndx] + (value & ~1)
+        return placed
+
+    def link(self):
+        cpu = self.cpu
+        for elf, sec, at in self._pending:
+            for off, rtype, symname in elf.relocations(sec):
+                if symname not in self.sym:
+                    raise KeyError("undefined symbol %s (needed by %s)" % (symname, sec))
+                target, where = self.sym[symname], at + off
+                if rtype in (10, 30):                                     # R_ARM_THM_CALL (BL), R_ARM_THM_JUMP24 (B.W): addend -4 in the instruction
+                    rel = target - (where + 4)
+                    S = 1 if rel < 0 else 0
+                    rel &= (1 << 25) - 1
+                    I1, I2 = (rel >> 23) & 1, (rel >> 22) & 1
+                    J1, J2 = (1 - I1) ^ S, (1 - I2) ^ S
+                    h1 = 0xF000 | (S << 10) | ((rel >> 12) & 0x3FF)
+                    h2 = (0xD000 if rtype == 10 else 0x9000) | (J1 << 13) | (J2 << 11) | ((rel >> 1) & 0x7FF)
+                    struct.pack_into("<HH", cpu.mem, where, h1, h2)
+                elif rtype == 2:                                          # R_ARM_ABS32: word += symbol address
+                    cpu.wr32(where, cpu.rd32(where) + target)
+                else:
+                    raise Unsupported("relocation type %d in %s" % (rtype, sec))
+        self._pending = []
