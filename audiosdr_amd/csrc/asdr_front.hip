@@ -204,15 +204,37 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
       }
       WAVE_SYNC();
       if (autodet) {
-        // .cpp:96-105: sequential float sum and first-maximum scan over lines 5..122, every lane of the row redundantly
-        // (same LDS addresses -> broadcast reads; no result hand-off needed)
-        float avg = 0.0f, mx = 0.0f;
+        // .cpp:96-105.  The float SUM over lines 5..122 is sequential in the reference and stays so (every lane of the row redundantly:
+        // same LDS addresses -> broadcast reads, four lines per read; no hand-off).  The first-maximum scan
+        // (`if (p > max) { line = i; max = p; }`, i ascending, from max = 0.0, line = 0) is order-free once ties go to the LOWER
+        // line: each lane scans its own eight lines, then four exchange steps over the row's 16 lanes keep, of two candidates, the
+        // higher-indexed one only if it is STRICTLY greater (a NaN power never wins, as in the reference: `NaN > max` is false).
+        float avg = 0.0f;
+        {
+          const float4 *P4 = reinterpret_cast<const float4 *>(P[r]);
+          float4 v = P4[1];                                   // lines 4..7
+          avg += v.y; avg += v.z; avg += v.w;                 // 5, 6, 7
+#pragma unroll 4
+          for (int q = 2; q < 30; ++q) { v = P4[q]; avg += v.x; avg += v.y; avg += v.z; avg += v.w; }   // 8..119
+          v = P4[30];                                         // lines 120..123
+          avg += v.x; avg += v.y; avg += v.z;                 // 120, 121, 122
+        }
+        float mx = 0.0f;
         int line = 0;
-#pragma unroll 2
-        for (int i = 5; i < 123; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = 8 * l + j;
           const float p = P[r][i];
-          avg += p;
-          if (p > mx) { line = i; mx = p; }
+          if (i >= 5 && i < 123 && p > mx) { line = i; mx = p; }
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          const float om = __shfl_xor(mx, d, 16);
+          const int ol = __shfl_xor(line, d, 16);
+          const bool other_is_higher = (l & d) == 0;          // the partner holds higher line numbers
+          // keep the lower-indexed candidate unless the higher-indexed one is strictly greater
+          const bool take = other_is_higher ? (om > mx) : !(mx > om);
+          mx = take ? om : mx; line = take ? ol : line;
         }
         avg /= 118.0f;
         const float ratio = mx / P[r][128 - line];                       // .cpp:107

@@ -83,6 +83,43 @@ def test_pre_autodetect_block_by_block(gpu, ao):
     b.close()
 
 
+def test_pre_detector_ties_and_degenerate_spectra(gpu, ao):
+    """The first-maximum scan runs in parallel on the GPU (lanes scan eight lines each, then exchange): the cases where ORDER decides
+    must come out as in the reference's sequential scan (AudioSDRpreProcessor.cpp:98-104) -- silence (no line beats the initial 0.0:
+    line 0, and the ratio divides by buffer[128]), an impulse at sample 0 (every line the same power, exactly: the first of lines
+    5..122 wins), an impulse elsewhere (flat magnitudes with rounding scatter), real-only tones (lines k and 128 - k mirror each
+    other), a full-scale DC block (the strongest lines are outside 5..122), maximum in the first / last scanned line."""
+    n_blk = 3
+    t = np.arange(128)
+    blocks = []
+    z = np.zeros(128, np.int16)
+    imp0 = z.copy(); imp0[0] = 20000
+    imp9 = z.copy(); imp9[9] = -12345
+    blocks += [(z, z), (imp0, z), (z, imp0), (imp0, imp0), (imp9, z), (imp9, imp9)]
+    for k in (5, 6, 64, 121, 122, 123, 4, 20):
+        c = np.round(9000 * np.cos(2 * np.pi * k * t / 128)).astype(np.int16)
+        sn = np.round(9000 * np.sin(2 * np.pi * k * t / 128)).astype(np.int16)
+        blocks += [(c, z), (c, sn), (c, c)]
+    blocks += [(np.full(128, 32767, np.int16), np.full(128, -32768, np.int16))]
+    n_ch = len(blocks)
+    I = np.stack([np.tile(b[0], (n_blk, 1)) for b in blocks]); Q = np.stack([np.tile(b[1], (n_blk, 1)) for b in blocks])
+    b = gpu.AudioSDRpreProcessorBatch(n_ch)
+    orcs = [ao.OraclePreProcessor() for _ in range(n_ch)]
+    b.startAutoI2SerrorDetection()
+    for o in orcs:
+        o.startAutoI2SerrorDetection()
+    lines = set()
+    for k in range(n_blk):
+        gi, gq = b.update(I[:, k:k + 1], Q[:, k:k + 1])
+        for c, o in enumerate(orcs):
+            wi, wq = o.update(I[c, k], Q[c, k])
+            assert np.array_equal(gi[c, 0], wi) and np.array_equal(gq[c, 0], wq), (k, c)
+            lines.add(o.state()["max_line"])
+        _cmp_state(b, orcs)
+    assert {0, 5, 122} <= lines, sorted(lines)        # silence -> 0; flat spectrum -> the first scanned line; the last scanned line
+    b.close()
+
+
 def test_pre_autodetect_many_blocks_per_call_and_self_switch_off(gpu, ao):
     """1,100 blocks in calls of 275: the correction changes INSIDE a call and applies from the next block; clean
     channels count 1,001 successes and switch their detector off mid-call; a setter between calls is honoured."""
