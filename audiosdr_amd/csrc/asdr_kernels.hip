@@ -259,9 +259,13 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // (ds_read_b128, prefetched a step ahead), stage k>0 takes the previous lane's four outputs of the previous step
 // through DPP row_shr:1, stage 3 writes back in place (ds_write_b128).  The y-independent part
 // p = (b0*x + b1*x1) + b2*x2 of all four samples is off the critical path; the recurrence is 3 dependent ops/sample.
+#ifndef ASDR_PIPE_PK_MASK
+#define ASDR_PIPE_PK_MASK 0   /* which kernel kinds run the pipelines' y-independent products packed (see PIPE_PK in the body) */
+#endif
 #ifndef ASDR_PIPE_CHUNK
 #define ASDR_PIPE_CHUNK 8   /* samples per lane per pipeline step: 4 (35 steps) or 8 (19 steps, less per-step overhead) */
 #endif
+template <bool PK = false>
 __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const float *cf, float *sv) {
   constexpr int C = ASDR_PIPE_CHUNK, NSTEP = ASDR_N / C + 3;
   const float b0 = cf[0], b1 = cf[1], b2 = cf[2], a1 = cf[3], a2 = cf[4];
@@ -304,12 +308,32 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
 #pragma unroll
       for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[nc * (C / 4) + q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
     }
+#if ASDR_PIPE_CHUNK == 8
+    if constexpr (PK) {
+    // Packed form (same separately rounded operations): samples j and j + 4 share a register pair, so that x[j-1] and x[j-2] of
+    // both are the pairs one and two places back -- every product of the y-independent part is an aligned v_pk_mul_f32.
+    {
+      const v2f B0 = (v2f){b0, b0}, B1 = (v2f){b1, b1}, B2 = (v2f){b2, b2};
+      v2f P[6];   // P[k] = (x[k-2], x[k+2]): k = 0, 1 hold the carried x2, x1 in their low halves
+      P[0] = (v2f){x2, x[2]}; P[1] = (v2f){x1, x[3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P[2 + k] = (v2f){x[k], x[k + 4]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v2f t = B0 * P[2 + k]; t += B1 * P[1 + k]; t += B2 * P[k];
+        p[k] = t.x; p[k + 4] = t.y;
+      }
+    }
+    } else
+#endif
+    {
     // y-independent partial sums p = (b0*x + b1*x[-1]) + b2*x[-2], in the reference's association
 #pragma unroll
     for (int j = 0; j < C; ++j) {
       const float xm1 = (j >= 1) ? x[j - 1] : x1, xm2 = (j >= 2) ? x[j - 2] : ((j == 1) ? x1 : x2);
       float t = b0 * x[j]; t += b1 * xm1; t += b2 * xm2;
       p[j] = t;
+    }
     }
     // recurrence: y = (p + a1*y[-1]) + a2*y[-2]
 #pragma unroll
@@ -963,6 +987,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // prefetches; the merged average + phase loop): experiments re-enable them for the compact rows with -DASDR_ALS_FULL_OPT=1.
   constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && (STRIDE == ASDR_STRIDE), ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && (STRIDE == ASDR_STRIDE);
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
+  // biquad pipelines with packed products (biquad_pipe<true>), by instantiation: bit 0 = the ALS kinds, 1 = the plain kinds, 2 = the SAM roles, 3 = the block pipeline
+  constexpr bool PIPE_PK = ((ASDR_PIPE_PK_MASK & 1) && HAS_ALS) || ((ASDR_PIPE_PK_MASK & 2) && !HAS_ALS && !HAS_SAM && ROLE == 0) ||
+                           ((ASDR_PIPE_PK_MASK & 4) && (HAS_SAM || ROLE > 3)) || ((ASDR_PIPE_PK_MASK & 8) && STREAM);
   if (ROLE == 0 && a.run_if != nullptr && *a.run_if == 0u) return;   // the pipeline's fallback launch: nothing to do unless the pipeline gave up
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
   // this wave's index in the launched schedule sub-range (the streaming pipeline launches its three roles one after the other)
@@ -1540,7 +1567,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       float sv[4];
       if (HAS_ALS && !ALS_FULL_OPT && !if_pre) load_if_rows();
       sv[0] = if_s4.x; sv[1] = if_s4.y; sv[2] = if_s4.z; sv[3] = if_s4.w;
-      biquad_pipe(L + (iq ? W1 : W0), true, st, if_cf, sv);
+      biquad_pipe<PIPE_PK>(L + (iq ? W1 : W0), true, st, if_cf, sv);
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
     }
     WAVE_SYNC();
@@ -1847,7 +1874,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float sv[4];
         const float4 s4 = *reinterpret_cast<const float4 *>(&S->img_state[iq][4 * st]);
         sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
-        biquad_pipe(L + (iq ? W1 : W0), do_env, st, &c_bq_pool[ASDR_TBL_AM_IMAGE][5 * st], sv);
+        biquad_pipe<PIPE_PK>(L + (iq ? W1 : W0), do_env, st, &c_bq_pool[ASDR_TBL_AM_IMAGE][5 * st], sv);
         if (do_env) *reinterpret_cast<float4 *>(&S->img_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       }
       WAVE_SYNC();
@@ -1953,7 +1980,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const bool on = af_en && (s8 < 4);
       float sv[4];
       sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
-      biquad_pipe(L + W0, on, st, af_cf, sv);
+      biquad_pipe<PIPE_PK>(L + W0, on, st, af_cf, sv);
       if (on) *reinterpret_cast<float4 *>(&S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       WAVE_SYNC();
     }
@@ -2281,7 +2308,10 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_sam_pre_kernel_uniform(
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_PRE_STRIDE];
   asdr_update_body<ASDR_PRE_STRIDE, false, false, true, 1, 4>(a, lds);
 }
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_kernel_uniform(UpdateArgs a) {
+#ifndef ASDR_POST_BOUNDS
+#define ASDR_POST_BOUNDS ASDR_WAVES_PER_EU
+#endif
+extern "C" __global__ __launch_bounds__(64, ASDR_POST_BOUNDS) void asdr_sam_post_kernel_uniform(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 5>(a, lds);
 }
