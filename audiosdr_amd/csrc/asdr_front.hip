@@ -13,6 +13,10 @@
 #include "asdr_fir.h"
 
 #define WAVE_SYNC() __syncthreads() /* workgroup == one wave: a wave barrier + LDS/VMEM waits */
+#ifndef ASDR_PRE_ABLATE
+#define ASDR_PRE_ABLATE 0   /* profiling builds: detector phases compiled out (1 radix-8-by-2, 2 stage 1, 4 stage 2, 8 powers, 16 sum, 32 maximum scan, 64 unit scale + store) */
+#endif
+#define PRE_ON(bit) (!(ASDR_PRE_ABLATE & (bit)))
 
 __constant__ float c_iq_taps[64];
 __constant__ float c_cftw[128][2];   // CMSIS twiddleCoef_128 (cos, +sin): the detector's FFT is the reference's arm_cfft_f32
@@ -41,15 +45,15 @@ __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (
 // AudioSDRpreProcessor: 16 lanes per channel (8 samples each; a DPP row is exactly one channel), 4 channels per wave.
 // Blocks of one call are processed in order because the detector may change the correction between blocks.
 // =====================================================================================================
-// One radix-8 butterfly of CMSIS-DSP arm_radix8_butterfly_f32 on points i1, i1 + n2, .., i1 + 7 n2 of X (oracle/asdr_front_oracle.c
+// One radix-8 butterfly of CMSIS-DSP arm_radix8_butterfly_f32 on the points xin[0..7] = X[i1], X[i1 + n2], .., X[i1 + 7 n2], outputs in
+// o[0..7] for the same places (registers: the caller loads and stores) (oracle/asdr_front_oracle.c
 // cf_radix8, which is held bit for bit against the reference's Cortex-M4 object: tests/test_cmsis_object.py): TW = false is the
 // twiddle-free form (the first column of a stage / the last stage), TW = true multiplies outputs 2..8 by (co[k], si[k]) = tw[(k - 1) tws].
 // Every product and sum separately rounded, in the object's association.
 #define CF_C81 0.70710678118f
 template <bool TW>
-__device__ __forceinline__ void cf_radix8(float2 *X, int i1, int n2, const float2 *tw, int tws) {
-  const int i2 = i1 + n2, i3 = i2 + n2, i4 = i3 + n2, i5 = i4 + n2, i6 = i5 + n2, i7 = i6 + n2, i8 = i7 + n2;
-  const float2 x1 = X[i1], x2 = X[i2], x3 = X[i3], x4 = X[i4], x5 = X[i5], x6 = X[i6], x7 = X[i7], x8 = X[i8];
+__device__ __forceinline__ void cf_radix8(const float2 *xin, float2 *o, const float2 *tw, int tws) {
+  const float2 x1 = xin[0], x2 = xin[1], x3 = xin[2], x4 = xin[3], x5 = xin[4], x6 = xin[5], x7 = xin[6], x8 = xin[7];
   float r1, r2, r3, r4, r5, r6, r7, r8, t1, t2, s1, s2, s3, s4, s5, s6, s7, s8;
   r1 = x1.x + x5.x; r5 = x1.x - x5.x;
   r2 = x2.x + x6.x; r6 = x2.x - x6.x;
@@ -71,7 +75,7 @@ __device__ __forceinline__ void cf_radix8(float2 *X, int i1, int n2, const float
     t2 = s5 - r2; s5 = s5 + r2; s8 = s7 - s6; s7 = s7 + s6;
     o2.x = r5 + s7; o8.x = r5 - s7; o6.x = t1 + s8; o4.x = t1 - s8;
     o2.y = s5 - r7; o8.y = s5 + r7; o6.y = t2 - r8; o4.y = t2 + r8;
-    X[i1] = o1; X[i2] = o2; X[i3] = o3; X[i4] = o4; X[i5] = o5; X[i6] = o6; X[i7] = o7; X[i8] = o8;
+    o[0] = o1; o[1] = o2; o[2] = o3; o[3] = o4; o[4] = o5; o[5] = o6; o[6] = o7; o[7] = o8;
   } else {
     float2 o1, o2, o3, o4, o5, o6, o7, o8;
     float p1, p2, p3, p4;
@@ -97,14 +101,18 @@ __device__ __forceinline__ void cf_radix8(float2 *X, int i1, int n2, const float
     p1 = w8.x * r5; p2 = w8.y * s5; p3 = w8.x * s5; p4 = w8.y * r5; o8.x = p1 + p2; o8.y = p3 - p4;
     p1 = w6.x * r6; p2 = w6.y * s6; p3 = w6.x * s6; p4 = w6.y * r6; o6.x = p1 + p2; o6.y = p3 - p4;
     p1 = w4.x * t1; p2 = w4.y * t2; p3 = w4.x * t2; p4 = w4.y * t1; o4.x = p1 + p2; o4.y = p3 - p4;
-    X[i1] = o1; X[i2] = o2; X[i3] = o3; X[i4] = o4; X[i5] = o5; X[i6] = o6; X[i7] = o7; X[i8] = o8;
+    o[0] = o1; o[1] = o2; o[2] = o3; o[3] = o4; o[4] = o5; o[5] = o6; o[6] = o7; o[7] = o8;
   }
 }
 
 __device__ __forceinline__ int dpp_row_shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); }
 
 __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
-  __shared__ float2 X[4][128];      // FFT work area, one row per channel of the wave
+  // FFT work area, one row per channel of the wave; point `pos` lives at XI(pos) = pos + pos / 8 (one pad per eight points): a lane's eight
+  // consecutive points (natural-order store, last radix-8 stage) are then 9 slots from its neighbour's and the 16 lanes of a channel hit
+  // 16 different bank pairs; unpadded, that stride is 16 floats -> 8-way conflicts (the columns of the first radix-8 stage: 2-way -> none)
+  __shared__ float2 X[4][144];
+#define XI(pos) ((pos) + ((pos) >> 3))
   __shared__ float P[4][132];       // line powers 0..127 (+ the reference's buffer[128] at [128])
   __shared__ float2 TW[128];        // CMSIS twiddleCoef_128: (cos, +sin)(2 pi k / 128)
   const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
@@ -155,52 +163,67 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
 
     // ---- skew detector, .cpp:82-122: image ratio of the strongest line of a 128-point FFT ---------------
     if (__any(autodet)) {
-      if (autodet) {
+      if (PRE_ON(64) && autodet) {
         // the block as complex float32 in natural order (.cpp:88-91)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) X[r][8 * l + j] = make_float2(unit_scale(xi[j]), unit_scale(xq[j]));
+        for (int j = 0; j < 8; ++j) X[r][9 * l + j] = make_float2(unit_scale(xi[j]), unit_scale(xq[j]));   // XI(8 l + j)
       }
       WAVE_SYNC();
       // arm_cfft_f32(&arm_cfft_sR_f32_len128, buffer, 0, 1) (.cpp:93), operation for operation (oracle ao_fft128 == the reference's
       // Cortex-M4 objects, bit for bit).  (1) arm_cfft_radix8by2_f32: the quarters q, q + 32, q + 64, q + 96 -- 32 values of q, two per lane.
-      if (autodet) {
+      if (PRE_ON(1) && autodet) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int q = l + 16 * h;
-          const float2 t1 = X[r][q], t3 = X[r][q + 32], t2o = X[r][q + 64], t4o = X[r][q + 96], w = TW[q];
+          const int q1 = XI(q), q3 = XI(q + 32), q2 = XI(q + 64), q4 = XI(q + 96);
+          const float2 t1 = X[r][q1], t3 = X[r][q3], t2o = X[r][q2], t4o = X[r][q4], w = TW[q];
           const float2 sum1 = make_float2(t1.x + t2o.x, t1.y + t2o.y), t2 = make_float2(t1.x - t2o.x, t1.y - t2o.y);
           const float2 sum3 = make_float2(t3.x + t4o.x, t3.y + t4o.y), t4 = make_float2(t4o.x - t3.x, t4o.y - t3.y);
           float m0 = t2.x * w.x, m1 = t2.y * w.y, m2 = t2.y * w.x, m3 = t2.x * w.y;
           const float2 o2 = make_float2(m0 + m1, m2 - m3);
           m0 = t4.x * w.y; m1 = t4.y * w.x; m2 = t4.y * w.y; m3 = t4.x * w.x;
           const float2 o4 = make_float2(m0 - m1, m2 + m3);
-          X[r][q] = sum1; X[r][q + 32] = sum3; X[r][q + 64] = o2; X[r][q + 96] = o4;
+          X[r][q1] = sum1; X[r][q3] = sum3; X[r][q2] = o2; X[r][q4] = o4;
         }
       }
       WAVE_SYNC();
       // (2) arm_radix8_butterfly_f32(half, 64, twiddleCoef_128, 2) on both halves, stage 1 (n2 = 8): 16 butterflies, one per lane --
       // column j = l & 7 of half l >> 3; column 0 is the twiddle-free form, column j uses tw[(k - 1) 2 j]
-      if (autodet) {
-        float2 *Xh = X[r] + 64 * (l >> 3);
+      if (PRE_ON(2) && autodet) {
+        float2 *Xh = X[r] + 72 * (l >> 3);          // XI(64 half + j + 8 k) = 72 half + j + 9 k
         const int j = l & 7;
-        if (j == 0) cf_radix8<false>(Xh, 0, 8, TW, 0);
-        else cf_radix8<true>(Xh, j, 8, TW, 2 * j);
+        float2 x[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = Xh[j + 9 * k];
+        if (j == 0) cf_radix8<false>(x, o, TW, 0);
+        else cf_radix8<true>(x, o, TW, 2 * j);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Xh[j + 9 * k] = o[k];
       }
       WAVE_SYNC();
-      // (3) stage 2 (n2 = 1): eight twiddle-free butterflies per half on consecutive points, one per lane
-      if (autodet) cf_radix8<false>(X[r] + 64 * (l >> 3), 8 * (l & 7), 1, TW, 0);
-      WAVE_SYNC();
-      if (autodet) {              // arm_cmplx_mag_squared_f32, .cpp:94
-        // (4) arm_bitreversal_32 is a permutation: natural-order line k = 16 c + 2 b + a sits at position 64 a + 8 b + c; the powers
-        // (arm_cmplx_mag_squared_f32: re re + im im, also held against its object) are formed straight from there
+      // (3) stage 2 (n2 = 1): eight twiddle-free butterflies per half on consecutive points, one per lane: lane l owns positions
+      // 8 l .. 8 l + 7.  (4) arm_bitreversal_32 is a permutation -- natural-order line k = 16 c + 2 b + a sits at position 64 a + 8 b + c --
+      // and the powers (arm_cmplx_mag_squared_f32, .cpp:94: re re + im im, also held against its object) are formed straight from the
+      // butterfly's outputs in registers: position 8 l + j is line 16 j + 2 (l & 7) + (l >> 3), so the 16 lanes of a channel write 16
+      // consecutive words of P for every j.
+      if (autodet) {
+        float2 x[8], o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = 8 * l + j, pos = 64 * (k & 1) + 8 * ((k >> 1) & 7) + (k >> 4);
-          const float2 x = X[r][pos];
-          const float p = x.x * x.x, q = x.y * x.y;
-          P[r][k] = p + q;
+        for (int k = 0; k < 8; ++k) x[k] = X[r][9 * l + k];
+        if (PRE_ON(4)) cf_radix8<false>(x, o, TW, 0);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = x[k];
         }
-        if (l == 0) P[r][128] = X[r][4].x;   // line 64's real part (position 4): what the reference's buffer[128] holds after the in-place magnitude pass
+        if (PRE_ON(8)) {
+          const int k0 = 2 * (l & 7) + (l >> 3);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float p = o[j].x * o[j].x, q = o[j].y * o[j].y;
+            P[r][16 * j + k0] = p + q;
+          }
+          if (l == 0) P[r][128] = o[4].x;   // line 64's real part (position 4): what the reference's buffer[128] holds after the in-place magnitude pass
+        }
       }
       WAVE_SYNC();
       if (autodet) {
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
         // line: each lane scans its own eight lines, then four exchange steps over the row's 16 lanes keep, of two candidates, the
         // higher-indexed one only if it is STRICTLY greater (a NaN power never wins, as in the reference: `NaN > max` is false).
         float avg = 0.0f;
-        {
+        if (PRE_ON(16)) {
           const float4 *P4 = reinterpret_cast<const float4 *>(P[r]);
           float4 v = P4[1];                                   // lines 4..7
           avg += v.y; avg += v.z; avg += v.w;                 // 5, 6, 7
@@ -221,6 +244,7 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
         }
         float mx = 0.0f;
         int line = 0;
+        if (PRE_ON(32)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int i = 8 * l + j;
@@ -235,6 +259,7 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
           // keep the lower-indexed candidate unless the higher-indexed one is strictly greater
           const bool take = other_is_higher ? (om > mx) : !(mx > om);
           mx = take ? om : mx; line = take ? ol : line;
+        }
         }
         avg /= 118.0f;
         const float ratio = mx / P[r][128 - line];                       // .cpp:107
