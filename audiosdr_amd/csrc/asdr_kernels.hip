@@ -36,6 +36,13 @@
 #ifndef ASDR_STRIDE
 #define ASDR_STRIDE 388
 #endif
+// Rows of the instantiations whose channels run a SHORT ALS filter on the compact overlay (als_small kinds, SAM + ALS post role): 392 floats,
+// i.e. 8 banks from channel to channel -- the filter's 5-bank operand windows of neighbouring channels then never overlap (at 388, 4 banks
+// apart, they do: 2-way).  One process per build: C4 -2.3 %, all-USB + ALS -2.2 %; the plain kinds lose 1.5 % at 392 and keep 388.
+#ifndef ASDR_ALS_STRIDE
+#define ASDR_ALS_STRIDE 392
+#endif
+#define ASDR_COMPACT_ROWS(stride) ((stride) < 500)   /* 388 / 392 against the long filters' 516 */
 #define SCR0 387   // SAM lock flag (last, unused word of the AGC table row; never live together)
 // noise-blanker overlay (dead before the rows above are written)
 #define NB_B 2     // [2,180): beta*mag[t] of detection indices 78..255 (t = 0..177) from the envelope pass, overwritten in place by
@@ -985,7 +992,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #endif
   // The ALS instantiations used to give up two of the plain kernel's orderings for registers (IF rows consumed before the ring
   // prefetches; the merged average + phase loop): experiments re-enable them for the compact rows with -DASDR_ALS_FULL_OPT=1.
-  constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && (STRIDE == ASDR_STRIDE), ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && (STRIDE == ASDR_STRIDE);
+  constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && ASDR_COMPACT_ROWS(STRIDE), ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && ASDR_COMPACT_ROWS(STRIDE);
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
   // biquad pipelines with packed products (biquad_pipe<true>), by instantiation: bit 0 = the ALS kinds, 1 = the plain kinds, 2 = the SAM roles, 3 = the block pipeline
   constexpr bool PIPE_PK = ((ASDR_PIPE_PK_MASK & 1) && HAS_ALS) || ((ASDR_PIPE_PK_MASK & 2) && !HAS_ALS && !HAS_SAM && ROLE == 0) ||
@@ -1532,7 +1539,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Hilbert ring (two previous blocks of mixed Q) is requested before the pipeline: 32 registers that the
     // pipeline and the mixer do not need, instead of two exposed HBM round trips after the mixer.  (Not in the SAM-only
     // instantiation: its only SSB channels are the padding slots, and it has no registers to spare at 3 waves/SIMD.)
-    constexpr bool RING_PREFETCH = !HAS_SAM && !(HAS_ALS && !UNIFORM && STRIDE == ASDR_STRIDE);   // (nor in the compact ALS rows' general form -- a few remainder waves: it spills with them)
+    constexpr bool RING_PREFETCH = !HAS_SAM && !(HAS_ALS && !UNIFORM && ASDR_COMPACT_ROWS(STRIDE));   // (nor in the compact ALS rows' general form -- a few remainder waves: it spills with them)
     if (RING_PREFETCH && is_ssb) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -2124,7 +2131,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     //   388-float rows: 64 + 128 + 32 + 32 (M <= 64 and delay + M <= 65: the host's choice) -> 12 waves per CU: the filter is
     //   a chain of dependent operations and its throughput follows the resident waves (profiles/README.md, occupancy experiment)
     if constexpr (HAS_ALS) {
-      constexpr bool COMPACT = (STRIDE == ASDR_STRIDE);
+      constexpr bool COMPACT = ASDR_COMPACT_ROWS(STRIDE);
       constexpr int AH = COMPACT ? 64 : 128;       // history kept from the previous block
       constexpr int XB = 128 - (128 - AH);         // L[XB + idx] = sample idx of the reference's 256-sample buffer (idx >= 128 - AH)
       constexpr int AW = XB + 256;                 // taps
@@ -2284,8 +2291,8 @@ ASDR_KERNEL(asdr_update_kernel_als, 8 * 516 + 260 + ASDR_ALS_LDS_PAD, ASDR_ALS_W
 ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260 + ASDR_ALS_LDS_PAD, ASDR_ALS_WAVES_PER_EU, 516, true, true, false, 1)
 // ALS with a short filter (taps <= 64, delay + taps <= 65: the reference's defaults are 55 and 3) on a channel that is not in SAM
 // mode: the filter's rows fit the plain instantiation's 388 floats per channel -> 12 waves per CU
-ASDR_KERNEL(asdr_update_kernel_als_small, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, true, false, true, 1)
-ASDR_KERNEL(asdr_update_kernel_als_small_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, true, false, false, 1)
+ASDR_KERNEL(asdr_update_kernel_als_small, 8 * ASDR_ALS_STRIDE, ASDR_WAVES_PER_EU, ASDR_ALS_STRIDE, true, false, true, 1)
+ASDR_KERNEL(asdr_update_kernel_als_small_mixed, 8 * ASDR_ALS_STRIDE, ASDR_WAVES_PER_EU, ASDR_ALS_STRIDE, true, false, false, 1)
 
 // SAM sub-range as three launches (asdr_launch_update): pre | PLL | post
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre_kernel(UpdateArgs a) {
@@ -2317,12 +2324,12 @@ extern "C" __global__ __launch_bounds__(64, ASDR_POST_BOUNDS) void asdr_sam_post
 }
 // ... and for SAM channels with a short ALS filter (ASDR_KERNEL_SAM_ALS): the filter is the post role's last stage, on the compact rows
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_als_kernel(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
-  asdr_update_body<ASDR_STRIDE, true, false, false, 1, 5>(a, lds);
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_ALS_STRIDE];
+  asdr_update_body<ASDR_ALS_STRIDE, true, false, false, 1, 5>(a, lds);
 }
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_als_kernel_uniform(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
-  asdr_update_body<ASDR_STRIDE, true, false, true, 1, 5>(a, lds);
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_ALS_STRIDE];
+  asdr_update_body<ASDR_ALS_STRIDE, true, false, true, 1, 5>(a, lds);
 }
 #ifndef ASDR_PLL_LANES
 #define ASDR_PLL_LANES 64   /* channels per wave of the PLL kernel (experiments: 32 = twice the waves, each half empty) */

@@ -17,6 +17,8 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant  # noqa: E402,F401  (ASDR_TOOLS_LIB)
 import audiosdr_amd as A  # noqa: E402
 from audiosdr_amd.synth import make_iq  # noqa: E402
 from oracle import asdr_oracle as ao  # noqa: E402

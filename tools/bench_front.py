@@ -14,9 +14,8 @@ import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import audiosdr_amd.binding as _binding  # noqa: E402
-if os.environ.get("ASDR_TOOLS_LIB"):   # a variant build (tools only): must be set before the first load
-    _binding.library_path = lambda _p=os.environ["ASDR_TOOLS_LIB"]: _p
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant  # noqa: E402,F401  (ASDR_TOOLS_LIB)
 import audiosdr_amd as A  # noqa: E402
 from oracle import asdr_oracle as ao  # noqa: E402
 from test_front_oracle import tone_iq  # noqa: E402

@@ -7,6 +7,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant  # noqa: E402,F401  (ASDR_TOOLS_LIB)
 import numpy as np
 import torch
 
