@@ -39,6 +39,9 @@
 // Rows of the instantiations whose channels run a SHORT ALS filter on the compact overlay (als_small kinds, SAM + ALS post role): 392 floats,
 // i.e. 8 banks from channel to channel -- the filter's 5-bank operand windows of neighbouring channels then never overlap (at 388, 4 banks
 // apart, they do: 2-way).  One process per build: C4 -2.3 %, all-USB + ALS -2.2 %; the plain kinds lose 1.5 % at 392 and keep 388.
+#ifndef ASDR_ALS_WINDOW
+#define ASDR_ALS_WINDOW 1   /* the default-length ALS filter reads its operands once per FOUR tap sets (sliding windows in registers); 0: per tap set */
+#endif
 #ifndef ASDR_ALS_STRIDE
 #define ASDR_ALS_STRIDE 392
 #endif
@@ -825,23 +828,39 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
 #pragma unroll
       for (int g = 0; g < 7; ++g) wr[g] = L[AW + WH * h + 4 * g + tq];
       const bool own_valid6 = !(tq == 3 && h != 0);   // tap 55 does not exist
-      auto epoch = [&](auto first_tag, int ep) {
+      // One tap set (four samples, one per lane of a quad; the first tap set is sample 0 alone).  J >= 0: the tap set is number J of a
+      // group of four whose operands were read TOGETHER in front of the group: a lane's 28 sum operands are x[i - D - h - 2 m],
+      // m = 0..27, and i advances by 4 from tap set to tap set, so 26 of the 28 are the previous tap set's, two places on -- E[k] =
+      // x[i0 - D - h - 2 k], k = -6..27, serves the four tap sets (tap set J uses E[m - 2 J]); likewise the operands of the lane's own
+      // taps for the update, F[k] = x[iu0 - D - h - 2 tq - 4 k], k = -3..12 (tap set J, tap group g: F[2 g - J]).  34 + 16 + 4 floats per
+      // lane and group instead of 4 x 36: the filter's LDS reads drop from 19 two-sample reads per tap set to 7.
+      auto epoch = [&](auto first_tag, auto j_tag, int ep, const float *E, const float *F, const float *XI) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int J = decltype(j_tag)::value;
         const int base = FIRST ? 0 : 4 * ep + 1;
         const int cntn = FIRST ? 1 : ((ep == 31) ? 3 : 4);
         const int n = base + tq, i = 128 + n;
         const bool mine = (s8 < cntn);
-        const float *xh = L + XB + (i - D - h);
-        float xs[7][4];
-#pragma unroll
-        for (int g = 0; g < 7; ++g) { xs[g][0] = xh[-8 * g]; xs[g][1] = xh[-8 * g - 2]; xs[g][2] = xh[-8 * g - 4]; xs[g][3] = xh[-8 * g - 6]; }
-        // the operands of this lane's own taps for the update below: x[iu - D - q], q = 8 g + 2 tq + h (requested with the sums' operands)
         const int nu = FIRST ? 0 : 4 * ep + 4;   // the updating sample of this tap set
-        const float *xu = L + XB + (128 + nu - D - h - 2 * tq);
-        float xo[7];
+        float xs[7][4], xo[7], xi;
+        if constexpr (J < 0) {
+          const float *xh = L + XB + (i - D - h);
 #pragma unroll
-        for (int g = 0; g < 7; ++g) xo[g] = xu[-8 * g];
-        const float xi = L[XB + i];   // the sample itself (e = x[i] - y), requested with the operands
+          for (int g = 0; g < 7; ++g) { xs[g][0] = xh[-8 * g]; xs[g][1] = xh[-8 * g - 2]; xs[g][2] = xh[-8 * g - 4]; xs[g][3] = xh[-8 * g - 6]; }
+          // the operands of this lane's own taps for the update below: x[iu - D - q], q = 8 g + 2 tq + h (requested with the sums' operands)
+          const float *xu = L + XB + (128 + nu - D - h - 2 * tq);
+#pragma unroll
+          for (int g = 0; g < 7; ++g) xo[g] = xu[-8 * g];
+          xi = L[XB + i];   // the sample itself (e = x[i] - y), requested with the operands
+        } else {
+#pragma unroll
+          for (int g = 0; g < 7; ++g) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xs[g][t] = E[6 + 4 * g + t - 2 * J];
+            xo[g] = F[3 + 2 * g - J];
+          }
+          xi = XI[J];
+        }
         float y = 0.0f;
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
@@ -865,23 +884,6 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
         // and a tap set is 144 instructions instead of 151 (21 of them one-cycle s_nop for the DPP read-after-write hazard): C4 -3.8 %.
         asm volatile("" : "+v"(y));
 #endif
-#ifdef ASDR_ALS_E_THROUGH_LDS   /* round 3, first form: the error of the tap set's updating sample through an LDS word, two wave syncs per tap set */
-        if (mine) {
-          const float e = L[XB + i] - y;
-          L[OUT + n] = notch ? e : y;
-          if ((n & 3) == 0) L[SCR] = e;
-        }
-        WAVE_SYNC();
-        if (nu < ASDR_N) {
-          const float e = L[SCR];
-#pragma unroll
-          for (int g = 0; g < 7; ++g) {
-            const float gq = e * xo[g]; const float dq = lam * gq; const float wn = wr[g] + dq;
-            wr[g] = (g == 6 && !own_valid6) ? wr[g] : wn;
-          }
-        }
-        WAVE_SYNC();
-#else
         // The error of the updating sample (n = nu: lane tq = 3 of the low quad, tq = 0 in the first tap set) goes to the channel's
         // eight lanes through two DPP moves -- its quad, then the partner quad (row_shr:4 into banks 1 and 3 only) -- instead of an
         // LDS word between two wave syncs: the tap set's dependent path error -> tap update -> next products stays in registers.
@@ -900,11 +902,33 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
             wr[g] = (g == 6 && !own_valid6) ? wr[g] : wn;
           }
         }
-#endif
       };
-      epoch(std::true_type{}, -1);
+      epoch(std::true_type{}, std::integral_constant<int, -1>{}, -1, nullptr, nullptr, nullptr);
+#if ASDR_ALS_WINDOW
+      // OUT may overlay the history (the stand-alone kernel: output n at buffer index 128 + n - 65): a group's reads, made in front of its
+      // first tap set, reach back to index i0 - D - h - 54 >= i0 - 64 - ... -- never below what the PREVIOUS groups' outputs (n <= base0 - 1,
+      // index <= i0 - 66) have overwritten -- and forward to samples of the current block, which nothing writes.
 #pragma unroll 1
-      for (int ep = 0; ep < 32; ++ep) epoch(std::false_type{}, ep);
+      for (int grp = 0; grp < 8; ++grp) {
+        const int ep0 = 4 * grp, i0 = 128 + 4 * ep0 + 1 + tq;
+        const float *xh0 = L + XB + (i0 - D - h);
+        const float *xu0 = L + XB + (128 + 4 * ep0 + 4 - D - h - 2 * tq);
+        float E[34], F[16], XI[4];
+#pragma unroll
+        for (int k = 0; k < 34; ++k) E[k] = xh0[-2 * (k - 6)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) F[k] = xu0[-4 * (k - 3)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) XI[j] = L[XB + i0 + 4 * j];
+        epoch(std::false_type{}, std::integral_constant<int, 0>{}, ep0, E, F, XI);
+        epoch(std::false_type{}, std::integral_constant<int, 1>{}, ep0 + 1, E, F, XI);
+        epoch(std::false_type{}, std::integral_constant<int, 2>{}, ep0 + 2, E, F, XI);
+        epoch(std::false_type{}, std::integral_constant<int, 3>{}, ep0 + 3, E, F, XI);
+      }
+#else
+#pragma unroll 1
+      for (int ep = 0; ep < 32; ++ep) epoch(std::false_type{}, std::integral_constant<int, -1>{}, ep, nullptr, nullptr, nullptr);
+#endif
       // the taps back to their LDS rows
 #pragma unroll
       for (int g = 0; g < 7; ++g) L[AW + WH * h + 4 * g + tq] = wr[g];
