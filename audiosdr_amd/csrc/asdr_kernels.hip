@@ -39,6 +39,9 @@
 // Rows of the instantiations whose channels run a SHORT ALS filter on the compact overlay (als_small kinds, SAM + ALS post role): 392 floats,
 // i.e. 8 banks from channel to channel -- the filter's 5-bank operand windows of neighbouring channels then never overlap (at 388, 4 banks
 // apart, they do: 2-way).  One process per build: C4 -2.3 %, all-USB + ALS -2.2 %; the plain kinds lose 1.5 % at 392 and keep 388.
+#ifndef ASDR_AGC_QUIET_PATH
+#define ASDR_AGC_QUIET_PATH 1   /* 0: every block through the chunk loop (measurements) */
+#endif
 #ifndef ASDR_ALS_WINDOW
 #define ASDR_ALS_WINDOW 1   /* the default-length ALS filter reads its operands once per FOUR tap sets (sliding windows in registers); 0: per tap set */
 #endif
@@ -2024,27 +2027,52 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ABL_ON(ABL_AGC) && __any(agc_en)) {
       const float *tab = L + AGC_TAB;
       const float gain_in = agc_gain_in;
-      if (agc_en) {   // stage the channel's gain table in LDS
+      // A QUIET block: in no channel of the wave does a sample exceed the envelope (the block's largest |x|, formed by all lanes:
+      // piece maxima, then three DPP steps over the channel's eight lanes) and no hang counter can run out inside the block -- then
+      // the envelope, the governing value and the gain do not move in any of the 128 samples (:412-428: neither branch fires): the
+      // counters drop by 128, every sample gets the gain carried in, and neither the table nor the per-sample rows are needed.
+      // With a steady signal that is most blocks once the envelope has crept up to the peaks (profiles/README.md).
+      float av16[16];
+      DEFINE_ALL_PATHS(av16, 16);
+      float blockmax = 0.0f;
+      if (agc_en) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float au[8];
+          load8(L + W0 + kA + 64 * h, au);
+          // |x| clamped to 1.0 (:410-411) for every sample, in parallel; the sequential pass below replaces it in place by the
+          // governing envelope value.  (v_max ignores a NaN operand, as `NaN > old` is false: a NaN sample never attacks.)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float ax = fabsf(au[j]); av16[8 * h + j] = (ax > 1.0f) ? 1.0f : ax; }   // NaN-preserving like the reference
+          float mx = av16[8 * h];
+#pragma unroll
+          for (int u = 1; u < 8; ++u) mx = fmaxf(mx, av16[8 * h + u]);
+          blockmax = (h == 0) ? mx : fmaxf(blockmax, mx);
+        }
+        blockmax = fmaxf(blockmax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(blockmax), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+        blockmax = fmaxf(blockmax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(blockmax), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
+        blockmax = fmaxf(blockmax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(blockmax), 0x141, 0xF, 0xF, true)));   // row_half_mirror: the partner quad
+      }
+      const float am_level = (float)(2.0 * (double)(carrier_fresh ? carrier_now : agc_carrier0));
+      const float am_clamped = (am_level > 1.0f) ? 1.0f : am_level;
+      // (AM: twice the carrier level stands in for |x| of every sample, :407-409 -- the lead lane holds it)
+      const bool agc_quiet = ASDR_AGC_QUIET_PATH && __all(!(agc_en && lead) || (agc_hc0 >= 128u && agc_hang >= 8u && !((is_am ? am_clamped : blockmax) > agc_old0)));
+      if (agc_en && !agc_quiet) {   // stage the channel's gain table and the |x| rows in LDS
 #pragma unroll
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = agc_t4[r]; }
-        // |x| clamped to 1.0 (:410-411) for every sample, in parallel; the sequential pass below replaces it in place by the
-        // governing envelope value
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          float au[8], av8[8];
-          load8(L + W0 + kA + 64 * h, au);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float ax = fabsf(au[j]); av8[j] = (ax > 1.0f) ? 1.0f : ax; }   // NaN-preserving like the reference
-          store8(L + AGC_GV + kA + 64 * h, av8);
-        }
+        store8(L + AGC_GV + kA, av16); store8(L + AGC_GV + kA + 64, av16 + 8);
       }
-      WAVE_SYNC();
+      if (!agc_quiet) WAVE_SYNC();
       TL(12);
+      if (agc_quiet) {
+        if (agc_en && lead) {
+          S->agc_hang_counter = agc_hc0 - 128u;      // envelope and gain stay as they are in HBM
+          status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)gain_in < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
+        }
+      } else
       if (agc_en && lead) {
         float old_abs = agc_old0;
         uint32_t hc = agc_hc0;
-        const float am_level = (float)(2.0 * (double)(carrier_fresh ? carrier_now : agc_carrier0));
-        const float am_clamped = (am_level > 1.0f) ? 1.0f : am_level;
         const float al_a = agc_al_a, be_a = agc_be_a, al_r = agc_al_r, be_r = agc_be_r;
         const uint32_t hang = agc_hang;
         float gv = -1.0f;   // envelope value governing the current gain; -1 = no update yet in this block
@@ -2124,9 +2152,26 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         S->agc_gain = g_end;
         status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
       }
-      WAVE_SYNC();
+      if (!agc_quiet) WAVE_SYNC();
       TL(13);
-      if (agc_en) {
+      if (agc_quiet) {
+        if (agc_en) {   // every sample at the gain carried in (:430-433)
+          const float sg = agc_sg;
+#pragma unroll 1
+          for (int h = 0; h < 2; ++h) {
+            float au[8];
+            load8(L + W0 + kA + 64 * h, au);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float o = gain_in * sg * au[j];
+              o = (o > 1.0f) ? 1.0f : o;
+              o = (o < -1.0f) ? -1.0f : o;
+              au[j] = o;
+            }
+            store8(L + W0 + kA + 64 * h, au);
+          }
+        }
+      } else if (agc_en) {
         const float sg = agc_sg;
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {

@@ -119,7 +119,7 @@ ROBUSTNESS_CASES = {
              "local-oscillator cache and the wave-uniform mixer both miss; every lane runs its own 2 x 16 sin/cos lookups"),
     "agc_general_form": dict(phases=False, agc=True, impulses=False,
         what="AGC hang time 0 (setAGChangTime(0)): the envelope releases between the audio's peaks and attacks again at each of them, "
-             "so every 8-sample chunk takes the AGC's general per-sample form (no hanging-chunk / attack-only fast form); input as C2"),
+             "so every 8-sample chunk takes the AGC's general per-sample form (no quiet-block, hanging-chunk or attack-only fast form); input as C2"),
     "impulse_every_block": dict(phases=False, agc=False, impulses=True,
         what="an impulse in every block of every channel: the blanker's general path (counts, mask decode / zero / ramp / encode)"),
     "all_three": dict(phases=True, agc=True, impulses=True, what="the three together"),

@@ -270,6 +270,45 @@ def test_agc_hanging_chunks_and_attacks(gpu, ao):
     batch.close()
 
 
+def test_agc_quiet_blocks(gpu, ao):
+    """The AGC's block-level fast form: when in NO channel of a wave a sample exceeds the envelope and no hang counter can run out
+    inside the block (counter >= 128, hang >= 8), the chunk loop, the gain table and the per-sample rows are skipped -- counters drop
+    by 128, every sample takes the gain carried in.  A loud stretch, then a soft one: every channel hangs until its counter runs
+    out.  Hang times swept around one block (2.6 .. 6.2 ms = 114 .. 273 samples) put the counters on either side of 128 at the
+    block boundaries (some channels of a wave quiet, others not: the wave takes the chunk loop); wave 0 keeps the default hang
+    time (4,410 samples: ~34 quiet blocks in a row, then release and attacks), wave 2 is AM (|x| = the carrier level), wave 3 has
+    the blanker on and the audio filter off.  AGC tap, int16 output and the status bits, block by block."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, n_blk = 32, 64
+    I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.3, noise=0.001)
+    env = np.ones(n_blk * 128)
+    env[128 * 8:128 * 50] = 0.3; env[128 * 50:128 * 52] = 1.0; env[128 * 52:] = 0.1
+    I = (I.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
+    Q = (Q.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
+    setters = [S("setDemodMode", 1), S("enableAudioFilter", sel=lambda c: c < 24), S("disableNoiseBlanker", sel=lambda c: c < 24)]
+    setters += [S("setAGChangTime", 2.6 + 0.45 * (c - 8), sel=(lambda k, c=c: k == c)) for c in range(8, 16)]
+    setters += [S("setDemodMode", 4, sel=lambda c: 16 <= c < 24), S("setAGChangTime", 3.1, sel=lambda c: c in (17, 21, 26, 29))]
+    batch, orcs = _mk(gpu, ao, n_ch, setters, taps=True)
+    for b in range(n_blk):
+        got = batch.update(I[:, b:b + 1], Q[:, b:b + 1])[:, 0]
+        taps = batch.read_taps()
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, b], Q[c, b])
+            assert np.array_equal(f32_bits(taps["AGC"][c]), f32_bits(orcs[c].tap("AGC"))), "block %d ch %d AGC tap" % (b, c)
+            assert np.array_equal(got[c], want), "block %d ch %d" % (b, c)
+        if b in (9, 20, 45, 51, 63):
+            compare_status(gpu, batch, orcs)
+    # the same settings without taps, four blocks per call (the multi-block loop keeps the state in HBM between blocks)
+    batch2, orcs2 = _mk(gpu, ao, n_ch, setters)
+    for b in range(0, n_blk, 4):
+        got = batch2.update(I[:, b:b + 4], Q[:, b:b + 4])
+        for c in range(n_ch):
+            want = orcs2[c].update(I[c, b:b + 4], Q[c, b:b + 4]).reshape(4, 128)
+            assert np.array_equal(got[c], want), "blocks %d.. ch %d" % (b, c)
+    compare_status(gpu, batch2, orcs2)
+    batch.close(); batch2.close()
+
+
 def test_calls_alternating_between_two_streams(gpu, ao):
     """asdr_update_device on a different stream than the previous call waits (event) for that call's kernels: every launch
     read-modify-writes the same per-channel state.  Two caller-owned streams used alternately, no host synchronisation in
