@@ -236,11 +236,14 @@ struct asdr_batch {
   // call to call only for calls on ASDR_STREAM_BATCH, whose contract leaves the ordering against other streams to the caller.
   hipStream_t lane[ASDR_LANES + 1] = {};   // [ASDR_LANES] = the stream of the sub-ranges that are not cut (the remainders' few long-lived waves)
   hipEvent_t ev_lane[ASDR_LANES + 1] = {};
-  int n_lanes = 2, n_lanes_sam = 4;      // lanes in use: 2 (C2: 0.1209 -> 0.1106 ms; 3 and 4 lanes: +0.5 %); schedules whose SAM channels run as
-                                         // pre | PLL | post launches take 4 (C3: 0.507 -> 0.465 ms: more PLL kernels, which leave issue slots free,
-                                         // beside pre / post kernels, which do not)
+  int n_lanes = 2, n_lanes_sam = 3;      // lanes in use: 2 (C2: 0.1209 -> 0.1106 ms; 3 and 4 lanes: +0.5 %); schedules whose SAM channels run as
+                                         // pre | PLL | post launches take 3 = one per pool stream (C3, host clock from idle to drained over 1,500
+                                         // calls: 0.499 -> 0.4645 ms: a PLL kernel, which leaves issue slots free, beside pre / post kernels,
+                                         // which do not; 2 lanes 0.493, 4 lanes -- two of them sharing a stream, which then carries half the
+                                         // work -- 0.495, 6 lanes 0.4705)
   int sched_lanes = 2;                   // ... as the schedule was built for (the lanes' writer bits in SlotInfo.lo)
   bool lanes_pending = false;            // the lanes hold launches that nothing has been ordered behind yet
+  bool sched_sam_heavy = false;          // the schedule's lane count is the SAM one (the three-launch SAM form is at least half of it)
   bool last_was_lanes = false;           // the previous call ran on the lanes (asdr_update_device on ASDR_STREAM_BATCH)
   int lanes_min_waves = 1024;            // smallest sub-range that is run as lanes
   bool lanes_enabled = true;
@@ -562,7 +565,8 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     // lane l's piece (the launcher's split: waves [w l / n, w (l + 1) / n) of the sub-range) and inside it.
     {   // 4 lanes when the pre | PLL | post launches are most of the work (C3: 0.505 -> 0.456 ms), 2 otherwise (C4, a seventh SAM: 0.345 / 0.37-0.43)
       const int sam_slots_ = b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS];
-      b->sched_lanes = (b->sam_split && 2 * sam_slots_ >= pos) ? b->n_lanes_sam : b->n_lanes;
+      b->sched_sam_heavy = b->sam_split && 2 * sam_slots_ >= pos;
+      b->sched_lanes = b->sched_sam_heavy ? b->n_lanes_sam : b->n_lanes;
     }
     for (int k = 0; k < ASDR_KERNEL_KINDS; k++) {
       const long w = b->kind_uniform_slots[k] / 8;
@@ -745,6 +749,7 @@ int sync_all(asdr_batch *b) {
   HIPCHK(hipStreamSynchronize(b->last_stream));   // nullptr = the null stream
   HIPCHK(hipStreamSynchronize(b->stream));
   if (b->lanes_pending) { for (int l = 0; l < ASDR_LANES + 1; l++) if (b->lane[l]) HIPCHK(hipStreamSynchronize(b->lane[l])); b->lanes_pending = false; }
+
   return 0;
 }
 
@@ -1699,6 +1704,10 @@ int asdr_region_timing_begin(asdr_batch_t *b, void *stream_) {
     b->region_stream = (hipStream_t)stream_; b->region_on_lanes = false;
   }
   HIPCHK(hipEventRecord(b->rev0, b->region_stream));
+  // ... and no lane runs ahead into the region: never-joined lanes drift apart (a lane that shares its stream with another falls behind
+  // the rest), and a lane that is hundreds of calls ahead at the begin marker has done part of the region's work before it -- the
+  // region then reads shorter than the work takes (C3 with four lanes on three streams read 0.45 ms per call for a true 0.49)
+  if (b->region_on_lanes) for (int l = 1; l < ASDR_LANES + 1; l++) if (b->lane[l]) HIPCHK(hipStreamWaitEvent(b->lane[l], b->rev0, 0));
   b->region_calls = 0;
   return 0;
 }

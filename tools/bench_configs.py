@@ -39,9 +39,12 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
     outs, ms = [], []
     T = blocks_per_launch
     dO = torch.empty((n_ch, T, BLOCK), dtype=torch.int16, device="cuda")
+    resident = []   # every uploaded input stays resident: the steady-state phases below cycle through them (ONE block repeated puts a
+                    # phase jump at every block boundary -- the blanker detects it, the PLL re-acquires: C3 +8 %)
     for li, b0 in enumerate(range(0, n_blk - T + 1, T)):
         dI = torch.from_numpy(np.ascontiguousarray(I[:, b0:b0 + T])).cuda()
         dQ = torch.from_numpy(np.ascontiguousarray(Q[:, b0:b0 + T])).cuda()
+        resident.append((dI, dQ))
         torch.cuda.synchronize()
         batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
         t = batch.last_kernel_ms()
@@ -56,12 +59,15 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
     global STEADY_MS, STEADY_BATCH_MS, LANE_CALLS
     one = max(1e-3, float(np.median(ms)))
     n_rep = int(min(4000, max(20, 250.0 / one)))
-    for _ in range(n_rep):
-        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
+    def go(i, stream):
+        di, dq = resident[i % len(resident)]
+        batch.update_device(di.data_ptr(), dq.data_ptr(), dO.data_ptr(), T, stream)
+    for i in range(n_rep):
+        go(i, 0)
     torch.cuda.synchronize()
     batch.region_timing_begin(0)
-    for _ in range(n_rep):
-        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
+    for i in range(n_rep):
+        go(i, 0)
     total, calls = batch.region_timing_end()
     STEADY_MS = total / max(1, calls)
     # ... and the same launches on the batch's own streams (ASDR_STREAM_BATCH: the pieces of every sub-range on never-joined lanes)
@@ -70,12 +76,12 @@ def run_launches(batch, I, Q, blocks_per_launch, warm_launches, timed_launches):
         return ms, np.concatenate(outs, axis=1)
     lc0 = batch.lane_calls()
     batch.set_launch_timing(False)   # (an event pair around every call keeps it off the lanes)
-    for _ in range(n_rep):
-        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, A.STREAM_BATCH)
+    for i in range(n_rep):
+        go(i, A.STREAM_BATCH)
     batch.synchronize()
     batch.region_timing_begin(A.STREAM_BATCH)
-    for _ in range(n_rep):
-        batch.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, A.STREAM_BATCH)
+    for i in range(n_rep):
+        go(i, A.STREAM_BATCH)
     total, calls = batch.region_timing_end()
     STEADY_BATCH_MS = total / max(1, calls)
     LANE_CALLS = batch.lane_calls() - lc0
