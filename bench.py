@@ -560,7 +560,18 @@ def main():
     k_ms = region_ms / max(1, region_calls) if batch is not None else 0.0
     pair_ms = None
     ordered = None
+    steady = None
     lane_calls = batch.lane_calls() if batch is not None else 0
+    if batch is not None and args.config == "c2" and args.steps < 1000:
+        # A short timed region (the driver's --warmup 5 --steps 20) is the first few blocks of a FRESH receiver bank: the AGC's envelope
+        # is still creeping up to the signal's peaks (attacking samples in most eight-sample chunks; profiles/README.md "The first blocks
+        # of a fresh batch").  `value` stays what those steps took; the same batch after 500 further steps is reported beside it.
+        ms_s = measure_region(batch, step, stream, 500, 1500)
+        ach_s = ALGO_BYTES_PER_BLOCK * n_ch / (ms_s * 1e-3) / 1e9
+        steady = {"ms_per_step": round(ms_s, 5), "frac": round(ach_s / HBM_PEAK_GBS, 4), "Msamples_per_s": round(n_ch * BLOCK / ms_s / 1e3, 1),
+                  "what": "the same batch, same launch form, after the timed region: 500 untimed steps, then one HIP-event pair around 1,500 "
+                          "steps -- the receiver bank in its steady state (the timed region above is blocks %d..%d of a fresh bank)"
+                          % (args.warmup, args.warmup + args.steps - 1)}
     if batch is not None and args.config == "c2":
         if not args.caller_stream:   # the same steps in strict stream order, on a caller's stream
             def cs_step(i):
@@ -634,6 +645,7 @@ def main():
                          "launch_stream": "caller's stream (strict stream order)" if args.caller_stream else
                                           "ASDR_STREAM_BATCH: the batch's own streams; %d of the %d untimed + timed calls ran as two never-joined lanes (halves of the channel range)" % (lane_calls, untimed + args.steps),
                          "caller_stream_ordered": ordered,
+                         "steady_state": steady,
                          "kernel_ms_event_pair_per_launch": None if pair_ms is None else round(pair_ms, 5),
                          "algorithmic_bytes_per_channel_block": round(cfg["algo"], 1),
                          "algorithmic_bytes_per_launch": int(round(algo))},
