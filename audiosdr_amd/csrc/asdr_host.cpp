@@ -563,7 +563,7 @@ void flush_host(asdr_batch *b, std::vector<int32_t> &rows_out, bool &bulk, bool 
     }
     // The lanes' writers: in every uniform sub-range, for lane l >= 1, the first wave of each settings group at or behind the start of
     // lane l's piece (the launcher's split: waves [w l / n, w (l + 1) / n) of the sub-range) and inside it.
-    {   // 4 lanes when the pre | PLL | post launches are most of the work (C3: 0.505 -> 0.456 ms), 2 otherwise (C4, a seventh SAM: 0.345 / 0.37-0.43)
+    {   // 3 lanes (one per pool stream) when the pre | PLL | post launches are at least half of the work (C3: 0.5165 -> 0.481 ms), 2 otherwise (C4, a seventh SAM: 0.331 / 0.386)
       const int sam_slots_ = b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS];
       b->sched_sam_heavy = b->sam_split && 2 * sam_slots_ >= pos;
       b->sched_lanes = b->sched_sam_heavy ? b->n_lanes_sam : b->n_lanes;
