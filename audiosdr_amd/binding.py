@@ -60,7 +60,7 @@ EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read",
             "asdr_create_sharded", "asdr_n_shards", "asdr_shard", "asdr_shard_first_channel", "asdr_shard_device",
             "asdr_host_alloc", "asdr_host_free", "asdr_host_register", "asdr_host_unregister", "asdr_set_host_chunks",
-            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures", "asdr_set_launch_split", "asdr_order_after", "asdr_order_before", "asdr_lane_calls", "asdr_set_lanes"] +
+            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures", "asdr_set_launch_split", "asdr_order_after", "asdr_order_before", "asdr_lane_calls", "asdr_sam_role_calls", "asdr_set_lanes"] +
            ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
 
 _lib = None
@@ -156,6 +156,7 @@ def load_library(path=None):
         L.asdr_order_after.argtypes = [vp, vp]; L.asdr_order_after.restype = _i
         L.asdr_order_before.argtypes = [vp, vp]; L.asdr_order_before.restype = _i
         L.asdr_lane_calls.argtypes = [vp]; L.asdr_lane_calls.restype = C.c_long
+        L.asdr_sam_role_calls.argtypes = [vp]; L.asdr_sam_role_calls.restype = C.c_long
         L.asdr_set_lanes.argtypes = [vp, _i, _i]; L.asdr_set_lanes.restype = _i
     if path is None:
         _lib = L
@@ -214,6 +215,10 @@ class AudioSDRBatch:
 
     def lane_calls(self):
         return int(self._L.asdr_lane_calls(self._h))
+
+    def sam_role_calls(self):
+        """Multi-block calls that ran the SAM roles on three chained streams (include/asdr.h)."""
+        return int(self._L.asdr_sam_role_calls(self._h))
 
     def set_lanes(self, on=True, min_waves=0):
         self._chk(self._L.asdr_set_lanes(self._h, 1 if on else 0, int(min_waves)))

@@ -182,6 +182,9 @@ typedef struct {
                              one 8 KB tile per group of 8 schedule slots, [tile][sample][I, Q][slot in tile] -- the pre kernel's wave
                              writes its tile whole, the PLL kernel's lanes (one channel each) read 32-byte segments of 8 tiles;
                              NULL = the fused SAM kernel */
+  uint32_t *sam_lock;     /* ... and the PLL's lock flag of the block, one word per schedule slot of the launch, beside the tiles (not
+                             through the status word: when the three roles of consecutive blocks overlap -- pre(k+1) | PLL(k+1) beside
+                             post(k), asdr_launch_sam_role -- the status word may already hold block k+1's flag when post(k) reads it) */
   LoEntry *lo_ring;       /* [ASDR_LO_RING] the streaming pipeline's oscillator role leaves block b's pairs in entry b % ASDR_LO_RING;
                              its progress counter is stream_prog[3 * stream_waves] */
   ChainConsts k;

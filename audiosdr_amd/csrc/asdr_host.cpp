@@ -49,6 +49,7 @@ extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int 
 extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream);
 extern "C" int asdr_kernels_upload_tables(void);
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
+extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int uniform, int role, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
 
 namespace {
@@ -295,7 +296,10 @@ struct asdr_batch {
                                     // channels, 9 % slower all-ALS; profiles/README.md "Round 3" is the one source of these numbers)
   bool als_split = false;           // decided when the schedule is built
   float *d_xch_sam = nullptr;       // SAM sub-range as pre | PLL | post launches: the IF rows of the current block (1 KB per slot)
-  size_t xch_sam_slots = 0;
+  size_t xch_sam_slots = 0;         // ... TWO sets of tiles (and of lock words behind them): consecutive blocks of a multi-block call alternate
+  hipEvent_t ev_role[6] = {};       // SAM role streams: [0..1] pre done, [2..3] PLL done, [4..5] post done, by block parity
+  bool sam_role_streams = true;     // (ASDR_NO_SAM_ROLE_STREAMS: off, for measurements)
+  long stat_sam_role_calls = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode or AM: the modes the block pipeline has roles for (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   long stat_stream_launches = 0;
@@ -832,6 +836,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     for (int i = 0; i < ASDR_LANES + 1 && ok; i++)
       if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
+    b->sam_role_streams = getenv("ASDR_NO_SAM_ROLE_STREAMS") == nullptr;
     if (ok && (b->stream = pool_stream(device, 0)) == nullptr) ok = false;   // the pool's first stream (= lane 0: a batch runs on the lanes or on its own stream, never both at once)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
@@ -949,6 +954,7 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->ev_fork) hipEventDestroy(b->ev_fork);
   for (int i = 0; i < ASDR_AUX_STREAMS; i++) if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]);   // (the streams belong to the process-wide pool)
   for (int i = 0; i < ASDR_LANES + 1; i++) if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]);
+  for (int i = 0; i < 6; i++) if (b->ev_role[i]) hipEventDestroy(b->ev_role[i]);
   // (b->stream and the helper streams belong to the process-wide pool)
   delete b;
 }
@@ -1042,11 +1048,18 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   if (sam_split && (size_t)sam_slots > b->xch_sam_slots) {
     HIPCHK(hipStreamSynchronize(stream));
     float *grown = nullptr;
-    HIPCHK(hipMalloc(&grown, (size_t)sam_slots * 2 * ASDR_N * sizeof(float)));   // (pointer and size change only once this succeeded)
+    HIPCHK(hipMalloc(&grown, 2 * ((size_t)sam_slots * 2 * ASDR_N * sizeof(float) + (size_t)sam_slots * sizeof(uint32_t))));   // two sets: tiles | tiles | lock words | lock words (pointer and size change only once this succeeded)
     if (b->d_xch_sam) hipFree(b->d_xch_sam);
     b->d_xch_sam = grown; b->xch_sam_slots = (size_t)sam_slots;
   }
+  // tiles / lock words of the slots [first, ..) of a SAM kind's sub-range, set `parity` (0 everywhere but in the role streams below)
+  auto set_sam_rows = [&](UpdateArgs &x, int kind, int first, int parity) {
+    const size_t at = (size_t)(first - b->kind_first[kind]) + (kind == ASDR_KERNEL_SAM_ALS ? (size_t)b->kind_slots[ASDR_KERNEL_SAM] : 0);
+    x.xch_sam = b->d_xch_sam + ((size_t)parity * b->xch_sam_slots + at) * 2 * ASDR_N;
+    x.sam_lock = reinterpret_cast<uint32_t *>(b->d_xch_sam + 2 * b->xch_sam_slots * 2 * ASDR_N) + (size_t)parity * b->xch_sam_slots + at;
+  };
   a.xch_sam = sam_split ? b->d_xch_sam : nullptr;
+  a.sam_lock = sam_split ? reinterpret_cast<uint32_t *>(b->d_xch_sam + 2 * b->xch_sam_slots * 2 * ASDR_N) : nullptr;
   // ... and channels with a short ALS filter as two: the chain up to the AGC | the filter and the output stage (stage taps off: the taps
   // of the last two stages are the fused kernel's)
   const bool als_split = b->als_split && !b->taps_on && b->kind_uniform_slots[ASDR_KERNEL_ALS_SMALL] > 0;
@@ -1178,8 +1191,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
           al.lo_cache = b->d_lo + (size_t)(1 + (l % ASDR_LANES)) * 2 * ASDR_LO_ENTRIES;   // this lane's own set: its writers fill it, its waves read it (general-kernel waves have no entry)
           al.lo_write = 1u;
           al.lo_writer_bit = ASDR_LO_WRITER_LANE(l % ASDR_LANES);   // (lane 0: ASDR_LO_WRITER; a direct launch: its wave 0, under any name)
-          if (sam_split && su.kind == ASDR_KERNEL_SAM) al.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
-          if (sam_split && su.kind == ASDR_KERNEL_SAM_ALS) al.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
+          if (sam_split && (su.kind == ASDR_KERNEL_SAM || su.kind == ASDR_KERNEL_SAM_ALS)) set_sam_rows(al, su.kind, first, 0);
           const int form = (als_split && su.kind == ASDR_KERNEL_ALS_SMALL && su.uniform) ? 2 : su.uniform;
           if (per_block) {
             al.in_i = dI + (size_t)lb * ASDR_N; al.in_q = dQ + (size_t)lb * ASDR_N; al.out = dOut + (size_t)lb * ASDR_N; al.n_blocks = 1;
@@ -1219,6 +1231,18 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   }
   int main_item = 0;
   for (int i = 1; i < n_items; i++) if (items[i].slots > items[main_item].slots) main_item = i;
+  // SAM role streams (see the launch below): a multi-block call whose schedule is ONE sub-range of SAM channels run as three launches
+  const bool sam_roles = b->sam_role_streams && per_block && n_launch >= 2 && parts == 1 && n_items == 1 && taps == nullptr && sam_split &&
+                         (subs[items[0].sub].kind == ASDR_KERNEL_SAM || subs[items[0].sub].kind == ASDR_KERNEL_SAM_ALS);
+  hipStream_t s_pre = nullptr, s_pll = nullptr;
+  if (sam_roles) {
+    s_pre = aux_stream(b, 0); s_pll = aux_stream(b, 1);
+    if (!s_pre || !s_pll) return fail("stream creation failed");
+    for (int i = 0; i < 6; i++) if (!b->ev_role[i]) HIPCHK(hipEventCreateWithFlags(&b->ev_role[i], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(b->ev_fork, stream));
+    HIPCHK(hipStreamWaitEvent(s_pre, b->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_fork, 0));
+    b->stat_sam_role_calls++;
+  }
   for (int lb = 0; lb < n_launch; lb++) {
     if (per_block) {
       a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
@@ -1242,11 +1266,24 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
         a.direct_ch0 = s0.ch + (first - subs[i].first); a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo;
         if (first != subs[i].first) a.lo_write = 0u;   // (a direct launch's wave 0 is the writer: only the piece that holds the group's first wave)
       }
-      if (sam_split && subs[i].kind == ASDR_KERNEL_SAM)   // this sub-range's tiles (1 KB per slot, 8 slots per tile)
-        a.xch_sam = b->d_xch_sam + (size_t)(first - b->kind_first[ASDR_KERNEL_SAM]) * 2 * ASDR_N;
-      if (sam_split && subs[i].kind == ASDR_KERNEL_SAM_ALS)   // ... behind those of the SAM kind
-        a.xch_sam = b->d_xch_sam + (size_t)(b->kind_slots[ASDR_KERNEL_SAM] + first - b->kind_first[ASDR_KERNEL_SAM_ALS]) * 2 * ASDR_N;
+      const bool sam3 = sam_split && (subs[i].kind == ASDR_KERNEL_SAM || subs[i].kind == ASDR_KERNEL_SAM_ALS);
+      if (sam3) set_sam_rows(a, subs[i].kind, first, sam_roles ? (lb & 1) : 0);   // this sub-range's tiles (1 KB per slot, 8 slots per tile) and lock words
       const int form = (als_split && subs[i].kind == ASDR_KERNEL_ALS_SMALL && subs[i].uniform) ? 2 : subs[i].uniform;
+      if (sam_roles) {
+        // SAM role streams: block lb's pre | PLL | post on three streams, chained by events, so that pre(lb + 1) and PLL(lb + 1) run beside
+        // post(lb) -- the PLL's 128-step chain per block (~32 us for any bank size) then bounds the call alone instead of adding to the
+        // other two roles.  The roles of a block touch disjoint state (as the block pipeline's: status bits by atomics, the lock flag
+        // beside the tiles), the tiles alternate between two sets, and pre(lb + 2) waits for post(lb) to have left its set.
+        const int pa = lb & 1;
+        if (lb >= 2) HIPCHK(hipStreamWaitEvent(s_pre, b->ev_role[4 + pa], 0));
+        if (asdr_launch_sam_role(&a, subs[i].kind, form, 0, s_pre) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_role[pa], s_pre)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_role[pa], 0));
+        if (asdr_launch_sam_role(&a, subs[i].kind, form, 1, s_pll) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_role[2 + pa], s_pll)); HIPCHK(hipStreamWaitEvent(stream, b->ev_role[2 + pa], 0));
+        if (asdr_launch_sam_role(&a, subs[i].kind, form, 2, stream) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_role[4 + pa], stream));
+        continue;
+      }
       if (asdr_launch_update(&a, subs[i].kind, form, s) != 0) return fail("update kernel launch failed");
       if (it != main_item) HIPCHK(hipEventRecord(b->ev_join[n_aux - 1], s));
     }
@@ -1436,6 +1473,14 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
     b->h2d_stream = pool_stream(b->device, 1); b->d2h_stream = pool_stream(b->device, 2);
     if (!b->h2d_stream || !b->d2h_stream) return fail("stream creation failed");
   }
+  // Behind the lanes first: calls on ASDR_STREAM_BATCH may still be running on them, and what follows rewrites rows their kernels read
+  // (the flush: parameters, schedule) and state they write (launch-form fuzz, seed 144: a setter, then this entry point, while lane 2 of a
+  // nine-block call was still at block 3 -- its channel ran the rest of that call with the filter the setter had just enabled).
+  if (b->lanes_pending) {
+    if (needs_flush(b)) { if (sync_all(b) != 0) return -1; }
+    else { if (lanes_join_into(b, b->stream) != 0) return -1; b->lanes_pending = false; }
+    b->last_stream = b->stream; b->last_was_lanes = false;
+  }
   // the schedule must exist before the plan can be read off it
   if (b->ev_last_valid && b->stream != b->last_stream) {
     HIPCHK(hipEventRecord(b->ev_last, b->last_stream));
@@ -1596,6 +1641,10 @@ int asdr_order_after(asdr_batch_t *b, void *stream_) {   // the batch's calls on
 long asdr_lane_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_lane_calls; return t; }
   return b ? b->stat_lane_calls : -1;
+}
+long asdr_sam_role_calls(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_sam_role_calls; return t; }
+  return b ? b->stat_sam_role_calls : -1;
 }
 int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves) {
   if (!b) return fail("null batch");

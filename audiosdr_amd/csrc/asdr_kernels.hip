@@ -1117,6 +1117,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                                   store8(tap_base + (size_t)(id) * tap_stride + 64 * h_, tv_); } } } while (0)
 
     uint32_t status = S->status;
+    const uint32_t status_in = status;   // (a role's own bits as it found them: nobody else writes those)
     // Small operands first (memory waits count loads in order: what is requested first can be waited for alone): the carried
     // mixer phase of the modes whose mixer does not depend on this block's data, the frequency shift, the oscillator cache's key.
     const bool mix_early = is_ssb || (DO2 && is_am);   // (the pipeline's roles 1 and 3 run no mixer)
@@ -1609,7 +1610,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (DO1) { TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1); }
     // A role's own status bits go back with atomics: the three roles of a channel group update one word
     auto store_status_bits = [&](uint32_t mask) {
-      if (lead) { atomicAnd(&S->status, ~mask); atomicOr(&S->status, status & mask); }
+      if (lead && ((status ^ status_in) & mask) != 0u) { atomicAnd(&S->status, ~mask); atomicOr(&S->status, status & mask); }   // (only when a bit of its own changed)
     };
     if (ROLE == 1 || ROLE == 2) {   // streaming pipeline, boundary A: the IF output rows I (W0), Q (W1) cross through the exchange ring
       float *xa = a.xch_a + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH)) * (2 * ASDR_N) + kF;
@@ -1642,7 +1643,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const float *src = sam_lds + 16 * k;
         *reinterpret_cast<float4 *>(sam_tile + 4 * (lane_i + 64 * k)) = make_float4(src[0], src[STRIDE], src[2 * STRIDE], src[3 * STRIDE]);
       }
-      if (lead) S->status = status;
+      store_status_bits(ASDR_S_NB_DETECTED);   // (this role's bit only, atomically: the post role of the PREVIOUS block may be running beside it)
       continue;
     }
     // ---- SAM: quadrature PLL, AudioSDR.cpp:688-749 (sequential per channel) ---------------------------------
@@ -1693,7 +1694,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float *dst = sam_lds + 16 * k;
         dst[0] = pc[k].x; dst[STRIDE] = pc[k].y; dst[2 * STRIDE] = pc[k].z; dst[3 * STRIDE] = pc[k].w;
       }
-      if (is_sam) pll_locked = (status & ASDR_S_PLL_LOCKED) != 0u;
+      if (is_sam) pll_locked = a.sam_lock[wave_g * 8 + c8] != 0u;   // (as the PLL kernel left it for THIS block: see UpdateArgs.sam_lock)
       WAVE_SYNC();
     }
     // envelope detector runs for AM, and for SAM when the PLL is unlocked at the end of the block (:132)
@@ -2291,7 +2292,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #endif
       }
     }
-    if (!STREAM) { if (lead) S->status = status; }
+    if (ROLE == 5) store_status_bits(ASDR_S_AGC_ACTIVE);   // (the pre role and the PLL of the NEXT block may be running beside this one)
+    else if (!STREAM) { if (lead) S->status = status; }
     else { store_status_bits(ASDR_S_AGC_ACTIVE); sig_pending = (uint32_t)blk + 1u; }
     WAVE_SYNC();
     // The first wave of every settings group leaves the NEXT block's local-oscillator pairs in the group's entry of the other half (LoEntry).
@@ -2532,8 +2534,10 @@ extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs 
     [&](int i, const float *xr, const float *xi) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) { float *e = xt + (size_t)(i + u) * 16; e[0] = xr[u]; e[8] = xi[u]; } });
-  const uint32_t st = Sc->status;
-  Sc->status = (st & ~ASDR_S_PLL_LOCKED) | (lk ? ASDR_S_PLL_LOCKED : 0u);
+  a.sam_lock[s] = lk ? 1u : 0u;
+  if (((Sc->status & ASDR_S_PLL_LOCKED) != 0u) != lk) {   // (one bit of a word other roles update too; only this kernel writes this one)
+    if (lk) atomicOr(&Sc->status, ASDR_S_PLL_LOCKED); else atomicAnd(&Sc->status, ~ASDR_S_PLL_LOCKED);
+  }
 }
 
 // Streaming pipeline: workgroups [0, W) run role 1, [W, 2W) role 2, [2W, 3W) role 3 of the W channel groups (W = a.stream_waves; the oscillator role is workgroup 0's second wave),
@@ -2747,6 +2751,26 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   }
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// One role of the three-launch SAM form on its own stream (role 0 = pre, 1 = PLL, 2 = post): the host overlaps the roles of
+// consecutive blocks of a multi-block call (asdr_host.cpp, SAM role streams).
+extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int uniform, int role, hipStream_t stream) {
+  const int n_waves = a->n_sched / 8;
+  if (n_waves <= 0) return 0;
+  if (role == 0) {
+    if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  } else if (role == 1) {
+    hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
+  } else if (variant == ASDR_KERNEL_SAM_ALS) {
+    if (uniform) hipLaunchKernelGGL(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  } else {
+    if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

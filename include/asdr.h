@@ -135,6 +135,13 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
 int asdr_order_after(asdr_batch_t *b, void *stream);
 int asdr_order_before(asdr_batch_t *b, void *stream);
 long asdr_lane_calls(asdr_batch_t *b);
+/* SAM role streams: a multi-block call (n_blocks >= 2) of a batch whose schedule is ONE sub-range of SAM channels run as three launches
+ * per block (pre | PLL | post: 512 or more SAM channels configured alike) puts the three roles on three streams chained by events, so
+ * that pre(k + 1) and PLL(k + 1) run beside post(k): the PLL's 128-step dependent chain per block (about 32 us for any bank size) then
+ * bounds the call alone -- 61 -> about 35 us per block for 512 receivers.  Results are bit-identical (the roles of a block touch disjoint
+ * state; tiles and lock words alternate between two sets).  asdr_sam_role_calls() = calls that ran that way; environment
+ * ASDR_NO_SAM_ROLE_STREAMS=1 at asdr_create time switches it off.  (AudioSDR.cpp:688-749 is the chain.) */
+long asdr_sam_role_calls(asdr_batch_t *b);
 int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves);
 int asdr_synchronize(asdr_batch_t *b);
 

@@ -168,3 +168,38 @@ def test_lanes_on_a_mixed_schedule(gpu, ao):
         o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
         assert np.array_equal(wA[c], o.update(bI[c], bQ[c]).reshape(total, 128)), c
     hip.free_all(); A.close(); B.close()
+
+
+def test_host_rows_call_behind_running_lanes(gpu):
+    """asdr_update (host rows) right behind a long multi-block call that is still running on the lanes, with a setter in between:
+    the host path rewrites parameter rows (its flush) and must not start before EVERY lane is done -- found by the launch-form fuzz
+    (seed 144: the setter's channel, in the third lane, ran the rest of the running call with the filter the setter had just
+    enabled).  16,384 SAM channels x 40 blocks keep the lanes busy for a few milliseconds; the setters (output gain: visible in every
+    sample from the block in which the row changes) hit channels of every lane.  (A functional check of the sequence: without the join the
+    outcome depends on which lane stream lags -- the fuzz seed failed one run in three, this sequence did not fail in six.)"""
+    from audiosdr_amd.synth import make_iq
+    n, uniq, total = 16384, 64, 42
+    fc = 6890.0 + 25.0 * (np.arange(uniq) % 5)
+    bI, bQ = make_iq(uniq, total, fc=fc, A=0.3, m=0.4, noise=0.01)
+    I, Q = _tile(bI, n), _tile(bQ, n)
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    A, B = _twin(gpu, n, 5)
+    A.set_lanes(4)      # four lanes on the pool's three streams: one stream lags
+    dA, dB = hip.malloc(n * total * 256), hip.malloc(n * total * 256)
+    last = (np.ascontiguousarray(I[:, 41:42]), np.ascontiguousarray(Q[:, 41:42]))
+    out = []
+    for b, d, s in ((A, dA, gpu.STREAM_BATCH), (B, dB, 0)):
+        b.update_device_strided(dI, dQ, d, 1, total, total, s)                     # block 0 (flushes the settings)
+        b.update_device_strided(dI + 256, dQ + 256, d + 256, 40, total, total, s)  # blocks 1..40: A on its lanes, not waited for
+        for c in (5, n // 4 + 3, n // 2 + 11, 3 * n // 4 + 7, n - 1):
+            b.setOutputGain(0.25, ch=c)     # (a parameter-row change only: the flush is a few microseconds of host work, the lanes still run)
+        out.append(b.update(*last))         # host rows, block 41 -- at once
+    outA, outB = out
+    assert A.lane_calls() == 1
+    assert np.array_equal(outA, outB), "block 41: %d samples differ" % int((outA != outB).sum())
+    A.synchronize(); B.synchronize()
+    wA, wB = hip.download(dA, (n, total, 128), np.int16)[:, :41], hip.download(dB, (n, total, 128), np.int16)[:, :41]
+    bad = np.argwhere(wA != wB)
+    assert bad.size == 0, "%d samples differ, first at %s" % (len(bad), bad[0].tolist())
+    hip.free_all(); A.close(); B.close()

@@ -362,6 +362,52 @@ def test_block_pipeline_with_odd_channels_beside_it(gpu, ao, limit):
     hip.free_all(); batch.close()
 
 
+@pytest.mark.parametrize("als", [False, True])
+def test_sam_role_streams(gpu, ao, als):
+    """SAM role streams (include/asdr.h asdr_sam_role_calls): in a multi-block call of a bank of SAM channels configured alike
+    (>= 512: the three-launch form) the pre | PLL | post roles of consecutive blocks overlap on three streams.  What could go wrong is
+    exactly what the test drives: the lock flag changes from block to block (the carrier jumps between an offset the PLL holds and one
+    it cannot, at splice points that differ from channel to channel), so post(k) must see PLL(k)'s flag while PLL(k + 1) already runs;
+    the tiles alternate between two sets; the status word is updated by three roles.  Calls of 12, 1, 7, 2 and 9 blocks: role
+    streams and the ordinary one-call-one-block form hand the state to each other.  Every block of every channel, and the getters."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 512, (12, 1, 7, 2, 9)
+    total = sum(plan)
+    near = 6890.0 + (np.arange(n_ch) % 7 - 3) * 40.0
+    Ia, Qa = make_iq(n_ch, total, fc=near, A=0.3, m=0.5, fm=400.0, noise=0.005)
+    Ib, Qb = make_iq(n_ch, total, fc=near + 2500.0, A=0.25, m=0.3, fm=300.0, noise=0.005)   # 2.5 kHz off: no lock
+    I, Q = Ia.copy(), Qa.copy()
+    for c in range(n_ch):
+        for b in range(total):
+            if ((b + c % 5) // 3) % 3 == 2:       # every channel loses its carrier for three blocks out of nine, shifted by channel
+                I[c, b], Q[c, b] = Ib[c, b], Qb[c, b]
+    setters = [S("setDemodMode", 5), S("setNoiseBlankerThresholdDb", 10.0), S("enableAudioFilter"), S("setAudioFilter", 0)]
+    if als:
+        setters.append(S("enableALSfilter"))
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    hip = Hip()
+    pos, locks = 0, set()
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(n_ch):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call of %d blocks at %d, ch %d" % (T, pos, c)
+        st = batch.read_status()
+        for c in range(0, n_ch, 7):
+            assert int(st["sam_locked"][c]) == orcs[c].getSAMphaseLockStatus(), "lock flag after block %d, ch %d" % (pos + T - 1, c)
+            locks.add(int(st["sam_locked"][c]))
+        pos += T
+    assert locks == {0, 1}                                  # both lock states were seen at call boundaries
+    assert batch.sam_role_calls() == sum(1 for T in plan if T >= 2)
+    from helpers import compare_status
+    compare_status(gpu, batch, orcs)
+    hip.free_all(); batch.close()
+
+
 def test_in_place_calls_never_take_the_pipeline(gpu, ao):
     """The pipeline's recovery restores channel state, not caller buffers: a call whose output rows alias its I rows (the reference's
     own convention, AudioSDR.cpp:158-165: the audio is written into blockI) keeps the in-kernel block loop -- also with injected
