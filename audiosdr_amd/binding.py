@@ -158,6 +158,10 @@ def load_library(path=None):
         L.asdr_lane_calls.argtypes = [vp]; L.asdr_lane_calls.restype = C.c_long
         L.asdr_sam_role_calls.argtypes = [vp]; L.asdr_sam_role_calls.restype = C.c_long
         L.asdr_set_lanes.argtypes = [vp, _i, _i]; L.asdr_set_lanes.restype = _i
+    if path is None or hasattr(L, "asdr_lanes_overlap_probe"):   # round 5
+        L.asdr_lanes_overlap_probe.argtypes = [vp]; L.asdr_lanes_overlap_probe.restype = _i
+        L.asdr_lanes_enabled.argtypes = [vp]; L.asdr_lanes_enabled.restype = _i
+        L.asdr_stream_pipeline_headroom_refusals.argtypes = [vp]; L.asdr_stream_pipeline_headroom_refusals.restype = C.c_long
     if path is None:
         _lib = L
     return L
@@ -219,6 +223,16 @@ class AudioSDRBatch:
     def sam_role_calls(self):
         """Multi-block calls that ran the SAM roles on three chained streams (include/asdr.h)."""
         return int(self._L.asdr_sam_role_calls(self._h))
+
+    def lanes_overlap_probe(self):
+        """1 = the pool's streams run concurrently on this device, 0 = they share a hardware queue (lanes default off), -1 = not probed."""
+        return int(self._L.asdr_lanes_overlap_probe(self._h))
+
+    def lanes_enabled(self):
+        return bool(self._L.asdr_lanes_enabled(self._h))
+
+    def stream_pipeline_headroom_refusals(self):
+        return int(self._L.asdr_stream_pipeline_headroom_refusals(self._h))
 
     def set_lanes(self, on=True, min_waves=0):
         self._chk(self._L.asdr_set_lanes(self._h, 1 if on else 0, int(min_waves)))

@@ -40,6 +40,9 @@
 #ifndef ASDR_STREAM_MIN_BLOCKS
 #define ASDR_STREAM_MIN_BLOCKS 8
 #endif
+#ifndef ASDR_STREAM_SIDE_MARGIN
+#define ASDR_STREAM_SIDE_MARGIN 16   /* resident-workgroup slots kept free on top of the side sub-ranges' waves when a pipeline call carries any */
+#endif
 #ifndef ASDR_STREAM_SIDE_WAVES
 #define ASDR_STREAM_SIDE_WAVES 64   /* waves of other kernel kinds / remainders a pipeline call may carry beside it (on the in-kernel block loop) */
 #endif
@@ -256,6 +259,7 @@ struct asdr_batch {
   // owner (ASDR_ALL fans out), asdr_update scatters / gathers host rows with one host thread per shard, and there is no collective.
   std::vector<asdr_batch *> shards;
   std::vector<int> shard_first;
+  void *workers = nullptr;   // (ShardWorkers *) asdr_update on host rows: one persistent thread per shard >= 1 (the caller's thread takes shard 0), started at the first such call
   int16_t *d_capture = nullptr;  // capture sink [n][capture_cap][128]
   long capture_cap = 0, capture_pos = 0;
   size_t io_cap = 0;
@@ -287,6 +291,7 @@ struct asdr_batch {
   bool stream_pipeline = true;      // small multi-block calls may run as the block pipeline (asdr_stream_kernel)
   int stream_query_waves = 0;       // ... as the occupancy query of asdr_create answered (the debug hook cannot go beyond it)
   int stream_max_waves = 0;         // channel groups the pipeline may hold: 3 w + 1 workgroups must be co-resident, one per compute unit
+  int stream_cap_workgroups = 0;    // the occupancy query's answer itself (resident workgroups of the pipeline kernel on this device)
   uint32_t stream_spin_limit = ASDR_STREAM_SPIN_LIMIT;
   void *d_stream_snap = nullptr;    // snapshot of the state a pipeline call advances (asdr_kernels.hip "the pipeline as a transaction")
   long stat_stream_recoveries = 0;  // pipeline calls that gave up and were re-run on the in-kernel block loop (read back at synchronisation points)
@@ -303,6 +308,7 @@ struct asdr_batch {
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode or AM: the modes the block pipeline has roles for (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   long stat_stream_launches = 0;
+  long stat_stream_headroom_refusals = 0;   // pipeline calls sent to the other launch forms because pipeline + side sub-ranges would not be co-resident (asdr_stream_pipeline_headroom_refusals)
   long stat_stream_alloc_failures = 0;   // the pipeline's buffers could not be allocated: the batch opted itself out (asdr_stream_pipeline_alloc_failures)
   uint32_t lo_parity = 0;
   uint32_t nb_phase = 0;         // blocks processed so far, mod 3 (position of every channel's blanker ring)
@@ -313,6 +319,7 @@ struct asdr_batch {
 namespace {
 
 int sharded_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks);
+void shard_workers_stop(asdr_batch *b);
 inline bool is_sharded(const asdr_batch *b);
 
 uint64_t agc_hash(float thr, float slope, float knee) {
@@ -718,15 +725,52 @@ const Chan *get(asdr_batch *&b, int ch) {
 // a pool stream between batches only adds ordering nobody needs; it never breaks the ordering somebody does (a stream is in-order).
 constexpr int kPoolMax = 16;
 struct StreamPool { hipStream_t s[kPoolMax] = {}; int size = 0; std::mutex m; };
-StreamPool g_pool[16];
+StreamPool g_pool[16];   // [kPoolDevices]
+constexpr int kPoolDevices = 16;   // device ordinals 0 .. 15 (a node holds 8)
 hipStream_t pool_stream(int device, int i) {
-  if (device < 0 || device >= 16) return nullptr;
+  if (device < 0 || device >= kPoolDevices) return nullptr;
   StreamPool &p = g_pool[device];
   std::lock_guard<std::mutex> g(p.m);
   if (p.size == 0) { const char *e = getenv("ASDR_STREAM_POOL"); p.size = e ? std::max(1, std::min(atoi(e), kPoolMax)) : 3; }
   const int k = (i < 0) ? p.size - 1 : i % p.size;
   if (!p.s[k] && hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return p.s[k];
+}
+// Do two streams of the pool really run at the same time?  The lanes rest on it: HIP maps the streams of a process onto a
+// few hardware queues, and two streams that share a queue run one after the other -- then two never-joined halves gain nothing and a
+// batch does better on its caller's stream order.  Probed once per device and process, at the first asdr_create that wants lanes: a
+// 30-us spin kernel on each of the pool's first two streams; together they end after one duration (concurrent) or two (serialised).
+// 1 = concurrent, 0 = serialised (lanes default off for batches created from then on), -1 = not probed / the probe itself failed
+// (lanes stay at their default: an error here must not change behaviour).
+int g_lanes_probe[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+extern "C" int asdr_launch_spin(unsigned long long ticks, hipStream_t stream);
+int lanes_overlap_probe(int device) {
+  if (device < 0 || device >= kPoolDevices) return -1;
+  static std::mutex pm;
+  std::lock_guard<std::mutex> g(pm);
+  if (g_lanes_probe[device] >= 0) return g_lanes_probe[device];
+  if (getenv("ASDR_NO_LANES_PROBE")) return -1;
+  hipStream_t s0 = pool_stream(device, 0), s1 = pool_stream(device, 1);
+  if (!s0 || !s1 || s0 == s1) return -1;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool ok = true;
+  for (hipEvent_t &e : ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
+  const unsigned long long ticks = 3000;   // 30 us at 100 MHz
+  float both = 0.0f, one = 0.0f;
+  if (ok) {
+    // warm both streams (first launches pay code-object loading), then the measured pair
+    ok = asdr_launch_spin(10, s0) == 0 && asdr_launch_spin(10, s1) == 0 && hipStreamSynchronize(s0) == hipSuccess && hipStreamSynchronize(s1) == hipSuccess;
+    ok = ok && hipEventRecord(ev[0], s0) == hipSuccess && hipStreamWaitEvent(s1, ev[0], 0) == hipSuccess;   // both start behind the same marker
+    ok = ok && asdr_launch_spin(ticks, s0) == 0 && asdr_launch_spin(ticks, s1) == 0;
+    ok = ok && hipEventRecord(ev[1], s0) == hipSuccess && hipEventRecord(ev[2], s1) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s0) == hipSuccess && hipStreamSynchronize(s1) == hipSuccess;
+    ok = ok && hipEventElapsedTime(&one, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&both, ev[0], ev[2]) == hipSuccess;
+  }
+  for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+  if (!ok) { (void)hipGetLastError(); return -1; }
+  const float later = std::max(one, both);
+  g_lanes_probe[device] = (later < 1.6f * 0.030f + 0.02f) ? 1 : 0;   // one duration (+ launch latency) against two
+  return g_lanes_probe[device];
 }
 hipStream_t aux_stream(asdr_batch *b, int i) {
   if (!b->aux[i]) b->aux[i] = pool_stream(b->device, i + 1);   // (+ 1: a lane call's pieces and an ordinary call's helpers start on different pool streams)
@@ -812,6 +856,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete b; fail("no HIP device: libasdr_hip has no CPU path"); return nullptr; }
     if (device < 0 || device >= ndev) { delete b; fail("bad device ordinal"); return nullptr; }
+    if (device >= 16) { delete b; fail("device ordinal >= 16: the per-device stream pool of this library has 16 entries"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { delete b; fail("hipSetDevice failed"); return nullptr; }
     bool ok = true;
     auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
@@ -836,6 +881,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     for (int i = 0; i < ASDR_LANES + 1 && ok; i++)
       if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
+    if (b->lanes_enabled && lanes_overlap_probe(device) == 0) b->lanes_enabled = false;   // the pool's streams share a hardware queue here: caller-stream order is the faster form
     b->sam_role_streams = getenv("ASDR_NO_SAM_ROLE_STREAMS") == nullptr;
     if (ok && (b->stream = pool_stream(device, 0)) == nullptr) ok = false;   // the pool's first stream (= lane 0: a batch runs on the lanes or on its own stream, never both at once)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
@@ -857,6 +903,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
       // 8.4 at 256, 11.0 at 512 -- against 18.9-20.2 us for the in-kernel block loop at every one of those sizes.
       int cus = 0;
       const int cap = asdr_stream_capacity(device, &cus);
+      b->stream_cap_workgroups = cap > 0 ? cap : 0;
       b->stream_max_waves = cap >= 3 ? cap / 3 : 0;
       if (b->stream_max_waves > ASDR_STREAM_MAX_WAVES) b->stream_max_waves = ASDR_STREAM_MAX_WAVES;
       b->stream_query_waves = b->stream_max_waves;
@@ -934,7 +981,7 @@ int asdr_shard_device(const asdr_batch_t *b, int shard) {
 
 void asdr_destroy(asdr_batch_t *b) {
   if (!b) return;
-  if (is_sharded(b) || !b->shard_first.empty()) { for (asdr_batch *sh : b->shards) asdr_destroy(sh); delete b; return; }
+  if (is_sharded(b) || !b->shard_first.empty()) { shard_workers_stop(b); for (asdr_batch *sh : b->shards) asdr_destroy(sh); delete b; return; }
   if (b->device == ASDR_NO_DEVICE) { delete b; return; }
   hipSetDevice(b->device);
   hipDeviceSynchronize();
@@ -1089,6 +1136,12 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
                        !b->taps_on &&
 #endif
                        subs[pipe_sub].slots / 8 <= b->stream_max_waves;
+  // All 3 w pipeline workgroups must be RESIDENT together (the roles wait for each other).  The sub-ranges beside the pipeline are
+  // long-running kernels on helper streams started at the same fork: every one of their waves may hold a slot a role-3 workgroup needs
+  // (then roles 1 and 2 spin out their polls and the call is re-run from the snapshot: exact, but several times slower).  With side
+  // waves the pipeline therefore keeps headroom for them plus a margin; alone it may fill the device.
+  if (take_pipeline && other_waves > 0 && b->stream_cap_workgroups > 0 &&
+      3 * (subs[pipe_sub].slots / 8) + other_waves + ASDR_STREAM_SIDE_MARGIN > b->stream_cap_workgroups) { take_pipeline = false; b->stat_stream_headroom_refusals++; }
   if (take_pipeline) {
     if (!b->d_xch_a) {   // first use: every buffer, or none (a failed allocation leaves the batch on the other launch forms)
       float *xa = nullptr, *xb = nullptr; uint32_t *prog = nullptr; LoEntry *ring = nullptr; void *snap = nullptr;
@@ -1404,11 +1457,18 @@ int asdr_capture_read(asdr_batch_t *b, int ch, long first_block, long n_blocks, 
 // as they are; pageable buffers go through the batch's pinned staging area, copied by a few worker threads per chunk.
 namespace {
 
-bool is_pinned_host(const void *p) {   // registered / hipHostMalloc'ed memory the DMA engines can address as it is
-  hipPointerAttribute_t at;
-  memset(&at, 0, sizeof at);
-  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // ordinary pageable memory is an error here
-  return at.type == hipMemoryTypeHost;
+// registered / hipHostMalloc'ed memory the DMA engines can address as it is -- the WHOLE range [p, p + bytes): its first and its last
+// byte are both page-locked host memory (a buffer registered for less than the call's rows, or a view that runs past a pinned region,
+// goes through the staging area like pageable memory)
+bool is_pinned_host(const void *p, size_t bytes) {
+  auto pinned_at = [](const void *q) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // ordinary pageable memory is an error here
+    return at.type == hipMemoryTypeHost;
+  };
+  if (!pinned_at(p)) return false;
+  return bytes <= 1 || pinned_at(static_cast<const char *>(p) + bytes - 1);
 }
 
 int host_parts(const asdr_batch *b, int n_blocks) {
@@ -1453,20 +1513,23 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
   const size_t count = (size_t)b->n * n_blocks * ASDR_N;
   if (count > b->io_cap) {
     HIPCHK(hipStreamSynchronize(b->stream));
+    b->io_cap = 0;   // (a failure part-way leaves "no buffers", never pointers that disagree with the recorded capacity)
     for (int i = 0; i < 3; i++) {
       if (b->d_io[i]) HIPCHK(hipFree(b->d_io[i]));
       b->d_io[i] = nullptr;
-      HIPCHK(hipMalloc(&b->d_io[i], count * sizeof(int16_t)));
     }
+    for (int i = 0; i < 3; i++) HIPCHK(hipMalloc(&b->d_io[i], count * sizeof(int16_t)));
     b->io_cap = count;
   }
-  const bool pinned = is_pinned_host(I) && is_pinned_host(Q) && is_pinned_host(out);
+  const size_t row_bytes_all = count * sizeof(int16_t);
+  const bool pinned = is_pinned_host(I, row_bytes_all) && is_pinned_host(Q, row_bytes_all) && is_pinned_host(out, row_bytes_all);
   if (!pinned && count > b->h_io_cap) {   // the pinned staging area, one row set per call
+    b->h_io_cap = 0;
     for (int i = 0; i < 3; i++) {
       if (b->h_io[i]) HIPCHK(hipHostFree(b->h_io[i]));
       b->h_io[i] = nullptr;
-      HIPCHK(hipHostMalloc((void **)&b->h_io[i], count * sizeof(int16_t), hipHostMallocPortable));
     }
+    for (int i = 0; i < 3; i++) HIPCHK(hipHostMalloc((void **)&b->h_io[i], count * sizeof(int16_t), hipHostMallocPortable));
     b->h_io_cap = count;
   }
   if (!b->h2d_stream) {   // kernels on the pool's first stream (b->stream), copies in on its second, out on its third
@@ -1563,24 +1626,67 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
 // asdr_update on a sharded batch: shard g's rows [shard_first[g], shard_first[g + 1]) of I, Q and out go through shard g's own
 // overlapped host path on its own device, one host thread per shard (the caller's thread takes shard 0); no collective, nothing
 // crosses between devices.  Errors of the worker threads come back as the call's error text.
+// The shard threads are PERSISTENT (round 5; round 4 created and joined G - 1 threads in every call): started at the first host-row call
+// of the sharded batch, parked on a condition variable between calls, stopped by asdr_destroy.  The caller's thread runs shard 0 and
+// gets its current device back before the call returns (asdr_update on a shard sets the shard's device).
+struct ShardWorkers {
+  struct Job { const int16_t *I = nullptr, *Q = nullptr; int16_t *out = nullptr; int n_blocks = 0; };
+  asdr_batch *parent = nullptr;
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  Job job;
+  unsigned long gen = 0;          // a call publishes its job under a new generation
+  size_t pending = 0;             // workers that have not finished the current generation
+  bool stop = false;
+  std::vector<int> rc;
+  std::vector<std::string> err;
+  static void run_shard(asdr_batch *parent, size_t g, const Job &j, int &rc, std::string &err) {
+    const size_t o = (size_t)parent->shard_first[g] * (size_t)j.n_blocks * ASDR_N;
+    rc = asdr_update(parent->shards[g], j.I + o, j.Q + o, j.out + o, j.n_blocks);
+    if (rc != 0) err = g_err;     // (thread-local: copied out for the caller's thread)
+  }
+  void loop(size_t g) {
+    unsigned long seen = 0;
+    for (;;) {
+      Job j;
+      { std::unique_lock<std::mutex> lk(m);
+        cv_go.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen; j = job; }
+      int r = 0; std::string e;
+      run_shard(parent, g, j, r, e);
+      { std::lock_guard<std::mutex> lk(m); rc[g] = r; err[g] = e; if (--pending == 0) cv_done.notify_all(); }
+    }
+  }
+  explicit ShardWorkers(asdr_batch *p) : parent(p), rc(p->shards.size(), 0), err(p->shards.size()) {
+    for (size_t g = 1; g < p->shards.size(); g++) th.emplace_back([this, g] { loop(g); });
+  }
+  ~ShardWorkers() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv_go.notify_all();
+    for (std::thread &t : th) t.join();
+  }
+};
+void shard_workers_stop(asdr_batch *b) { delete static_cast<ShardWorkers *>(b->workers); b->workers = nullptr; }
+
 int sharded_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out, int n_blocks) {
   if (!I || !Q) return 0;   // missing-input guard, AudioSDR.cpp:48-56
   if (!out) return fail("null output");
   if (n_blocks <= 0) return 0;
   const size_t G = b->shards.size();
-  const size_t row = (size_t)n_blocks * ASDR_N;
-  std::vector<int> rc(G, 0);
-  std::vector<std::string> err(G);
-  auto run = [&](size_t g) {
-    const size_t o = (size_t)b->shard_first[g] * row;
-    rc[g] = asdr_update(b->shards[g], I + o, Q + o, out + o, n_blocks);
-    if (rc[g] != 0) err[g] = g_err;   // (thread-local: copied out for the caller's thread)
-  };
-  std::vector<std::thread> th;
-  for (size_t g = 1; g < G; g++) th.emplace_back(run, g);
-  run(0);
-  for (std::thread &t : th) t.join();
-  for (size_t g = 0; g < G; g++) if (rc[g] != 0) return fail("shard " + std::to_string(g) + ": " + err[g]);
+  if (!b->workers) b->workers = new ShardWorkers(b);
+  ShardWorkers &w = *static_cast<ShardWorkers *>(b->workers);
+  int dev0 = -1;
+  const bool have_dev = hipGetDevice(&dev0) == hipSuccess;   // the caller's current device: shard 0's call below changes it
+  if (!have_dev) (void)hipGetLastError();
+  ShardWorkers::Job j; j.I = I; j.Q = Q; j.out = out; j.n_blocks = n_blocks;
+  { std::lock_guard<std::mutex> lk(w.m); w.job = j; w.pending = G - 1; w.gen++; }
+  w.cv_go.notify_all();
+  ShardWorkers::run_shard(b, 0, j, w.rc[0], w.err[0]);
+  { std::unique_lock<std::mutex> lk(w.m); w.cv_done.wait(lk, [&] { return w.pending == 0; }); }
+  if (have_dev) (void)hipSetDevice(dev0);
+  for (size_t g = 0; g < G; g++) if (w.rc[g] != 0) return fail("shard " + std::to_string(g) + ": " + w.err[g]);
   return 0;
 }
 
@@ -1641,6 +1747,16 @@ int asdr_order_after(asdr_batch_t *b, void *stream_) {   // the batch's calls on
 long asdr_lane_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_lane_calls; return t; }
   return b ? b->stat_lane_calls : -1;
+}
+int asdr_lanes_overlap_probe(asdr_batch_t *b) {   // what the create-time probe of the batch's device found (see lanes_overlap_probe)
+  if (!b) return -1;
+  if (is_sharded(b)) { int r = 1; for (asdr_batch *sh : b->shards) { const int v = asdr_lanes_overlap_probe(sh); if (v < r) r = v; } return r; }
+  return (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe[b->device] : -1;
+}
+int asdr_lanes_enabled(asdr_batch_t *b) {
+  if (!b) return -1;
+  if (is_sharded(b)) { for (asdr_batch *sh : b->shards) if (!sh->lanes_enabled) return 0; return 1; }
+  return b->lanes_enabled ? 1 : 0;
 }
 long asdr_sam_role_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_sam_role_calls; return t; }
@@ -2004,6 +2120,10 @@ long asdr_stream_pipeline_recoveries(asdr_batch_t *b) {
 long asdr_stream_pipeline_alloc_failures(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_stream_alloc_failures; return t; }
   return b ? b->stat_stream_alloc_failures : -1;
+}
+long asdr_stream_pipeline_headroom_refusals(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_stream_headroom_refusals; return t; }
+  return b ? b->stat_stream_headroom_refusals : -1;
 }
 int asdr_stream_pipeline_max_groups(asdr_batch_t *b) {   // (per shard: every shard is a launch of its own)
   if (is_sharded(b)) { int m = 0x7fffffff; for (asdr_batch *sh : b->shards) m = std::min(m, sh->stream_max_waves); return m; }

@@ -19,7 +19,9 @@
 // in binary64 here too, so the int16 output is bit-identical to the CPU restatement.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <string.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "asdr_device.h"
@@ -41,6 +43,24 @@
 // apart, they do: 2-way).  One process per build: C4 -2.3 %, all-USB + ALS -2.2 %; the plain kinds lose 1.5 % at 392 and keep 388.
 #ifndef ASDR_AGC_QUIET_PATH
 #define ASDR_AGC_QUIET_PATH 1   /* 0: every block through the chunk loop (measurements) */
+#endif
+#ifndef ASDR_ONEBLK
+#define ASDR_ONEBLK 1   /* one-block launches of the plain / short-ALS uniform kernels take their loop-free twins (asdr_launch_update); 0: the looped kernels (measurements) */
+#endif
+#ifndef ASDR_MW
+#define ASDR_MW 1         /* large one-block direct launches of the plain kernel take the four-wave workgroup form (asdr_update_kernel_mw); 0: one wave per workgroup */
+#endif
+#ifndef ASDR_MW_SHARE
+#define ASDR_MW_SHARE 7   /* what the four waves of an MW workgroup share: 1 audio cascades (2 waves x 16 channels), 2 blanker / phase chains, 4 AGC chain (1 wave x 32 channels) */
+#endif
+#ifndef ASDR_PF_WAVES
+#define ASDR_PF_WAVES 0   /* default distance of the row-warming touches (UpdateArgs.pf_waves), in waves; 0 = off.  Environment ASDR_PF_WAVES overrides */
+#endif
+#ifndef ASDR_MW_MIN_WAVES
+#define ASDR_MW_MIN_WAVES 64
+#endif
+#ifndef ASDR_ONEBLK_ROLES
+#define ASDR_ONEBLK_ROLES 1   /* the SAM pre / post and the two-launch ALS pre roles (always one block per launch) compiled without the block loop */
 #endif
 #ifndef ASDR_ALS_WINDOW
 #define ASDR_ALS_WINDOW 1   /* the default-length ALS filter reads its operands once per FOUR tap sets (sliding windows in registers); 0: per tap set */
@@ -275,6 +295,9 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 #ifndef ASDR_PIPE_PK_MASK
 #define ASDR_PIPE_PK_MASK 0   /* which kernel kinds run the pipelines' y-independent products packed (see PIPE_PK in the body) */
 #endif
+#ifndef ASDR_PIPE_PREFETCH_FENCE
+#define ASDR_PIPE_PREFETCH_FENCE 1
+#endif
 #ifndef ASDR_PIPE_CHUNK
 #define ASDR_PIPE_CHUNK 8   /* samples per lane per pipeline step: 4 (35 steps) or 8 (19 steps, less per-step overhead) */
 #endif
@@ -321,6 +344,12 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
 #pragma unroll
       for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[nc * (C / 4) + q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
     }
+#if ASDR_PIPE_PREFETCH_FENCE
+    // Round 5: the two LDS reads stay HERE, at the top of the step.  Left alone the scheduler sinks them to the step's last dozen
+    // instructions (their eight result registers are not needed before the next step), and the `s_waitcnt lgkmcnt(0)` at the top of the
+    // next step then sits out most of an LDS round trip -- once per step, 38 steps per block.
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #if ASDR_PIPE_CHUNK == 8
     if constexpr (PK) {
     // Packed form (same separately rounded operations): samples j and j + 4 share a register pair, so that x[j-1] and x[j-2] of
@@ -1003,7 +1032,11 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
       }
     }
 }
-template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0>
+// ONEBLK (round 5): the launch processes ONE block per channel (a.n_blocks == 1: every large batch -- the host issues a multi-block
+// call of a large schedule block by block -- and always the SAM / two-launch ALS roles).  The block loop below is then no loop at all:
+// nothing is loop-invariant, so nothing is hoisted in front of the body and kept in registers across all of it (lane masks, cache-entry
+// addresses, flag words: the plain kernel's 66 SGPR spills and 8 of its VGPRs were exactly that).
+template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0, bool ONEBLK_ = false>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds_wg) {
   // ROLE 4 / 5: the SAM sub-range as three launches -- 4 = everything in front of the PLL (scale, blanker, IF filter), then the
   // stand-alone PLL kernel (asdr_sam_pll_kernel: one LANE per channel, 64 channels per wave -- the PLL is a 128-step dependent chain
@@ -1025,7 +1058,20 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   constexpr bool PIPE_PK = ((ASDR_PIPE_PK_MASK & 1) && HAS_ALS) || ((ASDR_PIPE_PK_MASK & 2) && !HAS_ALS && !HAS_SAM && ROLE == 0) ||
                            ((ASDR_PIPE_PK_MASK & 4) && (HAS_SAM || ROLE > 3)) || ((ASDR_PIPE_PK_MASK & 8) && STREAM);
   if (ROLE == 0 && a.run_if != nullptr && *a.run_if == 0u) return;   // the pipeline's fallback launch: nothing to do unless the pipeline gave up
+  // MW (round 5): the plain chain in workgroups of FOUR waves = 32 channels that stop wasting lanes on the phases that use a fraction of
+  // a wave: the audio cascade (4 lanes per channel: 32 of 64 busy in a wave of its own) runs for 16 channels per wave on TWO of the
+  // four waves, the blanker's running average + mixer phase recurrences and the AGC's envelope recurrence (one lane per channel:
+  // 8 of 64) run for all 32 channels on ONE wave each, between two workgroup barriers -- what the multi-wave SAM instantiation does
+  // for the PLL.  The duties rotate with the workgroup index (rel: 0 = blanker / phase chains, 1 and 2 = audio cascades, 3 = AGC
+  // chain), so that every SIMD gets every duty.  Direct launches of one settings group only (mode, flags and tables are launch-uniform
+  // scalars: every barrier below is reached by all four waves or by none); padding waves of the last workgroup run the dummy channel.
+  constexpr bool MW = (WAVES > 1) && !HAS_SAM && (ROLE == 0);
+  constexpr int MW_SHARE = MW ? ASDR_MW_SHARE : 0;   // bit 0: audio cascades, bit 1: blanker / phase chains, bit 2: AGC chain (measurements: any subset)
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
+  const int mw_rel = MW ? ((wave - (int)blockIdx.x) & (WAVES - 1)) : 0;
+  float *const mwx = lds_wg + WAVES * 8 * STRIDE;   // MW: [8 * WAVES][8] floats of hand-off scratch behind the rows
+  // schedule slot / channel index of the workgroup's channel q (0 .. 8 * WAVES - 1), for the lanes that work on other waves' channels
+  auto mw_channel = [&](int q) -> int { const int sidx = (int)blockIdx.x * (8 * WAVES) + q; return (sidx < a.n_sched) ? a.direct_ch0 + sidx : a.n_channels; };
   // this wave's index in the launched schedule sub-range (the streaming pipeline launches its three roles one after the other)
   const int wave_g = STREAM ? (int)blockIdx.x % a.stream_waves : (int)blockIdx.x * WAVES + wave;
   float *const lds = lds_wg + wave * 8 * STRIDE;            // this wave's 8 channel rows
@@ -1034,11 +1080,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
 
   int4 slot = make_int4(a.n_channels, 0, 0, 0);
-  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, (int)((a.direct_lo & 0xFFu) | (wave_g == 0 ? a.lo_writer_bit : 0u)));
+  const bool mw_pad = MW && (wave_g * 8 >= a.n_sched);   // a wave behind the sub-range's last one: works on the dummy channel, stores nothing outside it
+  if (UNIFORM && a.direct_ch0 >= 0) slot = make_int4(mw_pad ? a.n_channels : a.direct_ch0 + wave_g * 8 + c8, (int)a.direct_mode, (int)a.direct_flags, (int)((a.direct_lo & 0xFFu) | (wave_g == 0 ? a.lo_writer_bit : 0u)));
   else if (WAVES == 1 || wave_g * 8 < a.n_sched) slot = *reinterpret_cast<const int4 *>(a.sched + wave_g * 8 + c8);   // {channel, mode, flags, -}
   else { const ChanParams *pd = a.params + a.n_channels; slot.y = (int)pd->mode; slot.z = (int)pd->flags; }   // padding wave of a multi-wave workgroup: dummy channel
   const int ch_ = slot.x;
-  const bool valid = UNIFORM || (ch_ < a.n_channels);
+  const bool valid = (UNIFORM && !mw_pad) || (ch_ < a.n_channels);
   const int loff_ = c8 * STRIDE;
 #define P (*Pp)
   const ChainConsts K = a.k;
@@ -1065,8 +1112,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   uint32_t carry_hs = 0u;
   uint32_t *const my_prog = STREAM ? a.stream_prog + (ROLE - 1) * a.stream_waves + wave_g : nullptr;
 
+  // (Not the ALS instantiations: their loop-free builds fail the ALS parity tests from the first block after a schedule change -- ALS tap
+  // 1 % off with every earlier tap exact -- for a reason not found yet; they keep the loop.  profiles/README.md, round 5.)
+  constexpr bool ONEBLK = !HAS_ALS && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
 #pragma unroll 1
-  for (int blk = 0; blk < a.n_blocks; ++blk) {
+  for (int blk = 0; blk < (ONEBLK ? 1 : a.n_blocks); ++blk) {
     // Per-iteration opaque copies of the lane coordinates: stops LICM from hoisting every per-lane address
     // of the (long) block body out of this loop, which would pin >100 VGPRs.
     int s8 = s8_; asm volatile("" : "+v"(s8));
@@ -1291,37 +1341,40 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // sequential, one lane per channel: the running average (:633-634), which does not depend on the detections:
       // avg = alpha*avg + beta*mag; avg[t] (the average BEFORE sample t) replaces beta*mag[t] in place.  The mixer's phase
       // recurrence (AudioSDR.h:513-518) is an independent dependent chain and rides in the same loop.
-      if (lead) {
-        float avg = nb_avg0, phase = mphase;
+      // The two recurrences of one channel on ONE lane (`Lc` = the channel's rows, avg0 / phase0 / inc = its carried average, mixer phase
+      // and increment, Sc = its state row, chain_phase = the phase sequence is wanted (wave-uniform: a lane that does not need it computes
+      // and drops it), en = the blanker is on).  Returns the phase after the block.
+      auto nb_chain = [&](float *Lc, ChanSmall *Sc, float avg0, float phase0, float inc, bool chain_phase, bool want_phase, bool en, bool ssb) -> float {
+        float avg = avg0, phase = phase0;
         // `if (t > twoPI) t -= twoPI; else if (t < 0) t += twoPI;` (.h:514-517) with one test per sample: the phase stays in
         // [0, twoPI], so for inc >= 0 only the first branch can fire and for inc < 0 only the second.  The test is written as
         // (t with its sign flipped for inc < 0) > (twoPI or 0), and t - twoPI == t + (-twoPI) exactly.
-        const bool up = !(minc < 0.0f);
+        const bool up = !(inc < 0.0f);
         const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
         const uint32_t flip = up ? 0u : 0x80000000u;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const float bmu = L[NB_B + u]; L[NB_B + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
+        for (int u = 0; u < 2; ++u) { const float bmu = Lc[NB_B + u]; Lc[NB_B + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
         float bm[8];
-        load8(L + NB_B + 2, bm);
+        load8(Lc + NB_B + 2, bm);
         int c_tail = 0;   // first chunk of the average-only loop below
-        if (!lo_hit && (DO2 || !UNIFORM)) {
+        if (chain_phase) {
         c_tail = 16;
         // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
         // wrap `t < 0 ? t + twoPI : t` is a sign-mask select (v_ashrrev + v_bfi, no compare -> VCC -> select hazard): the phase
         // chain is add, shift, select.  (t = -0.0 cannot occur: the phase is never -0.0 and x + y = -0.0 needs both -0.0.)
-        if (!(HAS_ALS && !ALS_FULL_OPT2) && __all(minc < 0.0f)) {   // (the ALS instantiations take the compact loop below: this one costs them spills)
+        if (!(HAS_ALS && !ALS_FULL_OPT2) && __all(inc < 0.0f)) {   // (the ALS instantiations take the compact loop below: this one costs them spills)
 #pragma unroll 1
           for (int c = 0; c < 16; c += 2) {
             float av[8], bn[8], pv[8];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
               float *cur = half ? bn : bm, *nxt = half ? bm : bn;   // ping-pong: no register copies
-              load8(L + NB_B + 2 + 8 * (c + half + 1), nxt);      // next chunk, a step ahead
+              load8(Lc + NB_B + 2 + 8 * (c + half + 1), nxt);      // next chunk, a step ahead
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
                 av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u];
                 pv[u] = phase;
-                const float t = phase + minc, tw = t + two_pi;
+                const float t = phase + inc, tw = t + two_pi;
                 const uint32_t tb = __float_as_uint(t), m = (uint32_t)((int32_t)tb >> 31);
 #ifdef ASDR_PHASE_SELECT_C
                 phase = __uint_as_float((__float_as_uint(tw) & m) | (tb & ~m));
@@ -1330,44 +1383,68 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                 asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(phase) : "v"(m), "v"(tw), "v"(t));
 #endif
               }
-              store8(L + PH + 8 * (c + half), pv);
-              store8(L + NB_B + 2 + 8 * (c + half), av);
+              store8(Lc + PH + 8 * (c + half), pv);
+              store8(Lc + NB_B + 2 + 8 * (c + half), av);
             }
           }
         } else {
 #pragma unroll 1
           for (int c = 0; c < 16; ++c) {
             float av[8], bn[8], pv[8];
-            load8(L + NB_B + 2 + 8 * (c + 1), bn);
+            load8(Lc + NB_B + 2 + 8 * (c + 1), bn);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u];
               pv[u] = phase;
-              const float t = phase + minc, tw = t + wrapv;
+              const float t = phase + inc, tw = t + wrapv;
               phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
             }
-            store8(L + PH + 8 * c, pv);
-            store8(L + NB_B + 2 + 8 * c, av);
+            store8(Lc + PH + 8 * c, pv);
+            store8(Lc + NB_B + 2 + 8 * c, av);
 #pragma unroll
             for (int u = 0; u < 8; ++u) bm[u] = bn[u];
           }
         }
-        }   // !lo_hit
+        }   // chain_phase
 #pragma unroll 1
         for (int c = c_tail; c < 22; c += 2) {   // c_tail is even; two chunks per trip, ping-pong like above
           float av[8], bn[8];
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             float *cur = half ? bn : bm, *nxt = half ? bm : bn;
-            load8(L + NB_B + 2 + 8 * ((c + half < 21) ? c + half + 1 : 21), nxt);
+            load8(Lc + NB_B + 2 + 8 * ((c + half < 21) ? c + half + 1 : 21), nxt);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; }
-            store8(L + NB_B + 2 + 8 * (c + half), av);
+            store8(Lc + NB_B + 2 + 8 * (c + half), av);
           }
         }
-        if (nb_en) S->nb_avg = avg;
-        if (mix_early && !lo_hit && c_tail != 0) { if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase; }
-        mphase_end = phase;
+        if (en) Sc->nb_avg = avg;
+        if (want_phase && c_tail != 0) {
+          // (the word's offset is formed HERE: hoisted in front of the block loop as a 64-bit select it costs the multi-wave SAM instantiation a spill)
+          uint32_t off = (uint32_t)offsetof(ChanSmall, phase_am);
+          asm volatile("" : "+v"(off));
+          if (ssb) off = (uint32_t)offsetof(ChanSmall, phase_ssb);
+          *reinterpret_cast<float *>(reinterpret_cast<char *>(Sc) + off) = phase;
+        }
+        return phase;
+      };
+      const bool chain_phase_own = !lo_hit && (DO2 || !UNIFORM);
+      if constexpr ((MW_SHARE & 2) != 0) {
+        // every channel's lead lane publishes its chain inputs; the duty wave (rel 0) runs the chains of all 8 * WAVES channels, one per lane
+        if (lead) *reinterpret_cast<float4 *>(mwx + 8 * (wave * 8 + c8)) = make_float4(nb_avg0, mphase, minc, __int_as_float((chain_phase_own ? 1 : 0) | ((mix_early && !lo_hit) ? 2 : 0)));
+        __syncthreads();
+        if (mw_rel == 0 && lane_i < 8 * WAVES) {
+          const int q = lane_i;
+          const float4 in4 = *reinterpret_cast<const float4 *>(mwx + 8 * q);
+          const int fl = __float_as_int(in4.w);
+          const bool any_phase = __any((fl & 1) != 0);
+          const float pe = nb_chain(lds_wg + q * STRIDE, row_ptr(a.small, (uint32_t)mw_channel(q) * (uint32_t)sizeof(ChanSmall)), in4.x, in4.y, in4.z, any_phase, (fl & 2) != 0, nb_en, is_ssb);
+          mwx[8 * q + 4] = pe;
+        }
+        __syncthreads();
+        if (lead) mphase_end = mwx[8 * (wave * 8 + c8) + 4];
+      } else {
+        if (lead) mphase_end = nb_chain(L, S, nb_avg0, mphase, minc, chain_phase_own, mix_early && !lo_hit, nb_en, is_ssb);
       }
       ph_ready = mix_early && !lo_hit;
       WAVE_SYNC();
@@ -1800,11 +1877,25 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float agc_gain_in = 0.f, agc_old0 = 0.f, agc_carrier0 = 0.f;
     uint32_t agc_hc0 = 0u;
     int agc_tab_idx = 0;
+    // MW: the two audio-duty waves (rel 1, 2) run the cascades of 16 channels each, lane = (channel of the half) x 4 + stage
+    const bool mw_audio_duty = (MW_SHARE & 1) && (mw_rel == 1 || mw_rel == 2);
+    ChanSmall *mw_af_S = S;
     if (ABL_ON(ABL_AF) && af_en) {
+      if constexpr ((MW_SHARE & 1) != 0) {
+        if (mw_audio_duty) {
+          const int chq = mw_channel(16 * (mw_rel - 1) + (lane_i >> 2));
+          mw_af_S = row_ptr(a.small, (uint32_t)chq * (uint32_t)sizeof(ChanSmall));
+          af_s4 = *reinterpret_cast<const float4 *>(&mw_af_S->af_state[4 * (lane_i & 3)]);
+          const float *cf = &c_bq_pool[row_ptr(a.params, (uint32_t)chq * (uint32_t)sizeof(ChanParams))->audio_table][5 * (lane_i & 3)];
+#pragma unroll
+          for (int z = 0; z < 5; ++z) af_cf[z] = cf[z];
+        }
+      } else {
       af_s4 = *reinterpret_cast<const float4 *>(&S->af_state[4 * (s8 & 3)]);
       const float *cf = &c_bq_pool[P.audio_table][5 * (s8 & 3)];
 #pragma unroll
       for (int z = 0; z < 5; ++z) af_cf[z] = cf[z];
+      }
     }
     if (ABL_ON(ABL_AGC) && agc_en) {
       agc_gain_in = S->agc_gain; agc_old0 = S->agc_old_abs; agc_hc0 = S->agc_hang_counter; agc_carrier0 = S->am_carrier;
@@ -1996,6 +2087,34 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
 
+    // Round 5: WARM THE ROWS OF A LATER WAVE (UpdateArgs.pf_waves).  The waves of a launch start in rounds (3,072 resident at a time), every
+    // wave of a round asks for its ~25 KB of rows at once, and a wave's first instructions wait out that burst (the prologue: 10 % of a
+    // wave's lifetime inside the full launch, 2 % alone).  Here -- the FIR is done, the wave computes for another third of its life and
+    // asks nothing of memory -- every lane touches one 128-byte line of the rows wave (this + pf_waves) will load: they are fetched
+    // while the memory system is idle and wait in L2 / the Infinity Cache.  Five loads per lane, results never used (waited for at
+    // the end of the block); the input rows of the NEXT call cannot be known, the state rows can.
+    uint32_t pf_v[5] = {0u, 0u, 0u, 0u, 0u};
+    bool pf_on = false;
+    if constexpr (ONEBLK && ROLE == 0 && UNIFORM && !HAS_ALS && !HAS_SAM) {   // (the loop-free plain kernels: the launches that carry big batches)
+      const int wp = wave_g + a.pf_waves;
+      pf_on = a.pf_waves > 0 && a.direct_ch0 >= 0 && wp * 8 < a.n_sched;
+      if (pf_on) {
+        const uint32_t chp = (uint32_t)(a.direct_ch0 + wp * 8 + c8);
+        const uint32_t s8u = (uint32_t)s8;
+        const char *p0 = reinterpret_cast<const char *>(a.nb_hist) + (size_t)chp * 1536u + ((s8u < 4u) ? ns : ns_mid) * 512u + (s8u & 3u) * 128u;   // the blanker ring's oldest and middle slots (same launch: same ring position)
+        const char *p1 = reinterpret_cast<const char *>(a.hil_q) + (size_t)chp * 1024u + s8u * 128u;
+        const char *p2 = reinterpret_cast<const char *>(a.hil_i) + (size_t)chp * 1024u + s8u * 128u;
+        const char *p3 = (s8u < 5u) ? reinterpret_cast<const char *>(a.small) + (size_t)chp * 448u + ((s8u * 128u < 444u) ? s8u * 128u : 444u)
+                       : (s8u < 7u) ? reinterpret_cast<const char *>(a.params) + (size_t)chp * 96u + (s8u - 5u) * 92u
+                                    : reinterpret_cast<const char *>(a.nb_mask) + (size_t)chp * ASDR_NB_MASK_ROW;
+        const size_t iop = ((size_t)chp * a.in_stride + blk) * (ASDR_N * 2);
+        const char *p4 = (s8u < 2u) ? reinterpret_cast<const char *>(a.in_i) + iop + s8u * 128u
+                       : (s8u < 4u) ? reinterpret_cast<const char *>(a.in_q) + iop + (s8u - 2u) * 128u
+                                    : reinterpret_cast<const char *>(a.nb_mask) + (size_t)chp * ASDR_NB_MASK_ROW + 128u;
+        pf_v[0] = *reinterpret_cast<const uint32_t *>(p0); pf_v[1] = *reinterpret_cast<const uint32_t *>(p1); pf_v[2] = *reinterpret_cast<const uint32_t *>(p2);
+        pf_v[3] = *reinterpret_cast<const uint32_t *>(p3); pf_v[4] = *reinterpret_cast<const uint32_t *>(p4);
+      }
+    }
     // the AGC gain table (row of 132 floats) is requested before the audio-filter pipeline and staged in LDS after it
     float4 agc_t4[5];
 #pragma unroll
@@ -2010,6 +2129,19 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) agc_t4[r] = reinterpret_cast<const float4 *>(gtab)[q]; }
     }
     // ---- audio IIR filter, AudioSDR.cpp:149, 280-286: lanes s8 = 0..3 are the four stages ---------------------
+    if constexpr ((MW_SHARE & 1) != 0) {
+      if (ABL_ON(ABL_AF) && af_en) {   // (launch-uniform: all four waves or none)
+        __syncthreads();               // every wave's demodulated audio is in its W0 rows
+        if (mw_audio_duty) {           // 16 cascades x 4 stages: the whole wave works
+          const int st = lane_i & 3;
+          float sv[4];
+          sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
+          biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + (lane_i >> 2)) * STRIDE + W0, true, st, af_cf, sv);
+          *reinterpret_cast<float4 *>(&mw_af_S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        }
+        __syncthreads();
+      }
+    } else
     if (ABL_ON(ABL_AF) && __any(af_en)) {
       const int st = s8 & 3;
       const bool on = af_en && (s8 < 4);
@@ -2070,24 +2202,26 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           S->agc_hang_counter = agc_hc0 - 128u;      // envelope and gain stay as they are in HBM
           status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)gain_in < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
         }
-      } else
-      if (agc_en && lead) {
-        float old_abs = agc_old0;
-        uint32_t hc = agc_hc0;
-        const float al_a = agc_al_a, be_a = agc_be_a, al_r = agc_al_r, be_r = agc_be_r;
-        const uint32_t hang = agc_hang;
+      }
+      {
+      // One channel's envelope / hang recurrence on ONE lane: Lc = the channel's rows (|x| row at AGC_GV, replaced in place by the governing
+      // envelope values; gain table at AGC_TAB), Sc = its state row.  Returns the gain after the block.
+      auto agc_chain = [&](float *Lc, ChanSmall *Sc, float old0, uint32_t hc0, float g_in, float al_a, float be_a, float al_r, float be_r, uint32_t hang,
+                           bool am, float am_lvl) -> float {
+        float old_abs = old0;
+        uint32_t hc = hc0;
         float gv = -1.0f;   // envelope value governing the current gain; -1 = no update yet in this block
         // Per sample (:412-428): attack if |x| > envelope, else release unless the hang counter runs.  A lone wave issues one
         // instruction per ~4.5 cycles whatever the dependency depth (tools/ubench/dep_chain.hip), so the loop is written for the
         // fewest instructions: only the taken branch's alpha / beta are selected, then one mul, mul, add.
         // AM: twice the carrier level stands in for |x| of every sample (:407-409): the lead lane overwrites its channel's row
         // with that constant once, so that the recurrence below needs no per-sample select
-        if (is_am) {
+        if (am) {
 #pragma unroll 1
-          for (int i = 0; i < ASDR_N; i += 4) *reinterpret_cast<float4 *>(L + AGC_GV + i) = make_float4(am_clamped, am_clamped, am_clamped, am_clamped);
+          for (int i = 0; i < ASDR_N; i += 4) *reinterpret_cast<float4 *>(Lc + AGC_GV + i) = make_float4(am_lvl, am_lvl, am_lvl, am_lvl);
         }
         float x_[8];
-        load8(L + AGC_GV, x_);
+        load8(Lc + AGC_GV, x_);
 #pragma unroll 1
         for (int i2 = 0; i2 < ASDR_N; i2 += 16) {   // two chunks per trip: the prefetched chunk ping-pongs between x and xn (no copies)
           float xn_[8];
@@ -2096,7 +2230,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           const int i = i2 + 8 * half;
           float *x = half ? xn_ : x_, *xn = half ? x_ : xn_;
           float gvv[8];
-          load8(L + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);   // next chunk, a step ahead
+          load8(Lc + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);   // next chunk, a step ahead
           // Hanging chunk: no sample of the chunk attacks (none exceeds the envelope, which therefore does not move) and the hang
           // counter cannot run out inside it -> envelope, gain and governing value stay, the counter drops by 8.  With a steady
           // signal most chunks between two envelope peaks are like this.  (v_max ignores a NaN operand, as `NaN > old` is false.)
@@ -2144,14 +2278,38 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               gvv[u] = gv;
             }
           }
-          store8(L + AGC_GV + i, gvv);
+          store8(Lc + AGC_GV + i, gvv);
         }
         }
-        S->agc_old_abs = old_abs;
-        S->agc_hang_counter = hc;
-        const float g_end = (gv < 0.0f) ? gain_in : agc_compress(tab, gv);
-        S->agc_gain = g_end;
-        status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
+        Sc->agc_old_abs = old_abs;
+        Sc->agc_hang_counter = hc;
+        const float g_end = (gv < 0.0f) ? g_in : agc_compress(Lc + AGC_TAB, gv);
+        Sc->agc_gain = g_end;
+        return g_end;
+      };
+      if constexpr ((MW_SHARE & 4) != 0) {
+        // MW: every wave says whether its block is quiet; the AGC-duty wave (rel 3) runs the chains of the other waves' channels, one per lane
+        // (the |x| rows and the gain tables are in the channels' LDS rows; the scalars come from the channels' state / parameter rows)
+        if (lead) { mwx[8 * (wave * 8 + c8) + 5] = __int_as_float(agc_quiet ? 1 : 0); mwx[8 * (wave * 8 + c8) + 6] = am_clamped; }
+        __syncthreads();
+        if (mw_rel == 3 && lane_i < 8 * WAVES) {
+          const int q = lane_i;
+          if (__float_as_int(mwx[8 * q + 5]) == 0) {
+            const int chq = mw_channel(q);
+            ChanSmall *Sq = row_ptr(a.small, (uint32_t)chq * (uint32_t)sizeof(ChanSmall));
+            const ChanParams *Pq = row_ptr(a.params, (uint32_t)chq * (uint32_t)sizeof(ChanParams));
+            mwx[8 * q + 7] = agc_chain(lds_wg + q * STRIDE, Sq, Sq->agc_old_abs, Sq->agc_hang_counter, Sq->agc_gain, Pq->agc_alpha_att, Pq->agc_beta_att,
+                                       Pq->agc_alpha_rel, Pq->agc_beta_rel, Pq->agc_hang_count, is_am, mwx[8 * q + 6]);
+          }
+        }
+        __syncthreads();
+        if (!agc_quiet && lead) { const float g_end = mwx[8 * (wave * 8 + c8) + 7]; status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u); }
+      } else {
+        if (!agc_quiet && agc_en && lead) {
+          const float g_end = agc_chain(L, S, agc_old0, agc_hc0, gain_in, agc_al_a, agc_be_a, agc_al_r, agc_be_r, agc_hang, is_am, am_clamped);
+          status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
+        }
+      }
       }
       if (!agc_quiet) WAVE_SYNC();
       TL(13);
@@ -2330,6 +2488,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
     }
+    if (pf_on) asm volatile("" :: "v"(pf_v[0]), "v"(pf_v[1]), "v"(pf_v[2]), "v"(pf_v[3]), "v"(pf_v[4]));   // (the touches are complete; nothing is done with them)
     TL(15);
   }
   if (STREAM && sig_pending) stream_signal(my_prog, sig_pending, lane);
@@ -2350,6 +2509,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   }
 ASDR_KERNEL(asdr_update_kernel, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, true, 1)
 ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, false, false, 1)
+// ... and the loop-free twin of the uniform-key kernel that carries the big batches (ONEBLK): launched when a.n_blocks == 1
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel_one(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 0, true>(a, lds);
+}
+// ... and its four-wave workgroup form (MW, asdr_update_body): 32 channels per workgroup, 49,664 B of rows + 1 KB of hand-off scratch -> 3 workgroups
+// = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
+#define ASDR_MW_WAVES 4
+extern "C" __global__ __launch_bounds__(64 * ASDR_MW_WAVES, ASDR_WAVES_PER_EU) void asdr_update_kernel_mw(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 8];
+  asdr_update_body<ASDR_STRIDE, false, false, true, ASDR_MW_WAVES, 0, true>(a, lds);
+}
 // SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
 ASDR_KERNEL(asdr_update_kernel_sam, ASDR_SAM_WAVES * 8 * ASDR_STRIDE + 260, ASDR_WAVES_PER_EU, ASDR_STRIDE, false, true, false, ASDR_SAM_WAVES)
 #ifndef ASDR_ALS_WAVES_PER_EU
@@ -2750,7 +2921,22 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
     }
   }
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
-  else { if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else {
+    // the four-wave workgroup form: large direct one-block launches (ASDR_MW=0 / ASDR_MW_MIN_WAVES=<n> in the environment: measurements, tests)
+    static int mw_on = -1, mw_min = ASDR_MW_MIN_WAVES, pf_dist = ASDR_PF_WAVES;
+    if (mw_on < 0) {
+      const char *e = getenv("ASDR_MW"); mw_on = e ? atoi(e) : ASDR_MW; const char *m = getenv("ASDR_MW_MIN_WAVES"); if (m) mw_min = atoi(m);
+      const char *f = getenv("ASDR_PF_WAVES"); if (f) pf_dist = atoi(f);
+    }
+    UpdateArgs al = *a;
+    al.pf_waves = (pf_dist > 0 && n_waves > pf_dist) ? pf_dist : 0;   // (a launch shorter than the distance has nobody to warm rows for)
+    if (uniform && mw_on && a->n_blocks == 1 && a->run_if == nullptr && a->direct_ch0 >= 0 && n_waves >= mw_min)
+      hipLaunchKernelGGL(asdr_update_kernel_mw, dim3((n_waves + ASDR_MW_WAVES - 1) / ASDR_MW_WAVES), dim3(64 * ASDR_MW_WAVES), 0, stream, al);
+    else
+    if (uniform && ASDR_ONEBLK && a->n_blocks == 1 && a->run_if == nullptr) hipLaunchKernelGGL(asdr_update_kernel_one, dim3(n_waves), dim3(64), 0, stream, al);
+    else if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -2771,6 +2957,17 @@ extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int unifor
     if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// A kernel that does nothing for `ticks` ticks of the 100 MHz real-time counter (one wave): the host's probe that two streams of the pool
+// really run concurrently (asdr_host.cpp lanes_overlap_probe).  Bounded: the caller passes a few thousand ticks.
+extern "C" __global__ void asdr_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int asdr_launch_spin(unsigned long long ticks, hipStream_t stream) {
+  hipLaunchKernelGGL(asdr_spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -81,7 +81,7 @@ C5_ALGO_BYTES_PER_BLOCK = (B_IO * C5_T + B_PARAMS + 2.0 * C5_STATE) / C5_T      
 CONFIGS = {
     # name: (channels of the whole job or per GPU, scaling, blocks per step, default settle steps)
     "c2": dict(channels=65536, per_gpu=True, scaling="weak", blocks=1, settle=1500, algo=ALGO_BYTES_PER_BLOCK,
-               kernel="asdr_update_kernel"),
+               kernel="asdr_update_kernel_one"),
     "c4": dict(channels=1048576, per_gpu=False, scaling="strong", blocks=1, settle=300, algo=C4_ALGO_BYTES_PER_BLOCK,
                kernel="asdr_update_kernel_als_small (+ the SAM pre | PLL | post launches and the remainders' launch beside it)"),
     "c5": dict(channels=4096, per_gpu=False, scaling="strong", blocks=C5_T, settle=4, algo=C5_ALGO_BYTES_PER_BLOCK,
@@ -271,6 +271,7 @@ def robustness(np, torch, dev, local_rank, n_ch, stream, timed):
         if c["impulses"]:
             sig.update(impulse_every=128)     # sample 64 of every block
         dI, dQ = tiled_input(np, torch, dev, n_ch, N_INPUT_BLOCKS, n_ch // 4, **sig)
+        torch.cuda.synchronize()   # (torch's stream has produced the inputs before the batch's own streams read them)
         batch = A.AudioSDRBatch(n_ch, device=local_rank)
 
         def step(i, batch=batch, dI=dI, dQ=dQ):
@@ -290,6 +291,100 @@ def robustness(np, torch, dev, local_rank, n_ch, stream, timed):
         batch.close()
         del dI, dQ
     return out
+
+
+C3_STATE = ST_NB + ST_IF + ST_PLL + ST_IMG + ST_AF + ST_AGC                               # 3464
+C3_ALGO_BYTES_PER_BLOCK = B_IO + B_PARAMS + 2 * C3_STATE                                 # 7,792
+
+
+def configure_c3(sdr):   # SAM, blanker at 10 dB (else no lock, Q2), audio filter audioAM, AGC default
+    sdr.setDemodMode(5); sdr.setNoiseBlankerThresholdDb(10.0); sdr.enableAudioFilter(); sdr.setAudioFilter(0)
+
+
+def other_configs(np, torch, dev, local_rank):
+    """BASELINE configs 3, 4 and 5 (their single-GPU shares) ON THE DRIVER'S RECORD: the default `bench.py --gpus 1` line carries, beside
+    C2's headline, one short measured region per config -- same method (one HIP-event pair on the launch stream, ASDR_STREAM_BATCH:
+    lanes where the schedule has them), SURVEY 8(d)'s bytes, and a one-channel bit-for-bit spot check against the CPU oracle of the
+    blocks in front of the region.  Sized to add a few seconds to the command."""
+    import audiosdr_amd as A
+    from audiosdr_amd.synth import make_iq
+    from oracle import asdr_oracle as ao
+    L = A.load_library()
+    stream = A.STREAM_BATCH
+    res = {}
+
+    def run(name, n_ch, T, n_in, uniq, sig, configure_batch, configure_oracle, check_ch, warm, timed, algo, kernel, what, capture=False):
+        uniq = min(uniq, n_ch)
+        I, Q = make_iq(uniq, n_in * T, **sig)                       # [uniq][n_in * T][128]
+        reps = (n_ch + uniq - 1) // uniq
+        t_in = [(torch.from_numpy(np.ascontiguousarray(I[:, b * T:(b + 1) * T])).to(dev).repeat(reps, 1, 1)[:n_ch].contiguous(),
+                 torch.from_numpy(np.ascontiguousarray(Q[:, b * T:(b + 1) * T])).to(dev).repeat(reps, 1, 1)[:n_ch].contiguous()) for b in range(n_in)]
+        dOut = None if capture else torch.empty((n_ch, T, BLOCK), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()                                    # (the inputs are torch's work on torch's stream: done before the batch's own streams read them)
+        batch = A.AudioSDRBatch(n_ch, device=local_rank)
+        configure_batch(batch)
+        if capture:
+            batch.capture_open(T * (warm + 1))
+
+        def step(i):
+            dI, dQ = t_in[i % n_in]
+            if capture:
+                if batch.capture_position + T > batch.capture_capacity:
+                    batch.capture_rewind()
+                batch.capture_update_device(dI.data_ptr(), dQ.data_ptr(), T, None, stream)
+            else:
+                batch.update_device(dI.data_ptr(), dQ.data_ptr(), dOut.data_ptr(), T, stream)
+
+        lc0 = batch.lane_calls()
+        for i in range(warm):
+            step(i)
+        batch.synchronize(); torch.cuda.synchronize()
+        # spot check: channel check_ch after the `warm` calls, against the oracle fed the same blocks
+        o = ao.OracleSDR(); configure_oracle(o, check_ch)
+        cu = check_ch % uniq
+        xi = np.concatenate([I[cu, (i % n_in) * T:(i % n_in + 1) * T] for i in range(warm)])
+        xq = np.concatenate([Q[cu, (i % n_in) * T:(i % n_in + 1) * T] for i in range(warm)])
+        want = o.update(xi, xq).reshape(-1, BLOCK)
+        if capture:
+            got = batch.capture_read(check_ch).reshape(-1, BLOCK)
+            ok = bool(np.array_equal(got, want[:got.shape[0]])) and got.shape[0] == want.shape[0]
+        else:
+            got = dOut[check_ch].cpu().numpy().reshape(-1, BLOCK)
+            ok = bool(np.array_equal(got, want[-T:]))
+        extra = {}
+        if name == "c3":
+            extra["lock_fraction"] = float(batch.read_status()["sam_locked"].mean())
+        if capture:
+            batch.capture_rewind()
+        ms = measure_region(batch, step, stream, 0, timed)
+        ach = algo * n_ch * T / (ms * 1e-3) / 1e9
+        d = {"workload": what, "channels": n_ch, "blocks_per_step": T, "ms_per_step": round(ms, 5), "Msamples_per_s": round(n_ch * T * BLOCK / ms / 1e3, 1),
+             "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_channel_block": round(algo, 1), "dominant_kernel": kernel,
+             "steps_timed": timed, "steps_untimed": warm, "lane_calls": batch.lane_calls() - lc0,
+             "oracle_spot_check": {"channel": check_ch, "blocks": int(want.shape[0]) if capture else T, "bit_exact": ok}}
+        if capture:
+            d["times_real_time"] = round(T * BLOCK / 44100.0 / (ms * 1e-3), 1)
+            d["calls_run_as_block_pipeline"] = batch.stream_pipeline_launches()
+        d.update(extra)
+        batch.close()
+        del t_in, dOut
+        res[name] = d
+
+    uniq = 3584
+    fc3 = 6890.0 + (np.arange(uniq) % 7 - 3) * 50.0
+    run("c3", 262144, 1, 16, uniq, dict(fc=fc3, A=0.3, m=0.5, fm=400.0), configure_c3, lambda o, c: configure_c3(o), 262143, 16, 96,
+        C3_ALGO_BYTES_PER_BLOCK, "asdr_sam_pre_kernel_uniform | asdr_sam_pll_kernel | asdr_sam_post_kernel_uniform (three launches per block)",
+        "C3: SAM + PLL carrier lock + AGC, 262,144 channels x 1 block/step; carriers 6890 + (c mod 7 - 3) x 50 Hz, 50 % AM at 400 Hz")
+
+    def c4_oracle(o, c):
+        o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
+    run("c4_share", 131072, 1, 12, uniq, dict(fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15), lambda b: configure_c4(b, lib=L), c4_oracle, 100001, 12, 96,
+        C4_ALGO_BYTES_PER_BLOCK, "asdr_update_kernel_als_small (+ the SAM pre | PLL | post-with-ALS launches and the remainders' launch beside it)",
+        "C4: one GPU's share (131,072 of 1,048,576 channels) of the mixed-mode batch: mode = channel mod 7, ALS notch, blanker at 10 dB; 1 block/step")
+    run("c5_share", 512, C5_T, 1, 512, dict(fc=6890.0, A=0.02, noise=0.05), configure_c5, lambda o, c: configure_c5(o), 511, 2, 8,
+        C5_ALGO_BYTES_PER_BLOCK, "asdr_stream_kernel (block pipeline)",
+        "C5: one GPU's share (512 of 4,096 WSPR receivers, BareBonesWSPR.ino settings); one step = a 646-block call into the capture sink", capture=True)
+    return res
 
 
 PCIE_REF_GBS = 63.0   # PCIe 5.0 x16, one direction (the figure the round-3 review prices the 768 B per channel-block against)
@@ -366,6 +461,8 @@ def main_single_process(args, cfg, settle_min, warm_req):
             dOut = torch.empty((hi - lo, BLOCK), dtype=torch.int16, device=dev)
             stream = torch.cuda.Stream(device=dev)
         shards.append(batch.shard(g)); bufs.append((dI, dQ, dOut, stream))
+    for d in sorted(set(devices)):
+        torch.cuda.synchronize(d)   # the inputs (torch's default streams) are complete before the shards' streams read them
 
     def step(i):
         b = i % N_INPUT_BLOCKS
@@ -421,6 +518,7 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="one process, N GPUs through a sharded batch (asdr_create_sharded)")
     ap.add_argument("--devices", type=str, default=None, help="--single-process: comma-separated device ordinals, one per shard")
     ap.add_argument("--no-host-path", action="store_true", help="skip the h2d_d2h_inclusive measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C3 / C4 share / C5 share beside C2's headline)")
     ap.add_argument("--caller-stream", action="store_true",
                     help="launch on torch's current stream (strict stream order) instead of ASDR_STREAM_BATCH")
     args = ap.parse_args()
@@ -516,6 +614,7 @@ def main():
         # is built FIRST: creating a batch (350 MB of state for c2) idles the GPU for tens of milliseconds, after which the first ~100
         # launches run 10-25 % slow while the clocks come back (tools/warmup_curve.py) -- the settle launches must run right up to
         # the measured batch's first step.
+        torch.cuda.synchronize()   # the inputs are torch's work on torch's stream; the steps run on the batch's own (non-blocking) streams
         batch = make_batch()
         scratch = None
         if settle_min > 0:
@@ -659,7 +758,7 @@ def main():
                 out["config"]["times_real_time"] = round(T * BLOCK / 44100.0 / (k_ms * 1e-3), 1)
         if args.dry_run:
             out["dry_run"] = True
-        if world == 1 and args.config == "c2" and not args.dry_run and not (args.no_robustness and args.no_host_path):
+        if world == 1 and args.config == "c2" and not args.dry_run and not (args.no_robustness and args.no_host_path and args.no_configs):
             if batch is not None:
                 batch.close(); batch = None
             del dI, dQ
@@ -667,6 +766,8 @@ def main():
                 out["h2d_d2h_inclusive"] = host_path(np, local_rank, n_ch)
             if not args.no_robustness:
                 out["robustness"] = robustness(np, torch, dev, local_rank, n_ch, stream, 300)
+            if not args.no_configs:
+                out["configs"] = other_configs(np, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -130,8 +130,21 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
  * block and joined at its end); from call to call it cannot, because the caller may have enqueued anything in between.  Results are
  * bit-identical either way (the halves touch disjoint channels; each lane has its own local-oscillator cache entries).
  * asdr_lane_calls() = calls that ran on the lanes so far; asdr_set_lanes(b, on, min_waves) switches them off / moves the smallest
- * batch (in waves of 8 channels, default 1024) that uses them; environment ASDR_NO_LANES=1 at asdr_create time = default off. */
+ * batch (in waves of 8 channels, default 1024) that uses them; environment ASDR_NO_LANES=1 at asdr_create time = default off.
+ * WHAT THE LANES REST ON, and what breaks them.  The batch's own streams come from ONE pool of three non-blocking streams per device and
+ * process, shared by every batch of the process on that device (asdr_synchronize / the host path of one batch therefore also waits for
+ * other batches' work on those streams; device ordinals 0..15).  HIP maps the streams a process uses onto a few hardware queues (four by
+ * default: the null stream + the pool's three); two streams that share a queue run strictly one after the other, and every further
+ * stream in the process -- the application's, a framework's -- can re-map the pool's streams onto a shared queue (measured: one
+ * back-to-back kernel stream that shares its queue, 0.122 -> 0.153 ms per 65,536-channel step).  asdr_create therefore PROBES the pool
+ * once per device and process (two 30-us spin kernels on the pool's first two streams: they end together, or one after the other) and
+ * leaves the lanes off for batches created on a device whose pool streams do not overlap; asdr_lanes_overlap_probe() = 1 concurrent /
+ * 0 serialised / -1 not probed (ASDR_NO_LANES_PROBE=1, or the probe failed: defaults kept), asdr_lanes_enabled() = what the batch does.
+ * The probe sees the stream population at create time; an application that creates many streams afterwards should re-check with its own
+ * timing, or keep its calls on its own stream (strict order, no lanes: bit-identical results, ~10 % slower for large one-group batches). */
 #define ASDR_STREAM_BATCH ((void *)(intptr_t)-1)
+int asdr_lanes_overlap_probe(asdr_batch_t *b);
+int asdr_lanes_enabled(asdr_batch_t *b);
 int asdr_order_after(asdr_batch_t *b, void *stream);
 int asdr_order_before(asdr_batch_t *b, void *stream);
 long asdr_lane_calls(asdr_batch_t *b);
@@ -305,6 +318,13 @@ long asdr_stream_pipeline_recoveries(asdr_batch_t *b);
  * AudioSDR.cpp:158-165 writes the audio into blockI) never takes the pipeline either: its recovery restores channel state, not
  * caller buffers. */
 long asdr_stream_pipeline_alloc_failures(asdr_batch_t *b);
+/* A pipeline call that carries sub-ranges BESIDE the pipeline (remainders, a few SAM / ALS channels: long-running kernels on helper
+ * streams) keeps resident-workgroup headroom for them: 3 x groups + side waves + a margin must fit the device's occupancy answer, or the
+ * call takes the other launch forms (results identical; this counts such calls).  Without side sub-ranges the pipeline may fill the
+ * device.  Streams are shared by all batches of a process on a device (one pool of three: see asdr_order_after), so another batch's
+ * kernels can still delay a pipeline's role waves -- then the bounded waits fire and the call is re-run from its snapshot
+ * (asdr_stream_pipeline_recoveries): exact, slower. */
+long asdr_stream_pipeline_headroom_refusals(asdr_batch_t *b);
 int asdr_stream_pipeline_max_groups(asdr_batch_t *b);
 int asdr_set_stream_pipeline(asdr_batch_t *b, int on);
 /* Large sub-ranges of the schedule as SEVERAL kernels on as many streams (bit-identical results: the pieces touch disjoint channels).
