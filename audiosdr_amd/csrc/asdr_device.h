@@ -187,10 +187,6 @@ typedef struct {
                              post(k), asdr_launch_sam_role -- the status word may already hold block k+1's flag when post(k) reads it) */
   LoEntry *lo_ring;       /* [ASDR_LO_RING] the streaming pipeline's oscillator role leaves block b's pairs in entry b % ASDR_LO_RING;
                              its progress counter is stream_prog[3 * stream_waves] */
-  int32_t pf_waves;       /* > 0 (direct one-block launches): every wave, half-way through its block, touches the rows that the wave pf_waves
-                             further on in the launch will load (one dword per 128-byte line: they travel to L2 / the Infinity Cache while the
-                             chip's waves are busy computing), so that a later wave's prologue is not an HBM round trip behind the burst of
-                             every wave of its round starting at once; 0 = off */
   ChainConsts k;
 } UpdateArgs;
 #define ASDR_STREAM_DEPTH 4

@@ -251,6 +251,7 @@ struct asdr_batch {
   bool last_was_lanes = false;           // the previous call ran on the lanes (asdr_update_device on ASDR_STREAM_BATCH)
   int lanes_min_waves = 1024;            // smallest sub-range that is run as lanes
   bool lanes_enabled = true;
+  bool lanes_forced = false;     // asdr_set_lanes(b, on > 0): the caller's word outranks the overlap probe
   long stat_lane_calls = 0;
   int launch_split = 1, launch_split_min_waves = 2048;   // asdr_set_launch_split: a sub-range of at least that many waves is launched as `launch_split` kernels on as many streams
   int stat_host_chunks = 0, stat_host_pinned = 0;   // what the last asdr_update did (asdr_host_path_info)
@@ -740,7 +741,7 @@ hipStream_t pool_stream(int device, int i) {
 // few hardware queues, and two streams that share a queue run one after the other -- then two never-joined halves gain nothing and a
 // batch does better on its caller's stream order.  Probed once per device and process, at the first asdr_create that wants lanes: a
 // 30-us spin kernel on each of the pool's first two streams; together they end after one duration (concurrent) or two (serialised).
-// 1 = concurrent, 0 = serialised (lanes default off for batches created from then on), -1 = not probed / the probe itself failed
+// 1 = concurrent, 0 = serialised (batches then stay on the ordinary path unless asdr_set_lanes asked for the lanes), -1 = not probed / the probe itself failed
 // (lanes stay at their default: an error here must not change behaviour).
 int g_lanes_probe[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 extern "C" int asdr_launch_spin(unsigned long long ticks, hipStream_t stream);
@@ -880,8 +881,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     if (ok && hipStreamSynchronize(nullptr) != hipSuccess) ok = false;
     for (int i = 0; i < ASDR_LANES + 1 && ok; i++)
       if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
-    b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;
-    if (b->lanes_enabled && lanes_overlap_probe(device) == 0) b->lanes_enabled = false;   // the pool's streams share a hardware queue here: caller-stream order is the faster form
+    b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;   // (the overlap probe runs at the first call that would use the lanes: update_device_part)
     b->sam_role_streams = getenv("ASDR_NO_SAM_ROLE_STREAMS") == nullptr;
     if (ok && (b->stream = pool_stream(device, 0)) == nullptr) ok = false;   // the pool's first stream (= lane 0: a batch runs on the lanes or on its own stream, never both at once)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
@@ -1036,7 +1036,13 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     // (a call the block pipeline may take is not a lane call: the pipeline runs on `stream` and needs that stream's ordering)
     const bool pipeline_candidate = b->stream_pipeline && n_blocks >= ASDR_STREAM_MIN_BLOCKS && b->plain_uniform_ssb &&
                                     b->kind_uniform_slots[ASDR_KERNEL_PLAIN] > 0 && b->kind_uniform_slots[ASDR_KERNEL_PLAIN] / 8 <= b->stream_max_waves;
-    use_lanes = !pipeline_candidate && total / 8 >= b->lanes_min_waves &&
+    bool lanes_ok = !pipeline_candidate && total / 8 >= b->lanes_min_waves;
+    // The first call that would take the lanes PROBES the pool on this device (once per device and process; not at asdr_create: a
+    // process that only ever calls on its own streams never creates the pool's lane streams -- every stream a process creates can push
+    // its other streams onto a shared hardware queue).  Serialised pool streams: the batch stays on the ordinary path unless the caller
+    // asked for the lanes explicitly (asdr_set_lanes).
+    if (lanes_ok && !b->lanes_forced && lanes_overlap_probe(b->device) == 0) { b->lanes_enabled = false; lanes_ok = false; }
+    use_lanes = lanes_ok &&
                 (batch_stream || total >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES || (b->sam_split && b->kind_slots[ASDR_KERNEL_SAM] + b->kind_slots[ASDR_KERNEL_SAM_ALS] > 0) ||
                  (b->als_split && b->kind_uniform_slots[ASDR_KERNEL_ALS_SMALL] > 0));   // (a strict call: only in its one-launch-per-block form)
   }
@@ -1755,8 +1761,10 @@ int asdr_lanes_overlap_probe(asdr_batch_t *b) {   // what the create-time probe 
 }
 int asdr_lanes_enabled(asdr_batch_t *b) {
   if (!b) return -1;
-  if (is_sharded(b)) { for (asdr_batch *sh : b->shards) if (!sh->lanes_enabled) return 0; return 1; }
-  return b->lanes_enabled ? 1 : 0;
+  if (is_sharded(b)) { for (asdr_batch *sh : b->shards) if (!asdr_lanes_enabled(sh)) return 0; return 1; }
+  if (!b->lanes_enabled) return 0;
+  const int probe = (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe[b->device] : -1;
+  return (probe == 0 && !b->lanes_forced) ? 0 : 1;   // (what the next lane-sized call will do, as far as is known now)
 }
 long asdr_sam_role_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_sam_role_calls; return t; }
@@ -1768,6 +1776,7 @@ int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves) {
   FOR_SHARDS(b, asdr_set_lanes(sh_, on, min_waves));
   if (b->device != ASDR_NO_DEVICE && b->lanes_pending) { HIPCHK(hipSetDevice(b->device)); if (sync_all(b) != 0) return -1; }
   b->lanes_enabled = on != 0;
+  b->lanes_forced = on != 0;
   if (on >= 2) { b->n_lanes = on; b->n_lanes_sam = on; b->sched_dirty = true; }   // an explicit count, for every schedule (the writers' places follow it)
   if (min_waves > 0) b->lanes_min_waves = std::max(2 * ASDR_LANES, min_waves);
   return 0;

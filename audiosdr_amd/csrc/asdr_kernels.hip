@@ -53,8 +53,11 @@
 #ifndef ASDR_MW_SHARE
 #define ASDR_MW_SHARE 7   /* what the four waves of an MW workgroup share: 1 audio cascades (2 waves x 16 channels), 2 blanker / phase chains, 4 AGC chain (1 wave x 32 channels) */
 #endif
-#ifndef ASDR_PF_WAVES
-#define ASDR_PF_WAVES 0   /* default distance of the row-warming touches (UpdateArgs.pf_waves), in waves; 0 = off.  Environment ASDR_PF_WAVES overrides */
+#ifndef ASDR_MIX_KEEP_Q
+#define ASDR_MIX_KEEP_Q 1   /* uniform SSB waves keep the mixed Q in registers from the mixer to the Hilbert stage (no LDS round trip of the mixed rows); 0: through W0 / W1 */
+#endif
+#ifndef ASDR_UNIT_SCALE
+#define ASDR_UNIT_SCALE 1   /* waves whose input gains are all 1.0 scale their samples with two binary32 operations (scale8); 0: always the binary64 form */
 #endif
 #ifndef ASDR_MW_MIN_WAVES
 #define ASDR_MW_MIN_WAVES 64
@@ -267,6 +270,23 @@ __device__ __forceinline__ float fast_sqrt1(float x) {
   float out = __uint_as_float(i);
   return 0.5f * (out + x / out);
 }
+// The same with the IEEE division x / out (an 11-instruction sequence) replaced by v_rcp_f32 + one Newton step on the reciprocal + one
+// residual correction of the quotient (6 instructions): bit-identical RESULTS for every x >= 7.6e-32 and for x = 0, checked over all 2^31
+// non-negative finite floats on the GPU (tools/ubench/sqrt_div_check.hip; tests/test_gpu_parity.py runs it).  Used where x = I^2 + Q^2 of
+// samples scaled with gain exactly 1.0 (x = 0 or x >= 9.3e-10: the unit-gain waves of scale8).
+__device__ __forceinline__ float fast_sqrt1_short(float x) {
+  uint32_t i = __float_as_uint(x);
+  i -= 1u << 23;
+  i >>= 1;
+  i += 1u << 29;
+  const float out = __uint_as_float(i);
+  const float r0 = __builtin_amdgcn_rcpf(out);
+  const float r = __builtin_fmaf(__builtin_fmaf(-out, r0, 1.0f), r0, r0);
+  const float q0 = x * r;
+  const float e = __builtin_fmaf(-out, q0, x);
+  const float q1 = __builtin_fmaf(e, r, q0);
+  return 0.5f * (out + q1);
+}
 // AudioSDR.cpp:483-494
 __device__ __forceinline__ float agc_compress(const float *tab, float abs_val) {
   uint32_t input = (uint32_t)(int)((double)abs_val * 32767.0) & 0xFFFFu;
@@ -296,7 +316,7 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 #define ASDR_PIPE_PK_MASK 0   /* which kernel kinds run the pipelines' y-independent products packed (see PIPE_PK in the body) */
 #endif
 #ifndef ASDR_PIPE_PREFETCH_FENCE
-#define ASDR_PIPE_PREFETCH_FENCE 1
+#define ASDR_PIPE_PREFETCH_FENCE 0   /* measured: no gain (profiles/README.md, round 5) */
 #endif
 #ifndef ASDR_PIPE_CHUNK
 #define ASDR_PIPE_CHUNK 8   /* samples per lane per pipeline step: 4 (35 steps) or 8 (19 steps, less per-step overhead) */
@@ -462,7 +482,16 @@ __device__ __forceinline__ double div_i16_by_32767(double x) {
   return __builtin_fma(x, 0x1.0002000400080p-15, x * 0x1.0002000400080p-75);
 }
 // AudioSDR.cpp:68-69 for 8 raw samples: ((float)s / 32767.0) * gain in binary64, rounded to float by the store
-__device__ __forceinline__ void scale8(const int16_t *s, double g, float *out) {
+// UNIT (wave-uniform: every gain of the wave's rows is exactly 1.0f, the reference's default, AudioSDR.h:172-175): the binary64 quotient
+// rounded to binary32 as TWO binary32 operations -- fmaf(x, rh, x * rl), rh = 0x1.0002p-15f and rl = 0x1.0002p-45f being the first four
+// copies of the 15-bit pattern of 1/32767 -- instead of five binary64-rate ones (convert, multiply, fma, multiply by the gain,
+// convert): equal for all 65,536 inputs (oracle ao_check_scale_unit_gain); the product with 1.0 is exact.  Round 5.
+__device__ __forceinline__ void scale8(const int16_t *s, double g, float *out, bool unit = false) {
+  if (unit) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float x = (float)s[j]; out[j] = __builtin_fmaf(x, 0x1.0002p-15f, x * 0x1.0002p-45f); }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
 #ifdef ASDR_OLD_SCALE
@@ -1115,6 +1144,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // (Not the ALS instantiations: their loop-free builds fail the ALS parity tests from the first block after a schedule change -- ALS tap
   // 1 % off with every earlier tap exact -- for a reason not found yet; they keep the loop.  profiles/README.md, round 5.)
   constexpr bool ONEBLK = !HAS_ALS && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
+  constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);   // the unit-gain scale (scale8): the loop-free instantiations have the registers for its second code path
 #pragma unroll 1
   for (int blk = 0; blk < (ONEBLK ? 1 : a.n_blocks); ++blk) {
     // Per-iteration opaque copies of the lane coordinates: stops LICM from hoisting every per-lane address
@@ -1259,10 +1289,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (nb_wave) {
       // (the newest block goes to its ring slot after the envelopes, below)
     } else if (DO1) {
+      const bool unit_in = UNIT_OK && __all(gain_i == 1.0f && gain_q == 1.0f);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float xi[8], xq[8];
-        scale8(ri[h].s, (double)gain_i, xi); scale8(rq[h].s, (double)gain_q, xq);
+        scale8(ri[h].s, (double)gain_i, xi, unit_in); scale8(rq[h].s, (double)gain_q, xq, unit_in);
         TAP8(ASDR_TAP_SCALED_I, h, xi); TAP8(ASDR_TAP_SCALED_Q, h, xq);
         store8(L + W0 + kA + 64 * h, xi); store8(L + W1 + kA + 64 * h, xq);
         SCHED_FENCE();
@@ -1289,25 +1320,38 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // of lanes s8 >= 1).  beta * envelope goes to the B row (index NB_B + t) for the sequential pass; the envelopes
       // themselves stay in registers for the threshold test.
       const bool own_tail = (s8 >= 1);
+      // (every gain the wave's ring slots arrived with is 1.0: the two-operation binary32 scale, see scale8)
+      const bool unit_ring = UNIT_OK && __all(g_oi == 1.0f && g_oq == 1.0f && (!nb_en || (g_mi == 1.0f && g_mq == 1.0f)));
+      // (the choice is made per scale call and per GROUP OF FOUR envelopes: a test per envelope keeps the divisions of a piece from interleaving,
+      // the whole pass in two copies costs the loop-free kernels 2 - 26 spilled registers)
+      auto env4 = [&](const float *pw4, float *mg4) {
+        if (unit_ring) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mg4[j] = fast_sqrt1_short(pw4[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mg4[j] = fast_sqrt1(pw4[j]);
+        }
+      };
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        float vim[8], vqm[8], bm8[8];
-        scale8(roi[h].s, (double)g_oi, vio + 8 * h); scale8(roq[h].s, (double)g_oq, vqo + 8 * h);
-        scale8(rmi[h].s, (double)g_mi, vim); scale8(rmq[h].s, (double)g_mq, vqm);
+        float vim[8], vqm[8], bm8[8], pw[8];
+        scale8(roi[h].s, (double)g_oi, vio + 8 * h, unit_ring); scale8(roq[h].s, (double)g_oq, vqo + 8 * h, unit_ring);
+        scale8(rmi[h].s, (double)g_mi, vim, unit_ring); scale8(rmq[h].s, (double)g_mq, vqm, unit_ring);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          mgm[8 * h + j] = fast_sqrt1(vim[j] * vim[j] + vqm[j] * vqm[j]); bm8[j] = K.nb_beta * mgm[8 * h + j];
-          if ((j & 3) == 3) SCHED_FENCE();
-        }
+        for (int j = 0; j < 8; ++j) pw[j] = vim[j] * vim[j] + vqm[j] * vqm[j];
+        env4(pw, mgm + 8 * h); env4(pw + 4, mgm + 8 * h + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bm8[j] = K.nb_beta * mgm[8 * h + j];
         if (nb_en) store8(L + NB_B + 50 + kA + 64 * h, bm8);
       }
       if (own_tail) {
-        float bm8[8];
+        float bm8[8], pw[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          mgt[j] = fast_sqrt1(vio[8 + j] * vio[8 + j] + vqo[8 + j] * vqo[8 + j]); bm8[j] = K.nb_beta * mgt[j];
-          if ((j & 3) == 3) SCHED_FENCE();
-        }
+        for (int j = 0; j < 8; ++j) pw[j] = vio[8 + j] * vio[8 + j] + vqo[8 + j] * vqo[8 + j];
+        env4(pw, mgt); env4(pw + 4, mgt + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bm8[j] = K.nb_beta * mgt[j];
         // index NB_B + k - 78 = 8 s8 + j - 12: lane 1 holds k = 72..79, of which 76, 77 land on the two padding words below NB_B
         if (nb_en) { if (s8 >= 2) store8(L + kA - 12, bm8); else *reinterpret_cast<float4 *>(L) = make_float4(bm8[4], bm8[5], bm8[6], bm8[7]); }
       } else {
@@ -1830,6 +1874,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
     // in HBM (slot hs = this block, hs^1 = previous block = the reference's exact 128-sample delay, :111)
+    // Uniform SSB waves (round 5): the mixed Q stays in registers for the Hilbert stage (same lane, same pieces) and neither mixed row
+    // goes back to LDS -- the delayed I comes from the HBM ring, nothing reads W0 / W1 again before the history overlays them.
+    constexpr bool QN_DIRECT_K = UNIFORM && ABL_ON(ABL_MIX) && (ASDR_MIX_KEEP_Q != 0);
+    const bool qn_direct = QN_DIRECT_K && is_ssb;
+    float qn[16];   // own pieces (samples kF + 32m + j at [4m + j]) of the mixed Q
+    DEFINE_ALL_PATHS(qn, 16);
     if (ABL_ON(ABL_MIX) && do_mix) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -1861,7 +1911,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           mi[j] = vi[j] * cc[j] - vq[j] * sn[j];
           mq[j] = vq[j] * cc[j] + vi[j] * sn[j];
         }
-        store4(L + W0 + kF + 32 * m, mi); store4(L + W1 + kF + 32 * m, mq);
+        if (qn_direct) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) qn[4 * m + j] = mq[j];
+        } else { store4(L + W0 + kF + 32 * m, mi); store4(L + W1 + kF + 32 * m, mq); }
 #ifndef ASDR_TEMPORAL_RINGS
         if (is_ssb) store4_nt(hi_ring + hs * 128 + 32 * m, mi);
 #else
@@ -1904,9 +1957,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     TL(7);
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
     if (__any(is_ssb)) {
-      float qn[16];   // own pieces (samples kF + 32m + j at [4m + j]) of the mixed Q
-      DEFINE_ALL_PATHS(qn, 16);
-      if (is_ssb) {
+      if (is_ssb && !qn_direct) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) load4(L + W1 + kF + 32 * m, qn + 4 * m);   // mixed Q, written above by other lanes too (same wave: LDS is in order)
       }
@@ -2087,34 +2138,6 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
 
-    // Round 5: WARM THE ROWS OF A LATER WAVE (UpdateArgs.pf_waves).  The waves of a launch start in rounds (3,072 resident at a time), every
-    // wave of a round asks for its ~25 KB of rows at once, and a wave's first instructions wait out that burst (the prologue: 10 % of a
-    // wave's lifetime inside the full launch, 2 % alone).  Here -- the FIR is done, the wave computes for another third of its life and
-    // asks nothing of memory -- every lane touches one 128-byte line of the rows wave (this + pf_waves) will load: they are fetched
-    // while the memory system is idle and wait in L2 / the Infinity Cache.  Five loads per lane, results never used (waited for at
-    // the end of the block); the input rows of the NEXT call cannot be known, the state rows can.
-    uint32_t pf_v[5] = {0u, 0u, 0u, 0u, 0u};
-    bool pf_on = false;
-    if constexpr (ONEBLK && ROLE == 0 && UNIFORM && !HAS_ALS && !HAS_SAM) {   // (the loop-free plain kernels: the launches that carry big batches)
-      const int wp = wave_g + a.pf_waves;
-      pf_on = a.pf_waves > 0 && a.direct_ch0 >= 0 && wp * 8 < a.n_sched;
-      if (pf_on) {
-        const uint32_t chp = (uint32_t)(a.direct_ch0 + wp * 8 + c8);
-        const uint32_t s8u = (uint32_t)s8;
-        const char *p0 = reinterpret_cast<const char *>(a.nb_hist) + (size_t)chp * 1536u + ((s8u < 4u) ? ns : ns_mid) * 512u + (s8u & 3u) * 128u;   // the blanker ring's oldest and middle slots (same launch: same ring position)
-        const char *p1 = reinterpret_cast<const char *>(a.hil_q) + (size_t)chp * 1024u + s8u * 128u;
-        const char *p2 = reinterpret_cast<const char *>(a.hil_i) + (size_t)chp * 1024u + s8u * 128u;
-        const char *p3 = (s8u < 5u) ? reinterpret_cast<const char *>(a.small) + (size_t)chp * 448u + ((s8u * 128u < 444u) ? s8u * 128u : 444u)
-                       : (s8u < 7u) ? reinterpret_cast<const char *>(a.params) + (size_t)chp * 96u + (s8u - 5u) * 92u
-                                    : reinterpret_cast<const char *>(a.nb_mask) + (size_t)chp * ASDR_NB_MASK_ROW;
-        const size_t iop = ((size_t)chp * a.in_stride + blk) * (ASDR_N * 2);
-        const char *p4 = (s8u < 2u) ? reinterpret_cast<const char *>(a.in_i) + iop + s8u * 128u
-                       : (s8u < 4u) ? reinterpret_cast<const char *>(a.in_q) + iop + (s8u - 2u) * 128u
-                                    : reinterpret_cast<const char *>(a.nb_mask) + (size_t)chp * ASDR_NB_MASK_ROW + 128u;
-        pf_v[0] = *reinterpret_cast<const uint32_t *>(p0); pf_v[1] = *reinterpret_cast<const uint32_t *>(p1); pf_v[2] = *reinterpret_cast<const uint32_t *>(p2);
-        pf_v[3] = *reinterpret_cast<const uint32_t *>(p3); pf_v[4] = *reinterpret_cast<const uint32_t *>(p4);
-      }
-    }
     // the AGC gain table (row of 132 floats) is requested before the audio-filter pipeline and staged in LDS after it
     float4 agc_t4[5];
 #pragma unroll
@@ -2488,7 +2511,6 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
     }
-    if (pf_on) asm volatile("" :: "v"(pf_v[0]), "v"(pf_v[1]), "v"(pf_v[2]), "v"(pf_v[3]), "v"(pf_v[4]));   // (the touches are complete; nothing is done with them)
     TL(15);
   }
   if (STREAM && sig_pending) stream_signal(my_prog, sig_pending, lane);
@@ -2923,17 +2945,12 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else {
     // the four-wave workgroup form: large direct one-block launches (ASDR_MW=0 / ASDR_MW_MIN_WAVES=<n> in the environment: measurements, tests)
-    static int mw_on = -1, mw_min = ASDR_MW_MIN_WAVES, pf_dist = ASDR_PF_WAVES;
-    if (mw_on < 0) {
-      const char *e = getenv("ASDR_MW"); mw_on = e ? atoi(e) : ASDR_MW; const char *m = getenv("ASDR_MW_MIN_WAVES"); if (m) mw_min = atoi(m);
-      const char *f = getenv("ASDR_PF_WAVES"); if (f) pf_dist = atoi(f);
-    }
-    UpdateArgs al = *a;
-    al.pf_waves = (pf_dist > 0 && n_waves > pf_dist) ? pf_dist : 0;   // (a launch shorter than the distance has nobody to warm rows for)
+    static int mw_on = -1, mw_min = ASDR_MW_MIN_WAVES;
+    if (mw_on < 0) { const char *e = getenv("ASDR_MW"); mw_on = e ? atoi(e) : ASDR_MW; const char *m = getenv("ASDR_MW_MIN_WAVES"); if (m) mw_min = atoi(m); }
     if (uniform && mw_on && a->n_blocks == 1 && a->run_if == nullptr && a->direct_ch0 >= 0 && n_waves >= mw_min)
-      hipLaunchKernelGGL(asdr_update_kernel_mw, dim3((n_waves + ASDR_MW_WAVES - 1) / ASDR_MW_WAVES), dim3(64 * ASDR_MW_WAVES), 0, stream, al);
+      hipLaunchKernelGGL(asdr_update_kernel_mw, dim3((n_waves + ASDR_MW_WAVES - 1) / ASDR_MW_WAVES), dim3(64 * ASDR_MW_WAVES), 0, stream, *a);
     else
-    if (uniform && ASDR_ONEBLK && a->n_blocks == 1 && a->run_if == nullptr) hipLaunchKernelGGL(asdr_update_kernel_one, dim3(n_waves), dim3(64), 0, stream, al);
+    if (uniform && ASDR_ONEBLK && a->n_blocks == 1 && a->run_if == nullptr) hipLaunchKernelGGL(asdr_update_kernel_one, dim3(n_waves), dim3(64), 0, stream, *a);
     else if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a);
   }

@@ -63,6 +63,7 @@ BLOCK = 128
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_INPUT_BLOCKS = 4                    # distinct resident input blocks cycled through by the steps
 PMC_FILE = os.path.join("profiles", "pmc_latest.json")
+ISSUE_FILE = os.path.join("profiles", "issue_latest.json")
 
 # ---- algorithmic bytes per channel-block, SURVEY.md 8d (minimal carried state read AND written once per block at T = 1) ----
 B_IO, B_PARAMS = 768, 96
@@ -714,6 +715,29 @@ def main():
                     traffic_source = "%s is from another build of the library: dropped" % PMC_FILE
         except Exception:
             pass
+        # The kernel against its ISSUE roofline (profiles/issue_latest.json, tools/issue_model.py: builder-run counter passes of this command on
+        # a caller's stream, stamped with the sources they were taken from): vector-unit cycles per wave by instruction class -> the time
+        # the launch would take if no vector unit ever idled.  Dropped when the file is from other sources.
+        issue = None
+        try:
+            with open(os.path.join(ROOT, ISSUE_FILE)) as f:
+                ij = json.load(f)
+            if args.config == "c2" and n_ch == CHANNELS_PER_GPU and not args.dry_run:
+                from audiosdr_amd import build as _build
+                if ij.get("source_sha256") == _build.source_sha256():
+                    floor = ij.get("valu_floor_ms")
+                    issue = {k: ij.get(k) for k in ("kernel", "valu_instructions_per_wave", "valu_instructions_per_wave_by_class", "cycles_per_instruction_by_class",
+                                                    "valu_cycles_per_wave", "wave_lifetime_cycles_in_the_full_launch", "wave_cycles_issuing_frac",
+                                                    "wave_cycles_issue_stalled_frac", "wave_cycles_parked_at_a_wait_frac", "shader_clock_ghz_during_the_launch",
+                                                    "resident_waves_per_simd", "valu_floor_ms")}
+                    issue["valu_busy_frac_this_run"] = round(floor / k_ms, 4) if floor and k_ms > 0 else None
+                    issue["source"] = "%s (rocprofv3 --pmc passes of this command on a caller's stream + tools/ubench/valu_rate.hip's cycles per instruction class)" % ISSUE_FILE
+                    issue["reading"] = ("valu_floor_ms = waves x valu_cycles_per_wave / (1024 SIMDs x clock): the launch with every vector unit busy every cycle. "
+                                        "The rest of the measured time is three resident waves per SIMD working through their own dependent streams "
+                                        "(wave_cycles_* fractions): occupancy (168 -> 128 VGPRs and 12.4 -> 10 KB of LDS per wave for a fourth wave) is the lever left, "
+                                        "not arithmetic -- DESIGN.md 5")
+        except Exception:
+            pass
         workload = {
             "c2": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
             "c4": "C4: mixed modes (channel mod 7: LSB, USB, CW_LSB, CW_USB, AM, SAM, WSPR) + ALS notch + blanker at 10 dB, %d channels "
@@ -749,6 +773,8 @@ def main():
                          "algorithmic_bytes_per_channel_block": round(cfg["algo"], 1),
                          "algorithmic_bytes_per_launch": int(round(algo))},
         }
+        if issue is not None:
+            out["roofline_issue"] = issue
         if args.config == "c2":
             out["roofline"]["hbm_read_share_frac"] = round(ALGO_READ_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0
         if args.config == "c5":

@@ -136,12 +136,15 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
  * other batches' work on those streams; device ordinals 0..15).  HIP maps the streams a process uses onto a few hardware queues (four by
  * default: the null stream + the pool's three); two streams that share a queue run strictly one after the other, and every further
  * stream in the process -- the application's, a framework's -- can re-map the pool's streams onto a shared queue (measured: one
- * back-to-back kernel stream that shares its queue, 0.122 -> 0.153 ms per 65,536-channel step).  asdr_create therefore PROBES the pool
- * once per device and process (two 30-us spin kernels on the pool's first two streams: they end together, or one after the other) and
- * leaves the lanes off for batches created on a device whose pool streams do not overlap; asdr_lanes_overlap_probe() = 1 concurrent /
- * 0 serialised / -1 not probed (ASDR_NO_LANES_PROBE=1, or the probe failed: defaults kept), asdr_lanes_enabled() = what the batch does.
- * The probe sees the stream population at create time; an application that creates many streams afterwards should re-check with its own
- * timing, or keep its calls on its own stream (strict order, no lanes: bit-identical results, ~10 % slower for large one-group batches). */
+ * back-to-back kernel stream that shares its queue, 0.122 -> 0.153 ms per 65,536-channel step).  The first call that would use the lanes
+ * therefore PROBES the pool, once per device and process (two 30-us spin kernels on the pool's first two streams: they end together, or
+ * one after the other), and a batch whose pool streams do not overlap stays on the ordinary path unless asdr_set_lanes(b, on > 0) asked
+ * for the lanes; asdr_lanes_overlap_probe() = 1 concurrent / 0 serialised / -1 not probed yet (or ASDR_NO_LANES_PROBE=1, or the probe
+ * failed: defaults kept), asdr_lanes_enabled() = what the batch's next lane-sized call will do.  (Not at asdr_create: a process that only
+ * ever calls on its own streams never creates the pool's lane streams -- two application streams driving two shards of one GPU lost 25 %
+ * to a probe at create time, round 5.)  The probe sees the stream population at that moment; an application that creates many streams
+ * afterwards should re-check with its own timing, or keep its calls on its own stream (strict order, no lanes: bit-identical results,
+ * ~10 % slower for large one-group batches). */
 #define ASDR_STREAM_BATCH ((void *)(intptr_t)-1)
 int asdr_lanes_overlap_probe(asdr_batch_t *b);
 int asdr_lanes_enabled(asdr_batch_t *b);

@@ -746,6 +746,20 @@ int ao_check_scale_division(void) {
   return bad;
 }
 
+/* all int16 at input gain 1.0 (the reference's default, AudioSDR.h:172-175): (float)(((float)s / 32767.0) * 1.0) -- the binary64 quotient
+ * rounded to binary32 -- against the kernels' binary32 form fmaf(x, rh, x * rl) with rh = 0x1.0002p-15, rl = 0x1.0002p-45 (1/32767 is
+ * the bit pattern 2^-15 repeated every 15 bits: rh holds two copies, rl the next two; asdr_kernels.hip scale8, unit-gain waves). */
+int ao_check_scale_unit_gain(void) {
+  int bad = 0;
+  for (int s = -32768; s < 32768; s++) {
+    const float want = (float)(((double)(float)s / 32767.0) * (double)1.0f);
+    const float x = (float)s;
+    const float got = fmaf(x, 0x1.0002p-15f, x * 0x1.0002p-45f);
+    if (memcmp(&want, &got, 4) != 0) bad++;
+  }
+  return bad;
+}
+
 /* The kernels' PLL phase update fmaf(filt + prev, 0.5f, phase) against the reference's (float)((double)phase + (double)(filt +
  * prev) / 2.0) (AudioSDR.cpp:732): halving is exact in binary64, and rounding the binary64 sum of two binary32-precision values
  * to binary32 is innocuous double rounding (53 >= 2*24 + 2), so the single-rounding fma must agree for EVERY pair.  Checked on n

@@ -151,6 +151,7 @@ const float *ao_biquad_table(int pool_index); /* 20 floats, index as in asdr_tab
 uint64_t ao_check_sin_index_division(uint32_t bits_lo, uint32_t bits_hi);
 uint64_t ao_check_sin_index_one_multiply(uint32_t bits_lo, uint32_t bits_hi);
 int ao_check_scale_division(void);
+int ao_check_scale_unit_gain(void);
 int ao_check_sin_interp_f32(void);
 uint64_t ao_check_pll_phase_update(uint32_t seed, uint64_t n);   /* asdr_kernels.hip: the PLL phase update as one fmaf */
 

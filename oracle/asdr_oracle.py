@@ -114,6 +114,7 @@ def lib():
     L.ao_biquad_table.argtypes = [i32]; L.ao_biquad_table.restype = fp
     L.ao_check_sin_index_division.argtypes = [C.c_uint32, C.c_uint32]; L.ao_check_sin_index_division.restype = C.c_uint64
     L.ao_check_scale_division.restype = i32
+    L.ao_check_scale_unit_gain.restype = i32
     L.ao_check_sin_interp_f32.restype = i32
     L.ao_bench_run.argtypes = [i32, i32, i32, i16p, i16p, i16p, i32]
     L.ao_bench_run.restype = C.c_double

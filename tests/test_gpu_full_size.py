@@ -52,9 +52,10 @@ def test_full_size_c3_batch(gpu, ao):
         for c in sample:
             got[c].append(dOut[c + uniq * 70].cpu().numpy().copy())
     for c in sample:
-        o = ao.OracleSDR(); cfg(o)
+        o = ao.OracleSDR(pll_wrap_bound=False); cfg(o)   # the DEFAULT oracle: the reference's unbounded wrap loops, which must never stall here
         want = o.update(I[c], Q[c]).reshape(n_blk, BLOCK)
         assert np.array_equal(np.stack(got[c]), want), "C3 channel %d" % c
+        assert o.pll_stalled() == 0
     st = batch.read_status()
     assert float(st["sam_locked"].mean()) == 1.0
     batch.close()
@@ -280,9 +281,15 @@ def test_c4_whole_job_on_one_gpu(gpu, ao):
         L.asdr_setDemodMode(batch._h, c, c % 7)
     batch.enableALSfilter(); batch.setNoiseBlankerThresholdDb(10.0)
     dOut = torch.empty((n_ch, 2, BLOCK), dtype=torch.int16, device="cuda")
-    sample = list(range(14))
-    tiles = [0, 292]                                  # 292 * 3584 = 1,046,528: the last whole tile
+    # Oracle sample (round 5: 28 -> 112 channel-positions): 14 channels = two per mode, from the channel positions 0..13 AND 3570..3583 of a
+    # tile (the first and the last waves a tile's channels land in after the schedule's sort by mode), in the first tile, the tile around the
+    # lanes' cut (tile 146: channel 523,264 -- the halves of every sub-range meet near there) and the last whole tile: two or more channels
+    # per (mode, lane, tile-end) combination.  All against the DEFAULT oracle (the reference's unbounded PLL wrap), which must not stall.
+    sample = list(range(14)) + list(range(uniq - 14, uniq))
+    tiles = [0, 146, 291]                             # tile 292 (from channel 1,046,528) is the batch's last, partial one: 2,048 channels
+    assert max(sample) + uniq * max(tiles) < n_ch
     got = {(c, t): [] for c in sample for t in tiles}
+    last = {c: [] for c in range(14)}
 
     def collect(nb):
         batch.synchronize()
@@ -290,6 +297,8 @@ def test_c4_whole_job_on_one_gpu(gpu, ao):
             _assert_tiled(torch, dOut[:, k], uniq, "C4 whole job")
             for (c, t) in got:
                 got[(c, t)].append(dOut[c + uniq * t, k].cpu().numpy().copy())
+            for c in range(14):                       # ... and the first channels of the partial last tile (the very end of the 32-bit row offsets)
+                last[c].append(dOut[c + uniq * 292, k].cpu().numpy().copy())
 
     for b in range(4):
         batch.update_device_strided(dI[b].data_ptr(), dQ[b].data_ptr(), dOut.data_ptr(), 1, 1, 2, gpu.STREAM_BATCH if b != 2 else 0)
@@ -300,11 +309,14 @@ def test_c4_whole_job_on_one_gpu(gpu, ao):
     batch.update_device(dI2.data_ptr(), dQ2.data_ptr(), dOut.data_ptr(), 2, 0)
     collect(2)
     for c in sample:
-        o = ao.OracleSDR()
+        o = ao.OracleSDR(pll_wrap_bound=False)
         o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
         want = o.update(I[c], Q[c]).reshape(n_blk, BLOCK)
+        assert o.pll_stalled() == 0
         for t in tiles:
             assert np.array_equal(np.stack(got[(c, t)]), want), "C4 channel %d of tile %d (mode %d)" % (c, t, c % 7)
+        if c < 14:
+            assert np.array_equal(np.stack(last[c]), want), "C4 channel %d of the last tile (mode %d)" % (c, c % 7)
     batch.close()
 
 

@@ -203,3 +203,53 @@ def test_host_rows_call_behind_running_lanes(gpu):
     bad = np.argwhere(wA != wB)
     assert bad.size == 0, "%d samples differ, first at %s" % (len(bad), bad[0].tolist())
     hip.free_all(); A.close(); B.close()
+
+
+def test_lanes_with_foreign_streams_alive_and_the_overlap_probe(gpu):
+    """Round 5: the lanes rest on the pool's streams running concurrently, which every other stream of the process can change (include/asdr.h,
+    "WHAT THE LANES REST ON").  With three torch streams alive and busy beside the batch: (1) asdr_create's probe has an answer for the device
+    (1 concurrent / 0 serialised; -1 only if switched off) and the batch's default follows it; (2) whatever the probe said, lane calls
+    and ordinary calls give identical audio (the geometry is a speed matter, never a correctness one)."""
+    import os
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n, total = 16384, 6
+    foreign = [torch.cuda.Stream() for _ in range(3)]
+    junk = [torch.zeros(1 << 20, device="cuda") for _ in foreign]
+    for s, t in zip(foreign, junk):
+        with torch.cuda.stream(s):
+            for _ in range(20):
+                t.add_(1.0)
+    bI, bQ = make_iq(64, total, fc=6290.0, A=0.25)
+    I, Q = _tile(bI, n), _tile(bQ, n)
+    A, B = _twin(gpu, n, 1)
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    dA, dB = hip.malloc(n * total * 256), hip.malloc(n * total * 256)
+    for b in range(total):
+        for s, t in zip(foreign, junk):                 # the foreign streams stay busy between the calls
+            with torch.cuda.stream(s):
+                t.mul_(1.0001)
+        off = b * 256
+        A.update_device_strided(dI + off, dQ + off, dA + off, 1, total, total, gpu.STREAM_BATCH)
+        B.update_device_strided(dI + off, dQ + off, dB + off, 1, total, total, 0)
+    A.synchronize(); B.synchronize()
+    assert A.lane_calls() == total - 1                  # (set_lanes(True) in _twin: the lanes run whatever the probe says)
+    wa, wb = hip.download(dA, (n, total, 128), np.int16), hip.download(dB, (n, total, 128), np.int16)
+    assert np.array_equal(wa, wb)
+    C = gpu.AudioSDRBatch(n)                            # a batch with the DEFAULT setting: its first lane-sized call probes the pool and follows it
+    C.setDemodMode(1); C.enableAudioFilter(); C.setNoiseBlankerThresholdDb(10.0)
+    dC = hip.malloc(n * total * 256)
+    for b in range(3):
+        C.update_device_strided(dI + b * 256, dQ + b * 256, dC + b * 256, 1, total, total, gpu.STREAM_BATCH)
+    C.synchronize()
+    probe = C.lanes_overlap_probe()
+    assert probe in ((0, 1) if not os.environ.get("ASDR_NO_LANES_PROBE") else (-1, 0, 1))
+    if not os.environ.get("ASDR_NO_LANES"):
+        assert C.lanes_enabled() == (probe != 0)
+        assert (C.lane_calls() > 0) == (probe != 0)
+    wc = hip.download(dC, (n, total, 128), np.int16)
+    assert np.array_equal(wc[:, :3], wa[:, :3])
+    for s in foreign:
+        s.synchronize()
+    hip.free_all(); A.close(); B.close(); C.close()

@@ -117,13 +117,13 @@ def test_shard_handles_with_device_local_pointers_lanes_and_capture(gpu):
         dO = torch.empty((hi - lo, nb, 128), dtype=torch.int16, device=dev)
         torch.cuda.synchronize(dev)
         v = sh.shard(g)
-        assert v.lanes_overlap_probe() in (0, 1), "the lanes probe did not run on device %d" % g
         for b in range(nb):                            # one block per call, on the shard's own streams
             v.update_device_strided(dI.data_ptr() + b * 256, dQ.data_ptr() + b * 256, dO.data_ptr() + b * 256, 1, nb, nb, gpu.STREAM_BATCH)
         outs.append((v, dO, lo, hi))
     got = np.empty((n, nb, 128), np.int16)
     for v, dO, lo, hi in outs:
         v.synchronize()
+        assert v.lanes_overlap_probe() in (0, 1), "the lanes probe did not run on this shard's device"
         if v.lanes_enabled():
             assert v.lane_calls() >= nb - 1, "shard on device %d never used its lanes" % v_dev(v, gpu)
         got[lo:hi] = dO.cpu().numpy()

@@ -605,3 +605,46 @@ def test_als_as_a_launch_of_its_own(gpu, ao):
         pos += T
     compare_status(gpu, batch, orcs)
     batch.close()
+
+
+def test_short_division_of_the_unit_gain_envelope_is_exhaustively_exact(gpu, tmp_path):
+    """The blanker envelope of unit-gain waves (asdr_kernels.hip fast_sqrt1_short) replaces the IEEE division inside the reference's
+    fast_sqrt_f32 (AudioSDR.h:434-446) by v_rcp_f32 + a Newton step + a residual correction.  v_rcp_f32 is a hardware approximation, so the
+    proof is an exhaustive run ON the GPU: tools/ubench/sqrt_div_check.hip compares the RESULT for all 2^31 non-negative finite floats.
+    They must agree for x = 0 and for every x >= 1e-30 (unit-gain samples give x = 0 or x >= 9.3e-10)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "ubench", "sqrt_div_check.hip")
+    exe = str(tmp_path / "sqrt_div_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", src, "-o", exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
+    m = re.search(r"mismatching inputs: (\d+) of \d+; \|x\| range of mismatches: \[(\S+) \(0x([0-9a-f]+)\), (\S+) \(0x([0-9a-f]+)\)\]", out)
+    assert m, out
+    n_bad, lo_bits, hi_bits = int(m.group(1)), int(m.group(3), 16), int(m.group(5), 16)
+    if n_bad:
+        assert lo_bits > 0, "x = 0 differs: %s" % out
+        assert np.uint32(hi_bits).view(np.float32) < 1e-30, "a mismatch at or above 1e-30: %s" % out
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_case_against_the_default_oracle_and_no_pll_stall(gpu, ao, name):
+    """Every GPU test above compares with an oracle that models the product's ONE defined difference in the signal path -- the SAM PLL's
+    bounded phase wrap (oracle/asdr_oracle.py PRODUCT_PLL_BOUND).  This test takes that switch away: every case of
+    tests/cases.py in one multi-block call against the DEFAULT oracle (the reference's own unbounded loops, AudioSDR.cpp:735-736),
+    bit for bit, and the oracle reports that none of its wrap loops ever reached the state in which the reference would hang
+    (ao_pll_stalled() == 0) -- i.e. the defined difference is inert on everything the suite feeds the chain."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, n_blk, setters, sig = CASES[name]
+    I, Q = make_iq(n_ch, n_blk, **sig)
+    batch = gpu.AudioSDRBatch(n_ch)
+    orcs = [ao.OracleSDR(pll_wrap_bound=False) for _ in range(n_ch)]
+    apply_setters(batch, orcs, setters)
+    got = batch.update(I, Q)
+    for c in range(n_ch):
+        want = orcs[c].update(I[c], Q[c]).reshape(n_blk, 128)
+        assert np.array_equal(got[c], want), "%s ch %d" % (name, c)
+        assert orcs[c].pll_stalled() == 0, "%s ch %d: a reference wrap loop would not have ended" % (name, c)
+    compare_status(gpu, batch, orcs)
+    batch.close()

@@ -372,6 +372,7 @@ def test_pll_phase_update_as_one_fma(ao):
 def test_scale_division_and_f32_interpolation_are_exact(ao):
     L = ao.lib()
     assert L.ao_check_scale_division() == 0        # s/32767.0 for all int16
+    assert L.ao_check_scale_unit_gain() == 0       # ... and the binary32 form the kernels use at input gain 1.0
     assert L.ao_check_sin_interp_f32() == 0        # sin_lut in float32 == reference's mixed form, all 65,536 phases
 
 

@@ -18,13 +18,14 @@ mkdir -p "$OUT"
 cd "$ROOT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-robustness --no-host-path > "$OUT/stats.log" 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-robustness --no-host-path --no-configs > "$OUT/stats.log" 2>&1 )
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cs" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-robustness --no-host-path --caller-stream > "$OUT/stats_cs.log" 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cs" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-robustness --no-host-path --no-configs --caller-stream > "$OUT/stats_cs.log" 2>&1 )
 f=$(find "$OUT/stats_cs" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_caller_stream.csv"
 bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc" > "$OUT/pmc.log" 2>&1
+bash tools/prof_pmc3.sh "gpurun_out/$TAG/pmc_mix" > "$OUT/pmc_mix.log" 2>&1
 export BENCH_CONFIGS_NO_LANES=1   # the counter passes and kernel traces of C3 / C4: strict stream order (one launch form per kernel name)
 bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c3" "tools/bench_configs.py c3: SAM, 262144 channels x 1 block per launch" python3 "$ROOT/tools/bench_configs.py" c3 > "$OUT/pmc_c3.log" 2>&1
 bash tools/prof_pmc2.sh "gpurun_out/$TAG/pmc_c4" "tools/bench_configs.py c4: mixed modes + ALS, 131072 channels x 1 block per launch" python3 "$ROOT/tools/bench_configs.py" c4 > "$OUT/pmc_c4.log" 2>&1
@@ -42,5 +43,5 @@ for c in c3 c4; do
   f=$(find "$OUT/stats_$c" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${c}_kernel_stats.csv"
 done
-rm -rf "$OUT/stats" "$OUT/stats_cs" "$OUT/stats_c3" "$OUT/stats_c4" "$OUT"/pmc/*/ "$OUT"/pmc_c3/*/ "$OUT"/pmc_c4/*/
+rm -rf "$OUT/stats" "$OUT/stats_cs" "$OUT/stats_c3" "$OUT/stats_c4" "$OUT"/pmc/*/ "$OUT"/pmc_mix/*/ "$OUT"/pmc_c3/*/ "$OUT"/pmc_c4/*/
 cat "$OUT/bench.json"; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/configs_1gpu.jsonl"; cat "$OUT/bench_c4.json" "$OUT/bench_c5.json" "$OUT/bench_c5_share.json"

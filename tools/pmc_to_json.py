@@ -14,7 +14,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if k.startswith("asdr_") and "reset" not in k:
+            if k.startswith("asdr_") and "reset" not in k and "spin" not in k:
                 per[(k.split("(")[0], row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
     for (k, d, name), v in per.items():
         acc[k][name].append(v)

@@ -10,7 +10,7 @@ LABEL=${2:-"bench.py C2, 65536 channels x 1 block per launch"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ $# -ge 2 ]; then shift 2; else shift $#; fi
 # the command stays an array, so a repository path with spaces survives; the program itself follows `--` (python3 <script>)
-if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python3 "$ROOT/bench.py" --steps 40 --warmup 10 --settle 0 --no-cpu-baseline --no-robustness --no-host-path --caller-stream); fi
+if [ $# -gt 0 ]; then CMD=("$@"); else CMD=(python3 "$ROOT/bench.py" --steps 40 --warmup 10 --settle 0 --no-cpu-baseline --no-robustness --no-host-path --no-configs --caller-stream); fi
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 p() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$n" -- "${CMD[@]}" > "$ROOT/$OUT/$n.log" 2>&1; }
