@@ -59,6 +59,12 @@
 #ifndef ASDR_UNIT_SCALE
 #define ASDR_UNIT_SCALE 1   /* waves whose input gains are all 1.0 scale their samples with two binary32 operations (scale8); 0: always the binary64 form */
 #endif
+#ifndef ASDR_C16
+#define ASDR_C16 0        /* large direct one-block launches of SSB-class groups take the 16-waves-per-CU kernel (asdr_update_kernel_c16); environment ASDR_C16 overrides */
+#endif
+#ifndef ASDR_C16_MIN_WAVES
+#define ASDR_C16_MIN_WAVES 64
+#endif
 #ifndef ASDR_MW_MIN_WAVES
 #define ASDR_MW_MIN_WAVES 64
 #endif
@@ -469,6 +475,8 @@ __device__ __forceinline__ void store_int4_nt(int4 *p, int4 v) {
   const i4v tv = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(tv, reinterpret_cast<i4v *>(p));
 }
+// the even entries of eight (the 16-waves-per-CU form keeps the mixer's phases of even samples only)
+__device__ __forceinline__ void store4e(float *p, const float *v) { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[2], v[4], v[6]); }
 __device__ __forceinline__ void store8(float *p, const float *v) {
   float4 *q = reinterpret_cast<float4 *>(p);
   q[0] = make_float4(v[0], v[1], v[2], v[3]); q[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -1073,6 +1081,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // behind it.  The IF rows cross in xch_sam; the lock flag in the status word.
   // ROLE 6: the whole chain up to and including the AGC for channels whose (short) ALS filter runs as a launch of its own
   // (asdr_als_kernel): the post-AGC row goes to the ALS input ring instead of through the filter and the output stage.
+  constexpr bool C16 = (STRIDE == 320);   // the 16-waves-per-CU form (see below, where the block loop starts)
   constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4 || ROLE == 6), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5 || ROLE == 6),
                  DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6);
   constexpr bool TO_ALS = (ROLE == 6);
@@ -1125,7 +1134,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const bool is_ssb = DO2 && ((mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                               (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode));
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
-  const bool is_am = (mode == ASDR_AMmode), is_sam = (HAS_SAM || ROLE >= 4) && (mode == ASDR_SAMmode);
+  const bool is_am = !C16 && (mode == ASDR_AMmode), is_sam = (HAS_SAM || ROLE >= 4) && (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
   const bool nb_en = DO1 && (pflags & ASDR_F_NB_EN), af_en = DO3 && (pflags & ASDR_F_AF_EN), agc_en = DO3 && (pflags & ASDR_F_AGC_EN);
   const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
@@ -1144,7 +1153,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // (Not the ALS instantiations: their loop-free builds fail the ALS parity tests from the first block after a schedule change -- ALS tap
   // 1 % off with every earlier tap exact -- for a reason not found yet; they keep the loop.  profiles/README.md, round 5.)
   constexpr bool ONEBLK = !HAS_ALS && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
-  constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);   // the unit-gain scale (scale8): the loop-free instantiations have the registers for its second code path
+  constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);
+  // C16 (round 5, asdr_update_kernel_c16): the same chain on 320-float rows and <= 128 VGPRs -- 10,240 B of LDS per wave, FOUR waves per
+  // SIMD = 16 per CU.  Direct one-block launches of ONE SSB-class settings group without stage taps (the launcher's choice: mode and
+  // flags are launch-uniform scalars, the AM / SAM / unknown-mode paths are compiled out).  What fits 320 floats and 128 registers:
+  //   * the mixer's phase row holds the EVEN samples' phases only (64 floats at PH): an odd one is one recurrence step from its neighbour
+  //   * the Hilbert FIR runs as TWO passes of 64 outputs over a 318-float window of the history, shifted down by 64 in between
+  //   * the AGC's gain table is read through L1 from its HBM row (no LDS copy)
+  //   * nothing is prefetched across a phase that does not need it (Hilbert ring, oscillator pairs, IF / audio / AGC state), and the blanker
+  //     keeps the oldest block RAW across its sequential pass (scaled again for the output)
+  static_assert(!C16 || (ONEBLK && UNIFORM && !HAS_ALS && !HAS_SAM && WAVES == 1 && ROLE == 0), "the 16-waves-per-CU form is the plain uniform one-block kernel");   // the unit-gain scale (scale8): the loop-free instantiations have the registers for its second code path
 #pragma unroll 1
   for (int blk = 0; blk < (ONEBLK ? 1 : a.n_blocks); ++blk) {
     // Per-iteration opaque copies of the lane coordinates: stops LICM from hoisting every per-lane address
@@ -1261,6 +1279,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #endif
 #pragma unroll
       for (int r = 0; r < 5; ++r) mkc[r] = mrow[8 * r];   // codes of the carried mask[128..265]
+      if constexpr (C16) {   // all five collapse into one word here (all ones or not); see the quiet test
+        const uint32_t all1 = (mkc[0] & mkc[1] & mkc[2] & mkc[3] & mkc[4]) == 0x01010101u && (mkc[0] | mkc[1] | mkc[2] | mkc[3] | mkc[4]) == 0x01010101u ? 0x01010101u : 0u;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) mkc[r] = all1;
+      }
     }
     // The input rows come LAST: with the blanker on, this block's samples only go into the ring (the chain works on the block that
     // arrived two calls ago), so nothing below waits for them until that store -- and memory waits count loads in order.
@@ -1303,6 +1326,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float4 if_s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float if_cf[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     bool if_pre = false;
+    auto load_if_rows_early = [&]() {
+      if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
+      const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
+#pragma unroll
+      for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
+      if_pre = true;
+    };
     TL(1);
     // ---- impulse noise blanker, AudioSDR.cpp:606-650 ------------------------------------------------------
     // Buffer coordinates as in the reference: [0,128) oldest, [128,256) middle, [256,384) newest.  The 3-slot ring
@@ -1320,6 +1350,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // of lanes s8 >= 1).  beta * envelope goes to the B row (index NB_B + t) for the sequential pass; the envelopes
       // themselves stay in registers for the threshold test.
       const bool own_tail = (s8 >= 1);
+      if (C16 && nb_en) {   // the 16-waves-per-CU form sends the newest block to its ring slot FIRST: 16 registers less across the envelope pass
+        int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + kA);
+        store_int4_nt(ni, ri[0].v); store_int4_nt(ni + 8, ri[1].v); store_int4_nt(ni + 16, rq[0].v); store_int4_nt(ni + 24, rq[1].v);
+        if (lead) { S->nb_gain[ns_new][0] = gain_i; S->nb_gain[ns_new][1] = gain_q; }
+      }
       // (every gain the wave's ring slots arrived with is 1.0: the two-operation binary32 scale, see scale8)
       const bool unit_ring = UNIT_OK && __all(g_oi == 1.0f && g_oq == 1.0f && (!nb_en || (g_mi == 1.0f && g_mq == 1.0f)));
       // (the choice is made per scale call and per GROUP OF FOUR envelopes: a test per envelope keeps the divisions of a piece from interleaving,
@@ -1333,6 +1368,38 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           for (int j = 0; j < 4; ++j) mg4[j] = fast_sqrt1(pw4[j]);
         }
       };
+      if constexpr (C16) {
+        // The 16-waves-per-CU form keeps the oldest block RAW across the sequential pass (16 registers instead of 32: it is scaled again
+        // for the output below) and takes the pieces in an order that lets every scaled piece die right behind its envelopes: middle
+        // block's first pieces | oldest block's second pieces (the re-scanned envelopes) | middle block's second pieces.
+        auto mid_piece = [&](int h) {
+          float vim[8], vqm[8], bm8[8], pw[8];
+          scale8(rmi[h].s, (double)g_mi, vim, unit_ring); scale8(rmq[h].s, (double)g_mq, vqm, unit_ring);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pw[j] = vim[j] * vim[j] + vqm[j] * vqm[j];
+          env4(pw, mgm + 8 * h); env4(pw + 4, mgm + 8 * h + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bm8[j] = K.nb_beta * mgm[8 * h + j];
+          if (nb_en) store8(L + NB_B + 50 + kA + 64 * h, bm8);
+        };
+        mid_piece(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (own_tail) {
+          float tio[8], tqo[8], bm8[8], pw[8];
+          scale8(roi[1].s, (double)g_oi, tio, unit_ring); scale8(roq[1].s, (double)g_oq, tqo, unit_ring);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pw[j] = tio[j] * tio[j] + tqo[j] * tqo[j];
+          env4(pw, mgt); env4(pw + 4, mgt + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bm8[j] = K.nb_beta * mgt[j];
+          if (nb_en) { if (s8 >= 2) store8(L + kA - 12, bm8); else *reinterpret_cast<float4 *>(L) = make_float4(bm8[4], bm8[5], bm8[6], bm8[7]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mgt[j] = 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mid_piece(1);
+      } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float vim[8], vqm[8], bm8[8], pw[8];
@@ -1358,7 +1425,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #pragma unroll
         for (int j = 0; j < 8; ++j) mgt[j] = 0.0f;
       }
-      if (nb_en) {   // newest block -> third ring slot, with its gains (blanker-off channels pass their own input: see above)
+      }   // !C16
+      if (nb_en && !C16) {   // newest block -> third ring slot, with its gains (blanker-off channels pass their own input: see above)
         int4 *ni = reinterpret_cast<int4 *>(hist + ns_new * 256 + kA);
 #ifndef ASDR_TEMPORAL_RINGS
         store_int4_nt(ni, ri[0].v); store_int4_nt(ni + 8, ri[1].v); store_int4_nt(ni + 16, rq[0].v); store_int4_nt(ni + 24, rq[1].v);
@@ -1374,7 +1442,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       TL(2);
-      if (DO1 && ABL_ON(ABL_IF) && WAVES == 1) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
+      if (DO1 && ABL_ON(ABL_IF) && WAVES == 1 && !C16) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
                                             // (not in the multi-wave SAM instantiation: no registers to spare)
         if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
         const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
@@ -1401,6 +1469,36 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float bm[8];
         load8(Lc + NB_B + 2, bm);
         int c_tail = 0;   // first chunk of the average-only loop below
+        if constexpr (C16) {
+          // The 16-waves-per-CU form of both loops: the averages replace the chunk IN its registers (no second array), the phases of the
+          // even samples only are kept: 20 registers instead of 32.  Same operations per sample.
+          float bn[8];
+          const int n_both = chain_phase ? 16 : 0;
+#pragma unroll 1
+          for (int c = 0; c < 22; c += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              float *cur = half ? bn : bm, *nxt = half ? bm : bn;
+              load8(Lc + NB_B + 2 + 8 * ((c + half < 21) ? c + half + 1 : 21), nxt);
+              if (c < n_both) {   // (wave-uniform)
+                float pe[4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const float a0 = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; cur[u] = a0;
+                  if ((u & 1) == 0) pe[u >> 1] = phase;
+                  const float t = phase + inc, tw = t + wrapv;
+                  phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+                }
+                store4(Lc + PH + 4 * (c + half), pe);
+              } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float a0 = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; cur[u] = a0; }
+              }
+              store8(Lc + NB_B + 2 + 8 * (c + half), cur);
+            }
+          }
+          c_tail = n_both;
+        } else {
         if (chain_phase) {
         c_tail = 16;
         // Both chains in ONE basic block (the scheduler interleaves them).  Every mode's shift is downwards (inc < 0): then the
@@ -1427,7 +1525,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                 asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(phase) : "v"(m), "v"(tw), "v"(t));
 #endif
               }
-              store8(Lc + PH + 8 * (c + half), pv);
+              if constexpr (C16) store4e(Lc + PH + 4 * (c + half), pv); else store8(Lc + PH + 8 * (c + half), pv);
               store8(Lc + NB_B + 2 + 8 * (c + half), av);
             }
           }
@@ -1443,7 +1541,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               const float t = phase + inc, tw = t + wrapv;
               phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
             }
-            store8(Lc + PH + 8 * c, pv);
+            if constexpr (C16) store4e(Lc + PH + 4 * c, pv); else store8(Lc + PH + 8 * c, pv);
             store8(Lc + NB_B + 2 + 8 * c, av);
 #pragma unroll
             for (int u = 0; u < 8; ++u) bm[u] = bn[u];
@@ -1462,6 +1560,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             store8(Lc + NB_B + 2 + 8 * (c + half), av);
           }
         }
+        }   // !C16
         if (en) Sc->nb_avg = avg;
         if (want_phase && c_tail != 0) {
           // (the word's offset is formed HERE: hoisted in front of the block loop as a 64-bit select it costs the multi-wave SAM instantiation a spill)
@@ -1514,6 +1613,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
       }
       TL(3);
+      if (C16 && DO1 && ABL_ON(ABL_IF)) { load_if_rows_early(); }   // (the envelopes are dead: the IF pipeline's state and coefficients are asked for here)
       // Quiet fast path (wave-uniform): if no channel of the wave has a detection in this block and every carried mask
       // entry is 1.0, the mask stays all ones -- no zeroing, no trailing ramp, the carried row is unchanged and the output is
       // the oldest block times 1.0 (x * 1.0f == x for every float) -- so counts / decode / zero / ramp / encode / multiply are skipped.
@@ -1523,11 +1623,22 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (nb_en && lead) status = (status & ~ASDR_S_NB_DETECTED) | (ch_det ? ASDR_S_NB_DETECTED : 0u);
 #pragma unroll
       for (int r = 0; r < 5; ++r) nb_quiet = nb_quiet && (mkc[r] == 0x01010101u);
+      if constexpr (C16) {   // (the 16-waves-per-CU form: the five code words are not kept across the block -- the general path, rare, asks for them again)
+        if (__any(!nb_quiet) && nb_en) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r) mkc[r] = mrow[8 * r];
+        }
+      }
 #ifdef ASDR_NB_ALWAYS_SLOW
       const bool nb_slow = true;
 #else
       const bool nb_slow = __any(!nb_quiet);
 #endif
+      if constexpr (C16) {   // the oldest block, scaled for the output (see the envelope pass)
+        asm volatile("" : "+v"(roi[0].v.x), "+v"(roi[1].v.x), "+v"(roq[0].v.x), "+v"(roq[1].v.x));   // (a NEW value chain: nothing of the first scale is kept alive)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { scale8(roi[h].s, (double)g_oi, vio + 8 * h, unit_ring); scale8(roq[h].s, (double)g_oq, vqo + 8 * h, unit_ring); }
+      }
       if (nb_slow) {
         // General path, on the mask's BYTE CODES (0..6 <-> {0, 1, .933, .75, .5, .25, .067}: the only values the mask ever holds,
         // AudioSDR.cpp:608, 623, 630): the carried codes go to LDS as they came from HBM, zeroing and the trailing ramp write code
@@ -1703,7 +1814,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // the cached sin/cos pairs of this lane's pieces likewise (local-oscillator cache hit: they come from L2)
     float lo_c[16], lo_s[16];
     DEFINE_ALL_PATHS(lo_c, 16); DEFINE_ALL_PATHS(lo_s, 16);
-    if (RING_PREFETCH && lo_hit) {
+    // The 16-waves-per-CU form: the cached pairs are the same for all 8 channels of the wave -- ONE 16-byte piece per lane (lane l: words
+    // 4 l .. 4 l + 3 of the entry's 128 cos | 128 sin), requested here and parked, behind the IF pipeline, in the phase areas of channels
+    // 0..3 (cos in 0 and 1, sin in 2 and 3: the layout the wave-uniform mixer stages its own pairs in; a cache hit leaves them unused).
+    float lo4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (C16 && lo_hit) load4(lo_rd->c + 4 * lane_i, lo4);
+    if (!C16 && RING_PREFETCH && lo_hit) {
       if (ROLE == 2) {   // written by another workgroup during this launch: `sc1` loads
         v4f c4[4], s4[4];
         xch_load4x4(lo_rd->c + kF, c4[0], c4[1], c4[2], c4[3]); xch_load4x4(lo_rd->s + kF, s4[0], s4[1], s4[2], s4[3]);
@@ -1726,6 +1842,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       biquad_pipe<PIPE_PK>(L + (iq ? W1 : W0), true, st, if_cf, sv);
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
     }
+    if (C16 && lo_hit) store4(lds + (lane_i >> 4) * STRIDE + PH + ((4 * lane_i) & 63), lo4);   // word i of [cos | sin]: row i >> 6, place i & 63
     WAVE_SYNC();
     TL(5);
     if (DO1) { TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1); }
@@ -1843,7 +1960,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             const float t = phase + minc, tw = t + wrapv;
             phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
           }
-          store8(L + PH + i, pv);
+          if constexpr (C16) store4e(L + PH + (i >> 1), pv); else store8(L + PH + i, pv);
         }
         if (is_ssb) S->phase_ssb = phase; else S->phase_am = phase;
         mphase_end = phase;
@@ -1863,13 +1980,28 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const uint32_t inc_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(minc));
     const bool mix_uni = __all(do_mix && __float_as_uint(mphase) == ph_first && __float_as_uint(minc) == inc_first);
     TL(6);
+    // One step of the phase recurrence (AudioSDR.h:513-518), exactly as the sequential loops form it: the 16-waves-per-CU form keeps the
+    // even samples' phases and takes an odd one from its even neighbour.
+    auto phase_step = [&](float p, float inc) -> float {
+      const bool up = !(inc < 0.0f);
+      const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
+      const uint32_t flip = up ? 0u : 0x80000000u;
+      const float t = p + inc, tw = t + wrapv;
+      return (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
+    };
     if (ABL_ON(ABL_MIX) && mix_uni && !lo_hit) {   // sin/cos of the wave's 128 phases, two per lane
-      const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane);
-      const float ph2[2] = {p2.x, p2.y};
+      float ph2[2];
+      if constexpr (C16) { ph2[0] = lds[PH + lane_i]; ph2[1] = phase_step(ph2[0], minc); WAVE_SYNC(); }   // (every lane has read channel 0's phases: the pairs below overwrite them)
+      else { const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane); ph2[0] = p2.x; ph2[1] = p2.y; }
       float c2[2], s2[2];
       sincos_batch<2>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
+      if constexpr (C16) {   // 128 cos in the 64-float phase areas of channels 0 and 1, 128 sin in those of channels 2 and 3
+        *reinterpret_cast<float2 *>(lds + (lane_i >> 5) * STRIDE + PH + ((2 * lane_i) & 63)) = make_float2(c2[0], c2[1]);
+        *reinterpret_cast<float2 *>(lds + (2 + (lane_i >> 5)) * STRIDE + PH + ((2 * lane_i) & 63)) = make_float2(s2[0], s2[1]);
+      } else {
       *reinterpret_cast<float2 *>(lds + STRIDE + PH + 2 * lane) = make_float2(c2[0], c2[1]);
       *reinterpret_cast<float2 *>(lds + 2 * STRIDE + PH + 2 * lane) = make_float2(s2[0], s2[1]);
+      }
       WAVE_SYNC();
     }
     // complex multiply by e^{j phase}, in place on this lane's own samples; the mixed I also goes to its 2-slot ring
@@ -1880,6 +2012,45 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const bool qn_direct = QN_DIRECT_K && is_ssb;
     float qn[16];   // own pieces (samples kF + 32m + j at [4m + j]) of the mixed Q
     DEFINE_ALL_PATHS(qn, 16);
+    if constexpr (C16) {
+      // The 16-waves-per-CU form: TWO copies of the multiply, chosen once per wave -- pairs staged in the phase areas (cache hit or
+      // wave-uniform phases) | per-channel lookups.  The second is the register-hungry one (binary64 table phases, gathers) and runs
+      // WITHOUT the Hilbert ring's 32 prefetched registers: they are given up in front of it and asked for again behind it.
+      if (ABL_ON(ABL_MIX) && do_mix) {
+        // (written out twice by a macro: as a generic lambda taking the staged / per-channel choice, the mixed-Q array it fills went to scratch)
+#define C16_MIX_LOOP(STAGED)                                                                                                                  \
+          _Pragma("unroll")                                                                                                                   \
+          for (int m = 0; m < 4; ++m) {                                                                                                       \
+            float cc[4], sn[4], vi[4], vq[4], mi[4], mq[4];                                                                                   \
+            load4(L + W0 + kF + 32 * m, vi); load4(L + W1 + kF + 32 * m, vq);                                                                 \
+            if (STAGED) {                                                                                                                     \
+              load4(lds + (m >> 1) * STRIDE + PH + 32 * (m & 1) + kF, cc); load4(lds + (2 + (m >> 1)) * STRIDE + PH + 32 * (m & 1) + kF, sn); \
+            } else {                                                                                                                          \
+              float ph[4];                                                                                                                    \
+              const float2 e2 = *reinterpret_cast<const float2 *>(L + PH + ((kF + 32 * m) >> 1));                                             \
+              ph[0] = e2.x; ph[1] = phase_step(e2.x, minc); ph[2] = e2.y; ph[3] = phase_step(e2.y, minc);                                     \
+              sincos_batch<4>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);                         \
+            }                                                                                                                                 \
+            _Pragma("unroll")                                                                                                                 \
+            for (int j = 0; j < 4; ++j) {                                                                                                     \
+              mi[j] = vi[j] * cc[j] - vq[j] * sn[j];                                                                                          \
+              mq[j] = vq[j] * cc[j] + vi[j] * sn[j];                                                                                          \
+            }                                                                                                                                 \
+            if (qn_direct) {                                                                                                                  \
+              _Pragma("unroll")                                                                                                               \
+              for (int j = 0; j < 4; ++j) qn[4 * m + j] = mq[j];                                                                              \
+            } else { store4(L + W0 + kF + 32 * m, mi); store4(L + W1 + kF + 32 * m, mq); }                                                    \
+            store4_nt(hi_ring + hs * 128 + 32 * m, mi);                                                                                       \
+          }
+        if (lo_hit || mix_uni) { C16_MIX_LOOP(true) }
+        else {
+          DEFINE_ALL_PATHS(hq_o, 16); DEFINE_ALL_PATHS(hq_m, 16);   // (given up: nothing of the prefetch is live across the lookups)
+          C16_MIX_LOOP(false)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { load4(hq_ring + hs * 128 + 32 * m, hq_o + 4 * m); load4(hq_ring + (hs ^ 1u) * 128 + 32 * m, hq_m + 4 * m); }
+        }
+      }
+    } else
     if (ABL_ON(ABL_MIX) && do_mix) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -1933,6 +2104,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // MW: the two audio-duty waves (rel 1, 2) run the cascades of 16 channels each, lane = (channel of the half) x 4 + stage
     const bool mw_audio_duty = (MW_SHARE & 1) && (mw_rel == 1 || mw_rel == 2);
     ChanSmall *mw_af_S = S;
+    auto load_af_agc_state = [&]() {
     if (ABL_ON(ABL_AF) && af_en) {
       if constexpr ((MW_SHARE & 1) != 0) {
         if (mw_audio_duty) {
@@ -1954,6 +2126,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       agc_gain_in = S->agc_gain; agc_old0 = S->agc_old_abs; agc_hc0 = S->agc_hang_counter; agc_carrier0 = S->am_carrier;
       agc_tab_idx = P.agc_table;
     }
+    };
+    if constexpr (!C16) load_af_agc_state();   // (the 16-waves-per-CU form asks behind the FIR: its registers are the FIR's)
     TL(7);
     // ---- SSB/CW/WSPR: 257-tap folded Hilbert on Q, I delayed 128, AudioSDR.cpp:89-118 ----------------------
     if (__any(is_ssb)) {
@@ -1962,6 +2136,57 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int m = 0; m < 4; ++m) load4(L + W1 + kF + 32 * m, qn + 4 * m);   // mixed Q, written above by other lanes too (same wave: LDS is in order)
       }
       WAVE_SYNC();   // every lane has consumed W0/W1/PH: the history may now overlay them
+      if constexpr (C16) {
+        // The 16-waves-per-CU form: 320-float rows cannot hold the 383-sample history at once.  Output i reads x[i + 1 .. i + 255]: outputs
+        // 0..63 need x[1..318], outputs 64..127 need x[65..382] -- the same 318-float window 64 samples on.  Pass 1 on x[1..318] (word m - 1
+        // as ever), the rows move down by 64 words, the block's last 64 samples fill the top, pass 2 runs the SAME code on the same words.
+        // Every lane computes 8 outputs per pass (4 pairs: 11-pair register windows instead of 15).
+        // (the ring's two blocks were requested in front of the IF pipeline, like the other forms: 32 registers the pipeline has to spare)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = kF + 32 * m + j;
+            if (k >= 1) L[XP + k - 1] = hq_o[4 * m + j];
+            L[XP + 127 + k] = hq_m[4 * m + j];
+            if (k < 63) L[XP + 255 + k] = qn[4 * m + j];   // x[256 + k], k < 63: what pass 1 reads of this block
+          }
+          store4_nt(hq_ring + hs * 128 + 32 * m, qn + 4 * m);   // newest replaces oldest in the HBM ring
+        }
+        if (lead) S->hil_slot = hs ^ 1u;
+        WAVE_SYNC();
+        TL(8);
+        v2f fa[4], fb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fa[e] = (v2f){0.0f, 0.0f}; fb[e] = (v2f){0.0f, 0.0f}; }
+        if (ABL_ON(ABL_HIL)) hilbert_fir<0, 4>(L, 4 * s8, fa);   // outputs 8 s8 + 2e, + 1
+        WAVE_SYNC();                                               // pass 1 has read everything it needs
+        {
+          float t[32];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) load4(L + XP + 64 + 32 * s8 + 4 * q, t + 4 * q);
+          WAVE_SYNC();                                             // (every lane's reads before any lane's writes)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) store4(L + XP + 32 * s8 + 4 * q, t + 4 * q);   // word j <- word j + 64: x[65 + j] at j
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int k = kF + 32 * m + j; if (k >= 63 && k < 127) L[XP + 191 + k] = qn[4 * m + j]; }   // x[256 + k] at word 256 + k - 65
+        }
+        WAVE_SYNC();
+        if (ABL_ON(ABL_HIL)) hilbert_fir<0, 4>(L, 4 * s8, fb);   // the same window 64 samples on: outputs 64 + 8 s8 + 2e, + 1
+        WAVE_SYNC();                                               // all history reads done: W1 may overwrite it
+        TL(9);
+        load_af_agc_state();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);   // delayed I = previous block's mixed I (:111)
+        *reinterpret_cast<float4 *>(L + W1 + 8 * s8) = make_float4(fa[0][0], fa[0][1], fa[1][0], fa[1][1]);
+        *reinterpret_cast<float4 *>(L + W1 + 8 * s8 + 4) = make_float4(fa[2][0], fa[2][1], fa[3][0], fa[3][1]);
+        *reinterpret_cast<float4 *>(L + W1 + 64 + 8 * s8) = make_float4(fb[0][0], fb[0][1], fb[1][0], fb[1][1]);
+        *reinterpret_cast<float4 *>(L + W1 + 64 + 8 * s8 + 4) = make_float4(fb[2][0], fb[2][1], fb[3][0], fb[3][1]);
+        WAVE_SYNC();
+      } else {
       if (is_ssb) {
         // history sample x[m'] with m' = B + k (B = 0: two blocks back = ring slot hs, 128: previous = slot hs^1,
         // 256: this block) is stored at L[XP + m' - 1] (x[0] is never used): natural order shifted by one float, so
@@ -2027,6 +2252,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int e = 0; e < FIR_NE; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
       }
       if (ROLE == 2) __syncthreads(); else WAVE_SYNC();   // (the helper's half is in W1 as well)
+      }   // !C16
       if (is_ssb) {   // sideband combine (:115-118) with the delayed I
         // x - y == x + (-y) exactly: the sideband is a sign bit, not a select between two forms (a wave-uniform
         // `sub_q ? a - b : a + b` per sample compiles to a scalar branch cascade per sample in the uniform-key instantiations)
@@ -2148,8 +2374,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       agc_al_a = P.agc_alpha_att; agc_be_a = P.agc_beta_att; agc_al_r = P.agc_alpha_rel; agc_be_r = P.agc_beta_rel;
       agc_sg = P.agc_static_gain; agc_hang = P.agc_hang_count;
       const float *gtab = a.agc_tab + (size_t)agc_tab_idx * ASDR_AGC_TAB_ROW;
+      if constexpr (!C16) {   // (the 16-waves-per-CU form reads the table through L1 where it needs it: no LDS copy)
 #pragma unroll
       for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) agc_t4[r] = reinterpret_cast<const float4 *>(gtab)[q]; }
+      }
     }
     // ---- audio IIR filter, AudioSDR.cpp:149, 280-286: lanes s8 = 0..3 are the four stages ---------------------
     if constexpr ((MW_SHARE & 1) != 0) {
@@ -2181,7 +2409,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // Split into (a) the sequential envelope/hang recurrence, which records for every sample the envelope value
     // that governs its gain, and (b) a parallel pass that evaluates the static compressor and applies the gain.
     if (ABL_ON(ABL_AGC) && __any(agc_en)) {
-      const float *tab = L + AGC_TAB;
+      const float *tab = C16 ? a.agc_tab + (size_t)agc_tab_idx * ASDR_AGC_TAB_ROW : L + AGC_TAB;
       const float gain_in = agc_gain_in;
       // A QUIET block: in no channel of the wave does a sample exceed the envelope (the block's largest |x|, formed by all lanes:
       // piece maxima, then three DPP steps over the channel's eight lanes) and no hang counter can run out inside the block -- then
@@ -2214,8 +2442,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // (AM: twice the carrier level stands in for |x| of every sample, :407-409 -- the lead lane holds it)
       const bool agc_quiet = ASDR_AGC_QUIET_PATH && __all(!(agc_en && lead) || (agc_hc0 >= 128u && agc_hang >= 8u && !((is_am ? am_clamped : blockmax) > agc_old0)));
       if (agc_en && !agc_quiet) {   // stage the channel's gain table and the |x| rows in LDS
+        if constexpr (!C16) {
 #pragma unroll
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = agc_t4[r]; }
+        }
         store8(L + AGC_GV + kA, av16); store8(L + AGC_GV + kA + 64, av16 + 8);
       }
       if (!agc_quiet) WAVE_SYNC();
@@ -2306,7 +2536,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         }
         Sc->agc_old_abs = old_abs;
         Sc->agc_hang_counter = hc;
-        const float g_end = (gv < 0.0f) ? g_in : agc_compress(Lc + AGC_TAB, gv);
+        const float g_end = (gv < 0.0f) ? g_in : agc_compress(C16 ? tab : Lc + AGC_TAB, gv);
         Sc->agc_gain = g_end;
         return g_end;
       };
@@ -2498,12 +2728,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             const float t = phase + inc, tw = t + wrapv;
             phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
           }
-          store8(lds + PH + i, pv);
+          store8(lds + (C16 ? 0 : PH) + i, pv);   // (the block is done: in the 16-waves-per-CU form channel 0's first 128 words serve)
         }
         lo_wr->key_phase = __float_as_uint(start); lo_wr->key_inc = __float_as_uint(inc); lo_wr->phase_end = phase;
       }
       WAVE_SYNC();
-      const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane_i);
+      const float2 p2 = *reinterpret_cast<const float2 *>(lds + (C16 ? 0 : PH) + 2 * lane_i);
       const float ph2[2] = {p2.x, p2.y};
       float c2[2], s2[2];
       sincos_batch<2>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
@@ -2535,6 +2765,13 @@ ASDR_KERNEL(asdr_update_kernel_mixed, 8 * ASDR_STRIDE, ASDR_WAVES_PER_EU, ASDR_S
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel_one(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 0, true>(a, lds);
+}
+// ... the 16-waves-per-CU form (C16, asdr_update_body): 320-float rows = 10,240 B of LDS per wave, <= 128 VGPRs; direct one-block launches
+// of an SSB-class settings group without stage taps
+#define ASDR_C16_STRIDE 320
+extern "C" __global__ __launch_bounds__(64, 4) void asdr_update_kernel_c16(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_C16_STRIDE];
+  asdr_update_body<ASDR_C16_STRIDE, false, false, true, 1, 0, true>(a, lds);
 }
 // ... and its four-wave workgroup form (MW, asdr_update_body): 32 channels per workgroup, 49,664 B of rows + 1 KB of hand-off scratch -> 3 workgroups
 // = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
@@ -2945,8 +3182,17 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
   else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else {
     // the four-wave workgroup form: large direct one-block launches (ASDR_MW=0 / ASDR_MW_MIN_WAVES=<n> in the environment: measurements, tests)
-    static int mw_on = -1, mw_min = ASDR_MW_MIN_WAVES;
-    if (mw_on < 0) { const char *e = getenv("ASDR_MW"); mw_on = e ? atoi(e) : ASDR_MW; const char *m = getenv("ASDR_MW_MIN_WAVES"); if (m) mw_min = atoi(m); }
+    static int mw_on = -1, mw_min = ASDR_MW_MIN_WAVES, c16_on = ASDR_C16, c16_min = ASDR_C16_MIN_WAVES, c16_pad = 0;
+    if (mw_on < 0) {
+      const char *e = getenv("ASDR_MW"); mw_on = e ? atoi(e) : ASDR_MW; const char *m = getenv("ASDR_MW_MIN_WAVES"); if (m) mw_min = atoi(m);
+      const char *c = getenv("ASDR_C16"); if (c) c16_on = atoi(c); const char *cm = getenv("ASDR_C16_MIN_WAVES"); if (cm) c16_min = atoi(cm);
+      const char *cp = getenv("ASDR_C16_PAD"); if (cp) c16_pad = atoi(cp);
+    }
+    const uint32_t dm = a->direct_mode;
+    const bool ssb_class = dm == ASDR_USBmode || dm == ASDR_LSBmode || dm == ASDR_CW_USBmode || dm == ASDR_CW_LSBmode || dm == ASDR_WSPRmode;
+    if (uniform && c16_on && a->n_blocks == 1 && a->run_if == nullptr && a->direct_ch0 >= 0 && a->taps == nullptr && ssb_class && n_waves >= c16_min)
+      hipLaunchKernelGGL(asdr_update_kernel_c16, dim3(n_waves), dim3(64), (size_t)c16_pad, stream, *a);   // (c16_pad: dynamic LDS that takes the occupancy back, measurements)
+    else
     if (uniform && mw_on && a->n_blocks == 1 && a->run_if == nullptr && a->direct_ch0 >= 0 && n_waves >= mw_min)
       hipLaunchKernelGGL(asdr_update_kernel_mw, dim3((n_waves + ASDR_MW_WAVES - 1) / ASDR_MW_WAVES), dim3(64 * ASDR_MW_WAVES), 0, stream, *a);
     else

@@ -43,3 +43,10 @@ def test_main_kernel_keeps_its_occupancy_budget():
     allocation granule on gfx950 puts 12,944 B at 11 waves again: profiles/README.md (m))."""
     r = _resources("asdr_kernels.hip")["asdr_update_kernel"]
     assert r["VGPRs"] <= 168 and r["LDS Size [bytes/block]"] <= 12800, r
+
+
+def test_the_16_waves_per_cu_kernel_fits_its_budget():
+    """asdr_update_kernel_c16 exists to run FOUR waves per SIMD: <= 128 VGPRs without spills and <= 10,240 B of LDS per wave (16 workgroups x
+    10,240 B = the CU's 160 KB)."""
+    r = _resources("asdr_kernels.hip")["asdr_update_kernel_c16"]
+    assert r["VGPRs"] <= 128 and r.get("VGPRs Spill", 0) == 0 and r["LDS Size [bytes/block]"] <= 10240, r
