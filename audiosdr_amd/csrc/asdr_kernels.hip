@@ -68,6 +68,9 @@
 #ifndef ASDR_MW_MIN_WAVES
 #define ASDR_MW_MIN_WAVES 64
 #endif
+#ifndef ASDR_ONEBLK_ALS
+#define ASDR_ONEBLK_ALS 1   /* the loop-free form for the ALS instantiations too (short-filter uniform kernel, SAM post role with the filter); 0: measurements */
+#endif
 #ifndef ASDR_ONEBLK_ROLES
 #define ASDR_ONEBLK_ROLES 1   /* the SAM pre / post and the two-launch ALS pre roles (always one block per launch) compiled without the block loop */
 #endif
@@ -1150,9 +1153,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   uint32_t carry_hs = 0u;
   uint32_t *const my_prog = STREAM ? a.stream_prog + (ROLE - 1) * a.stream_waves + wave_g : nullptr;
 
-  // (Not the ALS instantiations: their loop-free builds fail the ALS parity tests from the first block after a schedule change -- ALS tap
-  // 1 % off with every earlier tap exact -- for a reason not found yet; they keep the loop.  profiles/README.md, round 5.)
-  constexpr bool ONEBLK = !HAS_ALS && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
+  // (The ALS instantiations' loop-free builds failed the ALS parity tests until the guard of the tap store-back was taken from an opaque copy
+  // of the flag word: a compiler issue, see there.)
+  constexpr bool ONEBLK = (!HAS_ALS || ASDR_ONEBLK_ALS) && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
   constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);
   // C16 (round 5, asdr_update_kernel_c16): the same chain on 320-float rows and <= 128 VGPRs -- 10,240 B of LDS per wave, FOUR waves per
   // SIMD = 16 per CU.  Direct one-block launches of ONE SSB-class settings group without stage taps (the launcher's choice: mode and
@@ -2650,8 +2653,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         WAVE_SYNC();
         als_compute<COMPACT, XB, AW, WH, SCR, ALS_OUT>(L, als_en, adaptive, notch, M, D, lam, s8, k0);
         WAVE_SYNC();
-        if (als_en) {
-#pragma unroll 1
+        // The guard is formed from an OPAQUE copy of the flag word.  From `als_en` itself, in the loop-free uniform instantiations, hipcc
+        // (ROCm 7.2) emits it with the wrong polarity -- `s_bitcmp0_b32 flags, 3; s_cselect_b64 m, -1, 0` (m = NOT als_en, shared with the
+        // staging branch above) and here `s_andn2_b64 vcc, exec, m; s_cbranch_vccnz <behind the stores>` -- so the taps never went back to
+        // their HBM rows and every block started from the taps of the first one: the ALS tap ~1 % off with every earlier tap exact (the
+        // round's "parity failure not understood"; found in the ISA, profiles/README.md).
+        uint32_t flags_again = pflags;
+        if constexpr (UNIFORM) asm volatile("" : "+s"(flags_again)); else asm volatile("" : "+v"(flags_again));
+        if (flags_again & ASDR_F_ALS_EN) {
+#pragma unroll
           for (int m = 0; m < NW; ++m) {
             const float *we = L + AW + ((kF + 32 * m) >> 1);
             const float2 e2 = *reinterpret_cast<const float2 *>(we), o2 = *reinterpret_cast<const float2 *>(we + WH);
@@ -2794,6 +2804,11 @@ ASDR_KERNEL(asdr_update_kernel_als_mixed, 8 * 516 + 260 + ASDR_ALS_LDS_PAD, ASDR
 // mode: the filter's rows fit the plain instantiation's 388 floats per channel -> 12 waves per CU
 ASDR_KERNEL(asdr_update_kernel_als_small, 8 * ASDR_ALS_STRIDE, ASDR_WAVES_PER_EU, ASDR_ALS_STRIDE, true, false, true, 1)
 ASDR_KERNEL(asdr_update_kernel_als_small_mixed, 8 * ASDR_ALS_STRIDE, ASDR_WAVES_PER_EU, ASDR_ALS_STRIDE, true, false, false, 1)
+// ... and the loop-free twin of the uniform short-filter kernel (one-block launches: every large batch)
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_update_kernel_als_small_one(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_ALS_STRIDE];
+  asdr_update_body<ASDR_ALS_STRIDE, true, false, true, 1, 0, true>(a, lds);
+}
 
 // SAM sub-range as three launches (asdr_launch_update): pre | PLL | post
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_pre_kernel(UpdateArgs a) {
@@ -3166,7 +3181,7 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
     hipLaunchKernelGGL(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     hipLaunchKernelGGL(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   }
-  else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform && ASDR_ONEBLK && ASDR_ONEBLK_ALS && a->n_blocks == 1 && a->run_if == nullptr) hipLaunchKernelGGL(asdr_update_kernel_als_small_one, dim3(n_waves), dim3(64), 0, stream, *a); else if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if ((variant == ASDR_KERNEL_SAM || variant == ASDR_KERNEL_SAM_ALS) && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
     if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);

@@ -84,7 +84,7 @@ CONFIGS = {
     "c2": dict(channels=65536, per_gpu=True, scaling="weak", blocks=1, settle=1500, algo=ALGO_BYTES_PER_BLOCK,
                kernel="asdr_update_kernel_one"),
     "c4": dict(channels=1048576, per_gpu=False, scaling="strong", blocks=1, settle=300, algo=C4_ALGO_BYTES_PER_BLOCK,
-               kernel="asdr_update_kernel_als_small (+ the SAM pre | PLL | post launches and the remainders' launch beside it)"),
+               kernel="asdr_update_kernel_als_small_one (+ the SAM pre | PLL | post launches and the remainders' launch beside it)"),
     "c5": dict(channels=4096, per_gpu=False, scaling="strong", blocks=C5_T, settle=4, algo=C5_ALGO_BYTES_PER_BLOCK,
                kernel="asdr_stream_kernel"),
 }
@@ -380,7 +380,7 @@ def other_configs(np, torch, dev, local_rank):
     def c4_oracle(o, c):
         o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
     run("c4_share", 131072, 1, 12, uniq, dict(fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15), lambda b: configure_c4(b, lib=L), c4_oracle, 100001, 12, 96,
-        C4_ALGO_BYTES_PER_BLOCK, "asdr_update_kernel_als_small (+ the SAM pre | PLL | post-with-ALS launches and the remainders' launch beside it)",
+        C4_ALGO_BYTES_PER_BLOCK, "asdr_update_kernel_als_small_one (+ the SAM pre | PLL | post-with-ALS launches and the remainders' launch beside it)",
         "C4: one GPU's share (131,072 of 1,048,576 channels) of the mixed-mode batch: mode = channel mod 7, ALS notch, blanker at 10 dB; 1 block/step")
     run("c5_share", 512, C5_T, 1, 512, dict(fc=6890.0, A=0.02, noise=0.05), configure_c5, lambda o, c: configure_c5(o), 511, 2, 8,
         C5_ALGO_BYTES_PER_BLOCK, "asdr_stream_kernel (block pipeline)",
