@@ -38,6 +38,13 @@ __device__ __forceinline__ float unit_scale(int s) {
   return (float)__builtin_fma(x, 0x1.0002000400080p-15, x * 0x1.0002000400080p-75);
 }
 
+// The same value in three binary32 operations (the update kernel's unit-gain scale, asdr_kernels.hip scale8): equal to the form above for
+// every int16 (oracle ao_check_scale_unit_gain, CPU-exhaustive).  The IQ generator scales its carried blocks again in every launch.
+__device__ __forceinline__ float unit_scale32(int s) {
+  const float x = (float)s;
+  return __builtin_fmaf(x, 0x1.0002p-15f, x * 0x1.0002p-45f);
+}
+
 union Raw8 { int4 v; int16_t s[8]; };
 __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
 
@@ -326,13 +333,23 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
   // instruction touch every line of the rows (round 4: 0.0557 -> see profiles/README.md).  int16 rows: lane s8 owns samples
   // kA + 64 h + j (h = 0, 1; j < 8); float rows: pieces s8 + 8 q.
   const int kA = 8 * s8;
+  // The two carried blocks come from a RAW int16 ring in HBM (slot a.phase = the older one) and are scaled again here: the scale is a pure
+  // function of the sample, so the floats are the reference's bit for bit at a quarter of the carried traffic (round 5: 2,048 B of float
+  // history read + written per channel and launch -> 512 B read + 256 B written; what the update kernel does for its blanker ring).
+  int16_t *const hrow = a.hist + (size_t)chc * 256;
   {
-    const float4 *h = reinterpret_cast<const float4 *>(a.hist + (size_t)chc * 256) + s8;
-    float4 t[8];
+    Raw8 o[2], pv[2];
+    const int4 *po = reinterpret_cast<const int4 *>(hrow + (a.phase & 1u) * 128 + kA), *pp = reinterpret_cast<const int4 *>(hrow + ((a.phase & 1u) ^ 1u) * 128 + kA);
+    o[0].v = po[0]; o[1].v = po[8]; pv[0].v = pp[0]; pv[1].v = pp[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t[q] = h[8 * q];
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) reinterpret_cast<float4 *>(w)[s8 + 8 * q] = t[q];
+      for (int j = 0; j < 8; ++j) {
+        const int m = 64 * h + kA + j;                        // x[m] of the oldest block at w[m - 1]; x[0] is never read: the padding word
+        w[(m == 0) ? 383 : m - 1] = unit_scale32(o[h].s[j]);
+        w[127 + m] = unit_scale32(pv[h].s[j]);                // x[128 + m]
+      }
+    }
   }
 
   // Delay line in LDS: sample x[m] of the reference's 384-sample window (two carried blocks + the newest) at w[m - 1], m = 1..383
@@ -348,7 +365,11 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
         r0.v = p[0]; r1.v = p[8];   // int4 #8 = 64 samples on
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { w[255 + kA + j] = unit_scale(r0.s[j]); w[255 + 64 + kA + j] = unit_scale(r1.s[j]); }
+      for (int j = 0; j < 8; ++j) { w[255 + kA + j] = unit_scale32(r0.s[j]); w[255 + 64 + kA + j] = unit_scale32(r1.s[j]); }
+      if (valid && blk >= a.n_blocks - 2) {   // one of the two blocks the next call starts from: raw, into the slot of the block it replaces
+        int4 *ph = reinterpret_cast<int4 *>(hrow + ((a.phase + (uint32_t)blk) & 1u) * 128 + kA);
+        ph[0] = r0.v; ph[8] = r1.v;
+      }
     }
     WAVE_SYNC();
     // this lane's 16 outputs i0 + 2e, i0 + 2e + 1 (e = 0..7) as 8 packed pairs: AudioIQgenerator.cpp:60-76, taps c_iq_taps
@@ -388,6 +409,7 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
       int4 *po = reinterpret_cast<int4 *>(a.out_i + oo), *pq = reinterpret_cast<int4 *>(a.out_q + oo);
       po[0] = oi[0].v; po[8] = oi[1].v; pq[0] = oq[0].v; pq[8] = oq[1].v;
     }
+    if (blk + 1 == a.n_blocks) break;   // (the carried blocks are in the ring already)
     WAVE_SYNC();
     // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383] (word 383 is padding);
     // source and destination of each phase are disjoint, 16 floats per lane
@@ -399,11 +421,6 @@ __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
       dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3;
       WAVE_SYNC();
     }
-  }
-  if (valid) {
-    float4 *h = reinterpret_cast<float4 *>(a.hist + (size_t)ch * 256) + s8;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) h[8 * q] = reinterpret_cast<const float4 *>(w)[s8 + 8 * q];
   }
 }
 

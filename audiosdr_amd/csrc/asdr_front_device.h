@@ -17,7 +17,8 @@ typedef struct {
 } PreArgs;
 
 typedef struct {
-  float *hist;                 /* [n_channels][256]: the two older blocks of the 3-block delay line, scaled (AudioIQgenerator.cpp:52-60) */
+  int16_t *hist;               /* [n_channels][2][128]: the two older blocks of the 3-block delay line (AudioIQgenerator.cpp:52-60), RAW, as a ring */
+  uint32_t phase;              /* slot of the OLDER one (the same for every channel: blocks processed so far, mod 2); block b of a call replaces slot (phase + b) & 1 */
   const float *gains;          /* [n_channels][2]: gainI, gainQ */
   const int16_t *in;           /* [n_channels][in_stride][128] */
   int16_t *out_i, *out_q;      /* [n_channels][out_stride][128] */

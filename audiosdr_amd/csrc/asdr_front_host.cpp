@@ -221,7 +221,9 @@ int asdr_pre_read_state(asdr_pre_t *p, asdr_pre_state_t *dst) {
 // ============================== AudioIQgenerator ==============================
 struct asdr_iqgen_batch : DevBase {
   std::vector<float> gains;   // [n][2]: gainI, gainQ (AudioIQgenerator.h:69-70)
-  float *d_gains = nullptr, *d_hist = nullptr;
+  float *d_gains = nullptr;
+  int16_t *d_hist = nullptr;   // [n][2][128]: raw ring of the two carried blocks
+  uint32_t phase = 0;          // slot of the older one
   bool gains_dirty = true;
 };
 
@@ -234,8 +236,8 @@ asdr_iqgen_t *asdr_iqgen_create(int n_channels, int device) {
   g->gains.assign(2 * (size_t)n_channels, 1.0f);
   if (device != ASDR_NO_DEVICE) {
     if (hipMalloc(&g->d_gains, 2 * (size_t)n_channels * sizeof(float)) != hipSuccess ||
-        hipMalloc(&g->d_hist, 256 * (size_t)n_channels * sizeof(float)) != hipSuccess ||
-        hipMemset(g->d_hist, 0, 256 * (size_t)n_channels * sizeof(float)) != hipSuccess) {   // static buffers start zeroed (.cpp:37-38)
+        hipMalloc(&g->d_hist, 256 * (size_t)n_channels * sizeof(int16_t)) != hipSuccess ||
+        hipMemset(g->d_hist, 0, 256 * (size_t)n_channels * sizeof(int16_t)) != hipSuccess) {   // static buffers start zeroed (.cpp:37-38)
       fail("out of device memory"); if (g->d_gains) hipFree(g->d_gains); if (g->d_hist) hipFree(g->d_hist); dev_fini(*g); delete g; return nullptr;
     }
     hipDeviceSynchronize();
@@ -275,10 +277,11 @@ int asdr_iqgen_update_device(asdr_iqgen_t *g, const int16_t *dIn, int16_t *dI, i
     g->gains_dirty = false;
   }
   IqgenArgs a;
-  a.hist = g->d_hist; a.gains = g->d_gains; a.in = dIn; a.out_i = dI; a.out_q = dQ;
+  a.hist = g->d_hist; a.phase = g->phase; a.gains = g->d_gains; a.in = dIn; a.out_i = dI; a.out_q = dQ;
   a.n_channels = g->n; a.n_blocks = n_blocks; a.in_stride = (int32_t)in_stride_blocks; a.out_stride = (int32_t)out_stride_blocks;
   HIPCHK(hipEventRecord(g->ev0, stream));
   if (asdr_launch_iqgen(&a, stream) != 0) return fail("IQ generator kernel launch failed");
+  g->phase = (g->phase + (uint32_t)n_blocks) & 1u;
   HIPCHK(hipEventRecord(g->ev1, stream));
   g->ev_valid = true; g->last_stream = stream;
   return 0;

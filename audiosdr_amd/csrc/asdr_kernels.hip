@@ -68,6 +68,14 @@
 #ifndef ASDR_MW_MIN_WAVES
 #define ASDR_MW_MIN_WAVES 64
 #endif
+#ifndef ASDR_MW_PRIO
+#define ASDR_MW_PRIO 2   /* experiments: s_setprio <n> inside the duty sections of the four-wave form (three sibling waves wait for the duty wave) */
+#endif
+#ifndef ASDR_CHAIN_PRIO
+#define ASDR_CHAIN_PRIO 0   /* experiments: s_setprio <n> around the dependent-chain phases of EVERY form (IF / audio pipelines, blanker / AGC chains) */
+#endif
+#define CHAIN_PRIO_ON() do { if (ASDR_CHAIN_PRIO) __builtin_amdgcn_s_setprio(ASDR_CHAIN_PRIO); } while (0)
+#define CHAIN_PRIO_OFF() do { if (ASDR_CHAIN_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 #ifndef ASDR_ONEBLK_ALS
 #define ASDR_ONEBLK_ALS 1   /* the loop-free form for the ALS instantiations too (short-filter uniform kernel, SAM post role with the filter); 0: measurements */
 #endif
@@ -1579,6 +1587,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // every channel's lead lane publishes its chain inputs; the duty wave (rel 0) runs the chains of all 8 * WAVES channels, one per lane
         if (lead) *reinterpret_cast<float4 *>(mwx + 8 * (wave * 8 + c8)) = make_float4(nb_avg0, mphase, minc, __int_as_float((chain_phase_own ? 1 : 0) | ((mix_early && !lo_hit) ? 2 : 0)));
         __syncthreads();
+        if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
         if (mw_rel == 0 && lane_i < 8 * WAVES) {
           const int q = lane_i;
           const float4 in4 = *reinterpret_cast<const float4 *>(mwx + 8 * q);
@@ -1587,10 +1596,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           const float pe = nb_chain(lds_wg + q * STRIDE, row_ptr(a.small, (uint32_t)mw_channel(q) * (uint32_t)sizeof(ChanSmall)), in4.x, in4.y, in4.z, any_phase, (fl & 2) != 0, nb_en, is_ssb);
           mwx[8 * q + 4] = pe;
         }
+        if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (lead) mphase_end = mwx[8 * (wave * 8 + c8) + 4];
       } else {
+        CHAIN_PRIO_ON();
         if (lead) mphase_end = nb_chain(L, S, nb_avg0, mphase, minc, chain_phase_own, mix_early && !lo_hit, nb_en, is_ssb);
+        CHAIN_PRIO_OFF();
       }
       ph_ready = mix_early && !lo_hit;
       WAVE_SYNC();
@@ -1842,7 +1854,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       float sv[4];
       if (HAS_ALS && !ALS_FULL_OPT && !if_pre) load_if_rows();
       sv[0] = if_s4.x; sv[1] = if_s4.y; sv[2] = if_s4.z; sv[3] = if_s4.w;
+      CHAIN_PRIO_ON();
       biquad_pipe<PIPE_PK>(L + (iq ? W1 : W0), true, st, if_cf, sv);
+      CHAIN_PRIO_OFF();
       *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
     }
     if (C16 && lo_hit) store4(lds + (lane_i >> 4) * STRIDE + PH + ((4 * lane_i) & 63), lo4);   // word i of [cos | sin]: row i >> 6, place i & 63
@@ -2387,11 +2401,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if (ABL_ON(ABL_AF) && af_en) {   // (launch-uniform: all four waves or none)
         __syncthreads();               // every wave's demodulated audio is in its W0 rows
         if (mw_audio_duty) {           // 16 cascades x 4 stages: the whole wave works
+          if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
           const int st = lane_i & 3;
           float sv[4];
           sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
           biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + (lane_i >> 2)) * STRIDE + W0, true, st, af_cf, sv);
           *reinterpret_cast<float4 *>(&mw_af_S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+          if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
       }
@@ -2401,7 +2417,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const bool on = af_en && (s8 < 4);
       float sv[4];
       sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
+      CHAIN_PRIO_ON();
       biquad_pipe<PIPE_PK>(L + W0, on, st, af_cf, sv);
+      CHAIN_PRIO_OFF();
       if (on) *reinterpret_cast<float4 *>(&S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       WAVE_SYNC();
     }
@@ -2548,6 +2566,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         // (the |x| rows and the gain tables are in the channels' LDS rows; the scalars come from the channels' state / parameter rows)
         if (lead) { mwx[8 * (wave * 8 + c8) + 5] = __int_as_float(agc_quiet ? 1 : 0); mwx[8 * (wave * 8 + c8) + 6] = am_clamped; }
         __syncthreads();
+        if (ASDR_MW_PRIO && mw_rel == 3) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
         if (mw_rel == 3 && lane_i < 8 * WAVES) {
           const int q = lane_i;
           if (__float_as_int(mwx[8 * q + 5]) == 0) {
@@ -2558,13 +2577,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                                        Pq->agc_alpha_rel, Pq->agc_beta_rel, Pq->agc_hang_count, is_am, mwx[8 * q + 6]);
           }
         }
+        if (ASDR_MW_PRIO && mw_rel == 3) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (!agc_quiet && lead) { const float g_end = mwx[8 * (wave * 8 + c8) + 7]; status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u); }
       } else {
+        if (!agc_quiet) CHAIN_PRIO_ON();
         if (!agc_quiet && agc_en && lead) {
           const float g_end = agc_chain(L, S, agc_old0, agc_hc0, gain_in, agc_al_a, agc_be_a, agc_al_r, agc_be_r, agc_hang, is_am, am_clamped);
           status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
         }
+        if (!agc_quiet) CHAIN_PRIO_OFF();
       }
       }
       if (!agc_quiet) WAVE_SYNC();

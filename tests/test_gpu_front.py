@@ -181,9 +181,11 @@ def test_pre_device_pointers_in_place_and_strided(gpu, ao):
     hip.free_all()
 
 
+@pytest.mark.parametrize("calls", [(4, 1, 1, 1), (1, 2, 3, 1), (2, 5), (1, 1, 1, 1, 1, 1, 1)])
 @pytest.mark.parametrize("n_ch", [1, 7, 8, 9, 40])
-def test_iqgen_parity(gpu, ao, n_ch):
-    """AudioIQgenerator: 7 blocks as one call of 4 + three calls of 1, per-channel gain balance; int16 bit-exact."""
+def test_iqgen_parity(gpu, ao, n_ch, calls):
+    """AudioIQgenerator: 7 blocks as calls of 4 + 1 + 1 + 1 blocks (and other splits: the two carried blocks live in a raw int16 ring whose
+    slots a call of any length must leave right), per-channel gain balance; int16 bit-exact."""
     n_blk = 7
     rng = np.random.default_rng(n_ch)
     t = np.arange(n_blk * 128)
@@ -198,7 +200,9 @@ def test_iqgen_parity(gpu, ao, n_ch):
             bal = (1.0, 1.02, 4.0)[c % 3]
             g.setGainBalance(bal, ch=c); orcs[c].setGainBalance(bal)
     want = [o.update(x[c]) for c, o in enumerate(orcs)]
-    parts = [g.update(x[:, :4])] + [g.update(x[:, k:k + 1]) for k in range(4, 7)]
+    parts, k0 = [], 0
+    for T in calls:
+        parts.append(g.update(x[:, k0:k0 + T])); k0 += T
     gi = np.concatenate([p[0] for p in parts], axis=1); gq = np.concatenate([p[1] for p in parts], axis=1)
     for c in range(n_ch):
         assert np.array_equal(gi[c].reshape(-1), want[c][0]), "I ch %d" % c

@@ -94,7 +94,7 @@ def main():
     # 157.3 TFLOP/s / 2 = 78.6 T operations/s without FMA (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD counts an FMA as two).
     tops = n_ch * T * 24576 / (ms * 1e-3) / 1e12
     line("AudioIQgenerator (257-tap Hilbert)", n_ch, T, ms, 768, ok,
-         {"state_bytes_per_launch_per_channel": 2048,
+         {"state_bytes_per_launch_per_channel": 768 if T == 1 else 1024,   # raw int16 ring: two blocks read, one (a multi-block call: two) written
           "roofline_valu": {"bound": "valu", "achieved": round(tops, 2), "peak": 78.6, "unit": "T FP32 operations/s (no FMA)", "frac": round(tops / 78.6, 4),
                             "operations_per_channel_block": 24576}})
     g.close()
