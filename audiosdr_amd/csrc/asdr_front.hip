@@ -17,6 +17,10 @@
 #define ASDR_PRE_ABLATE 0   /* profiling builds: detector phases compiled out (1 radix-8-by-2, 2 stage 1, 4 stage 2, 8 powers, 16 sum, 32 maximum scan, 64 unit scale + store) */
 #endif
 #define PRE_ON(bit) (!(ASDR_PRE_ABLATE & (bit)))
+#ifndef ASDR_IQ_ABLATE
+#define ASDR_IQ_ABLATE 0    /* profiling builds: IQ generator phases compiled out (1 FIR, 2 binary64 output conversion, 4 scale + staging of the carried blocks) */
+#endif
+#define IQ_ON(bit) (!(ASDR_IQ_ABLATE & (bit)))
 
 __constant__ float c_iq_taps[64];
 __constant__ float c_cftw[128][2];   // CMSIS twiddleCoef_128 (cos, +sin): the detector's FFT is the reference's arm_cfft_f32
@@ -123,28 +127,43 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
   __shared__ float P[4][132];       // line powers 0..127 (+ the reference's buffer[128] at [128])
   __shared__ float2 TW[128];        // CMSIS twiddleCoef_128: (cos, +sin)(2 pi k / 128)
   const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
-  const int ch = blockIdx.x * 4 + r;
-  const bool valid = ch < a.n_channels;
   TW[lane] = make_float2(c_cftw[lane][0], c_cftw[lane][1]);
   TW[lane + 64] = make_float2(c_cftw[lane + 64][0], c_cftw[lane + 64][1]);
-  asdr_pre_state_t st;
-  if (valid) st = a.state[ch];      // every lane of the row keeps a copy; all of them update it identically
-  else { st.correction = 0; st.saved_sample = 0; st.failure_count = 0; st.success_count = 0; st.auto_detect = 0; st.swap = 0;
-         st.max_line = 0; st.strong = 0; st.max_power = 0.f; st.avg_power = 0.f; st.ratio = 0.f; }
+  // PERSISTENT waves (round 5, like the IQ generator below): the grid is what the chip holds at once and a wave walks over its channel
+  // quads g = blockIdx.x, + gridDim.x, ... with the next work item's state and input block requested before the detector of the current
+  // one.  (One workgroup per quad ran the resident waves in step -- everybody waits for HBM, everybody transforms, everybody stores: 46 % of
+  // a wave's life parked at a wait.)
+  const int n_quads = (a.n_channels + 3) >> 2;
+  asdr_pre_state_t n_st;
+  Raw8 n_ri, n_rq;
+  auto ask_state = [&](int g) { const int c = g * 4 + r; n_st = a.state[(c < a.n_channels) ? c : 0]; };   // every lane of the row keeps a copy; all of them update it identically
+  auto ask_block = [&](int g, int blk) {
+    const int c = g * 4 + r;
+    const size_t io = ((size_t)((c < a.n_channels) ? c : 0) * a.in_stride + blk) * ASDR_N + 8 * l;
+    n_ri.v = *reinterpret_cast<const int4 *>(a.in_i + io);
+    n_rq.v = *reinterpret_cast<const int4 *>(a.in_q + io);
+  };
+  int g = (int)blockIdx.x;
+  if (g < n_quads) { ask_state(g); ask_block(g, 0); }
+  WAVE_SYNC();
+#pragma unroll 1
+  for (; g < n_quads; g += (int)gridDim.x) {
+  const int ch = g * 4 + r;
+  const bool valid = ch < a.n_channels;
+  asdr_pre_state_t st = n_st;
+  if (!valid) { st.correction = 0; st.saved_sample = 0; st.failure_count = 0; st.success_count = 0; st.auto_detect = 0; st.swap = 0;
+                st.max_line = 0; st.strong = 0; st.max_power = 0.f; st.avg_power = 0.f; st.ratio = 0.f; }
   int corr = st.correction, saved = st.saved_sample, fail = st.failure_count, succ = st.success_count;
   int autodet = valid ? st.auto_detect : 0;
   const int swap = st.swap;
-  WAVE_SYNC();
 
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    Raw8 ri, rq;
-    ri.v = rq.v = make_int4(0, 0, 0, 0);
-    if (valid) {
-      const size_t io = ((size_t)ch * a.in_stride + blk) * ASDR_N + 8 * l;
-      ri.v = *reinterpret_cast<const int4 *>(a.in_i + io);
-      rq.v = *reinterpret_cast<const int4 *>(a.in_q + io);
-    }
+    Raw8 ri = n_ri, rq = n_rq;
+    if (!valid) ri.v = rq.v = make_int4(0, 0, 0, 0);
+    // the next work item's rows: asked for now, used after this block's detector
+    if (blk + 1 < a.n_blocks) ask_block(g, blk + 1);
+    else if (g + (int)gridDim.x < n_quads) { ask_state(g + (int)gridDim.x); ask_block(g + (int)gridDim.x, 0); }
     int xi[8], xq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { xi[j] = ri.s[j]; xq[j] = rq.s[j]; }
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
       if (PRE_ON(64) && autodet) {
         // the block as complex float32 in natural order (.cpp:88-91)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) X[r][9 * l + j] = make_float2(unit_scale(xi[j]), unit_scale(xq[j]));   // XI(8 l + j)
+        for (int j = 0; j < 8; ++j) X[r][9 * l + j] = make_float2(unit_scale32(xi[j]), unit_scale32(xq[j]));   // XI(8 l + j)
       }
       WAVE_SYNC();
       // arm_cfft_f32(&arm_cfft_sR_f32_len128, buffer, 0, 1) (.cpp:93), operation for operation (oracle ao_fft128 == the reference's
@@ -302,11 +321,30 @@ __global__ __launch_bounds__(64) void asdr_pre_kernel(PreArgs a) {
     st.auto_detect = autodet;
     a.state[ch] = st;
   }
+  }
+}
+
+// workgroups of 64 threads the current device holds at once (persistent waves): CUs x what the occupancy calculator says for the kernel
+template <typename K>
+static int resident_workgroups(K kernel, int *cache) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+    cache[dev] = cus * per_cu;
+  }
+  return cache[dev];
 }
 
 extern "C" int asdr_launch_pre(const PreArgs *a, void *stream) {
-  const int grid = (a->n_channels + 3) / 4;
-  hipLaunchKernelGGL(asdr_pre_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *a);
+  static int resident[64] = {0};
+  const int res = resident_workgroups(asdr_pre_kernel, resident);
+  if (res <= 0) return -1;
+  const int n_quads = (a->n_channels + 3) / 4;
+  hipLaunchKernelGGL(asdr_pre_kernel, dim3(n_quads < res ? n_quads : res), dim3(64), 0, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -319,113 +357,142 @@ extern "C" int asdr_launch_pre(const PreArgs *a, void *stream) {
 // =====================================================================================================
 #define IQ_STRIDE 388   /* 97 sixteen-byte slots == 1 (mod 16): the 8 channel rows start on different LDS slots */
 
+// PERSISTENT waves (round 5): the grid is what the chip holds at once (asdr_launch_iqgen) and every wave walks over its channel groups
+// g = blockIdx.x, + gridDim.x, ... with the NEXT work item's raw rows (the carried ring slots, the input block, the gains) requested before the
+// FIR of the current one.  With one workgroup per channel group all resident waves ran the same phase at the same time -- everybody loads,
+// everybody runs the FIR, everybody stores -- in three rounds (8,192 groups on 3,072 slots): load + store time and FIR time added up
+// (19.6 + 29.5 us of 49 measured with either compiled out, profiles/README.md).  What is left is arithmetic: the counters show the vector
+// units 98 % busy (three waves per SIMD, each with a vector instruction active in 33 % of its cycles).
 __global__ __launch_bounds__(64) void asdr_iqgen_kernel(IqgenArgs a) {
   __shared__ float W[8 * IQ_STRIDE];
   const int lane = threadIdx.x, c8 = lane >> 3, s8 = lane & 7;
-  const int ch = blockIdx.x * 8 + c8;
-  const bool valid = ch < a.n_channels;
   float *w = W + c8 * IQ_STRIDE;
   const int i0 = 16 * s8;
-  const int chc = valid ? ch : 0;   // clamped: lanes of a padding channel read channel 0 and discard
-  const float gain_i = a.gains[2 * chc], gain_q = a.gains[2 * chc + 1];
   // Global rows are touched in whole 16-byte pieces with the 8 lanes of a channel on 8 ADJACENT pieces (one wave instruction reads or
   // writes 128 contiguous bytes of each of its 8 rows), as in the update kernel: lanes on every second or eighth piece make every
   // instruction touch every line of the rows (round 4: 0.0557 -> see profiles/README.md).  int16 rows: lane s8 owns samples
-  // kA + 64 h + j (h = 0, 1; j < 8); float rows: pieces s8 + 8 q.
+  // kA + 64 h + j (h = 0, 1; j < 8).
   const int kA = 8 * s8;
+  const int n_groups = (a.n_channels + 7) >> 3;
+  const uint32_t slot_old = a.phase & 1u;
   // The two carried blocks come from a RAW int16 ring in HBM (slot a.phase = the older one) and are scaled again here: the scale is a pure
   // function of the sample, so the floats are the reference's bit for bit at a quarter of the carried traffic (round 5: 2,048 B of float
   // history read + written per channel and launch -> 512 B read + 256 B written; what the update kernel does for its blanker ring).
-  int16_t *const hrow = a.hist + (size_t)chc * 256;
-  {
-    Raw8 o[2], pv[2];
-    const int4 *po = reinterpret_cast<const int4 *>(hrow + (a.phase & 1u) * 128 + kA), *pp = reinterpret_cast<const int4 *>(hrow + ((a.phase & 1u) ^ 1u) * 128 + kA);
-    o[0].v = po[0]; o[1].v = po[8]; pv[0].v = pp[0]; pv[1].v = pp[8];
+  Raw8 n_old[2], n_prev[2], n_new[2];   // the next work item's rows, in flight
+  float n_gi = 0.0f, n_gq = 0.0f;
+  auto ask_group = [&](int g) {          // ring slots + gains of group g (lanes of a padding channel read channel 0 and discard)
+    const int ch = g * 8 + c8, chc = (ch < a.n_channels) ? ch : 0;
+    const int16_t *hrow = a.hist + (size_t)chc * 256;
+    const int4 *po = reinterpret_cast<const int4 *>(hrow + slot_old * 128 + kA), *pp = reinterpret_cast<const int4 *>(hrow + (slot_old ^ 1u) * 128 + kA);
+    n_old[0].v = po[0]; n_old[1].v = po[8]; n_prev[0].v = pp[0]; n_prev[1].v = pp[8];
+    n_gi = a.gains[2 * chc]; n_gq = a.gains[2 * chc + 1];
+  };
+  auto ask_block = [&](int g, int blk) { // input block blk of group g
+    const int ch = g * 8 + c8, chc = (ch < a.n_channels) ? ch : 0;
+    const int4 *p = reinterpret_cast<const int4 *>(a.in + ((size_t)chc * a.in_stride + blk) * ASDR_N + kA);
+    n_new[0].v = p[0]; n_new[1].v = p[8];   // int4 #8 = 64 samples on
+  };
+  int g = (int)blockIdx.x;
+  if (g < n_groups) { ask_group(g); ask_block(g, 0); }
+#pragma unroll 1
+  for (; g < n_groups; g += (int)gridDim.x) {
+    const int ch = g * 8 + c8;
+    const bool valid = ch < a.n_channels;
+    const int chc = valid ? ch : 0;
+    int16_t *const hrow = a.hist + (size_t)chc * 256;
+    const float gain_i = n_gi, gain_q = n_gq;
+    // Delay line in LDS: sample x[m] of the reference's 384-sample window (two carried blocks + the newest) at w[m - 1], m = 1..383
+    // -- natural order shifted by one float (x[0] is never read), the layout the shared packed FIR wants (asdr_fir.h).
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int m = 64 * h + kA + j;                        // x[m] of the oldest block at w[m - 1]; x[0] is never read: the padding word
-        w[(m == 0) ? 383 : m - 1] = unit_scale32(o[h].s[j]);
-        w[127 + m] = unit_scale32(pv[h].s[j]);                // x[128 + m]
+        if (IQ_ON(4)) {
+        w[(m == 0) ? 383 : m - 1] = unit_scale32(n_old[h].s[j]);
+        w[127 + m] = unit_scale32(n_prev[h].s[j]);            // x[128 + m]
+        }
       }
     }
-  }
-
-  // Delay line in LDS: sample x[m] of the reference's 384-sample window (two carried blocks + the newest) at w[m - 1], m = 1..383
-  // -- natural order shifted by one float (x[0] is never read), the layout the shared packed FIR wants (asdr_fir.h); the carried
-  // row in HBM holds w[0..255] = x[1..256] as it stands (its last word belongs to the next block and is overwritten first).
 #pragma unroll 1
-  for (int blk = 0; blk < a.n_blocks; ++blk) {
-    {   // newest block -> x[256..383] = w[255..382], scaled (.cpp:56)
-      Raw8 r0, r1;
-      r0.v = r1.v = make_int4(0, 0, 0, 0);
-      if (valid) {
-        const int4 *p = reinterpret_cast<const int4 *>(a.in + ((size_t)ch * a.in_stride + blk) * ASDR_N + kA);
-        r0.v = p[0]; r1.v = p[8];   // int4 #8 = 64 samples on
+    for (int blk = 0; blk < a.n_blocks; ++blk) {
+      {   // newest block -> x[256..383] = w[255..382], scaled (.cpp:56)
+        const Raw8 r0 = n_new[0], r1 = n_new[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[255 + kA + j] = unit_scale32(r0.s[j]); w[255 + 64 + kA + j] = unit_scale32(r1.s[j]); }
+        if (valid && blk >= a.n_blocks - 2) {   // one of the two blocks the next call starts from: raw, into the slot of the block it replaces
+          int4 *ph = reinterpret_cast<int4 *>(hrow + ((a.phase + (uint32_t)blk) & 1u) * 128 + kA);
+          ph[0] = r0.v; ph[8] = r1.v;
+        }
       }
+      // the next work item's rows: asked for now, used after this block's FIR
+      if (blk + 1 < a.n_blocks) ask_block(g, blk + 1);
+      else if (g + (int)gridDim.x < n_groups) { ask_group(g + (int)gridDim.x); ask_block(g + (int)gridDim.x, 0); }
+      WAVE_SYNC();
+      // this lane's 16 outputs i0 + 2e, i0 + 2e + 1 (e = 0..7) as 8 packed pairs: AudioIQgenerator.cpp:60-76, taps c_iq_taps
+      v2f acc2[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { w[255 + kA + j] = unit_scale32(r0.s[j]); w[255 + 64 + kA + j] = unit_scale32(r1.s[j]); }
-      if (valid && blk >= a.n_blocks - 2) {   // one of the two blocks the next call starts from: raw, into the slot of the block it replaces
-        int4 *ph = reinterpret_cast<int4 *>(hrow + ((a.phase + (uint32_t)blk) & 1u) * 128 + kA);
-        ph[0] = r0.v; ph[8] = r1.v;
-      }
-    }
-    WAVE_SYNC();
-    // this lane's 16 outputs i0 + 2e, i0 + 2e + 1 (e = 0..7) as 8 packed pairs: AudioIQgenerator.cpp:60-76, taps c_iq_taps
-    v2f acc2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
-    hilbert_fir_rows<0, 8>(w, i0 >> 1, acc2, c_iq_taps);
-    // The FIR owns 16 contiguous outputs per lane, the global rows 8-sample pieces: the Q row is handed over through LDS -- in the
-    // words of the oldest block (x[1..128] at w[0..127]), which no FIR read needs any more once every lane is through.  (Word 127 =
-    // x[128] is the first delayed I sample: the I pieces are read before the hand-over.)
-    float ivr[16];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ivr[8 * h + j] = w[127 + 64 * h + kA + j];   // x[128 + k]: the input delayed by one block
-    }
-    WAVE_SYNC();
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4 *>(w + i0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
-    WAVE_SYNC();
-    if (valid) {   // .cpp:78-82: (int16_t)(float * 32767.0 * gain) in binary64; v_cvt_i32_f64 saturates like the ARM target
-      Raw8 oi[2], oq[2];   // (int16_t) keeps the low half, like the reference's cast
+      for (int e = 0; e < 8; ++e) acc2[e] = (v2f){0.0f, 0.0f};
+      if (IQ_ON(1)) hilbert_fir_rows<0, 8>(w, i0 >> 1, acc2, c_iq_taps);
+      // The FIR owns 16 contiguous outputs per lane, the global rows 8-sample pieces: the Q row is handed over through LDS -- in the
+      // words of the oldest block (x[1..128] at w[0..127]), which no FIR read needs any more once every lane is through.  (Word 127 =
+      // x[128] is the first delayed I sample: the I pieces are read before the hand-over.)
+      float ivr[16];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        int vi[8], vq[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float iv = ivr[8 * h + j];
-          const float qv = w[64 * h + kA + j];
-          vi[j] = (int)(((double)iv * 32767.0) * (double)gain_i);
-          vq[j] = (int)(((double)qv * 32767.0) * (double)gain_q);
-        }
-        oi[h].v = make_int4(pack16(vi[0], vi[1]), pack16(vi[2], vi[3]), pack16(vi[4], vi[5]), pack16(vi[6], vi[7]));
-        oq[h].v = make_int4(pack16(vq[0], vq[1]), pack16(vq[2], vq[3]), pack16(vq[4], vq[5]), pack16(vq[6], vq[7]));
+        for (int j = 0; j < 8; ++j) ivr[8 * h + j] = w[127 + 64 * h + kA + j];   // x[128 + k]: the input delayed by one block
       }
-      const size_t oo = ((size_t)ch * a.out_stride + blk) * ASDR_N + kA;
-      int4 *po = reinterpret_cast<int4 *>(a.out_i + oo), *pq = reinterpret_cast<int4 *>(a.out_q + oo);
-      po[0] = oi[0].v; po[8] = oi[1].v; pq[0] = oq[0].v; pq[8] = oq[1].v;
-    }
-    if (blk + 1 == a.n_blocks) break;   // (the carried blocks are in the ring already)
-    WAVE_SYNC();
-    // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383] (word 383 is padding);
-    // source and destination of each phase are disjoint, 16 floats per lane
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      const float4 *src = reinterpret_cast<const float4 *>(w + 128 * (ph + 1) + 16 * s8);
-      float4 *dst = reinterpret_cast<float4 *>(w + 128 * ph + 16 * s8);
-      const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
-      dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3;
       WAVE_SYNC();
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4 *>(w + i0 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
+      WAVE_SYNC();
+      {   // .cpp:78-82: (int16_t)(float * 32767.0 * gain) in binary64; v_cvt_i32_f64 saturates like the ARM target
+        Raw8 oi[2], oq[2];   // (int16_t) keeps the low half, like the reference's cast
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int vi[8], vq[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float iv = ivr[8 * h + j];
+            const float qv = w[64 * h + kA + j];
+            if (IQ_ON(2)) {
+            vi[j] = (int)(((double)iv * 32767.0) * (double)gain_i);
+            vq[j] = (int)(((double)qv * 32767.0) * (double)gain_q);
+            } else { vi[j] = (int)(iv * 32767.0f); vq[j] = (int)(qv * 32767.0f); }
+          }
+          oi[h].v = make_int4(pack16(vi[0], vi[1]), pack16(vi[2], vi[3]), pack16(vi[4], vi[5]), pack16(vi[6], vi[7]));
+          oq[h].v = make_int4(pack16(vq[0], vq[1]), pack16(vq[2], vq[3]), pack16(vq[4], vq[5]), pack16(vq[6], vq[7]));
+        }
+        if (valid) {
+          const size_t oo = ((size_t)ch * a.out_stride + blk) * ASDR_N + kA;
+          int4 *po = reinterpret_cast<int4 *>(a.out_i + oo), *pq = reinterpret_cast<int4 *>(a.out_q + oo);
+          po[0] = oi[0].v; po[8] = oi[1].v; pq[0] = oq[0].v; pq[8] = oq[1].v;
+        }
+      }
+      WAVE_SYNC();   // (every read of this block's rows is done: the slide, or the next group's staging, may overwrite them)
+      if (blk + 1 == a.n_blocks) break;   // (the carried blocks are in the ring already)
+      // slide the delay line by one block (.cpp:54-55, 57-58): w[0..127] = w[128..255], then w[128..255] = w[256..383] (word 383 is padding);
+      // source and destination of each phase are disjoint, 16 floats per lane
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const float4 *src = reinterpret_cast<const float4 *>(w + 128 * (ph + 1) + 16 * s8);
+        float4 *dst = reinterpret_cast<float4 *>(w + 128 * ph + 16 * s8);
+        const float4 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+        dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3;
+        WAVE_SYNC();
+      }
     }
   }
 }
 
 extern "C" int asdr_launch_iqgen(const IqgenArgs *a, void *stream) {
-  const int grid = (a->n_channels + 7) / 8;
+  // as many workgroups as the device holds at once (persistent waves), at most one per channel group
+  static int resident[64] = {0};
+  const int res = resident_workgroups(asdr_iqgen_kernel, resident);
+  if (res <= 0) return -1;
+  const int n_groups = (a->n_channels + 7) / 8;
+  const int grid = n_groups < res ? n_groups : res;
   hipLaunchKernelGGL(asdr_iqgen_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -142,6 +142,37 @@ def test_pre_autodetect_many_blocks_per_call_and_self_switch_off(gpu, ao):
     b.close()
 
 
+def test_pre_more_channel_quads_than_resident_waves(gpu, ao):
+    """The pre-processor's waves are persistent: with more channel quads than the device holds waves a wave walks over several quads with
+    the next quad's state and block requested ahead.  32,782 channels (two full rounds of 4,096 waves of four channels + a partial
+    one + a partial last quad), 12 distinct streams tiled over them (clean, skewed both ways, noise), detector on, calls of 1 + 3 + 1
+    blocks, in place: the 12 distinct ones equal the oracle (audio and state), every channel equals its duplicate."""
+    n_ch, uniq, n_blk = 4096 * 4 * 2 + 4 * 3 + 2, 12, 5
+    I, Q = _streams(uniq, n_blk, [0, 1, 2, 3], seed=21)
+    reps = (n_ch + uniq - 1) // uniq
+    It = np.ascontiguousarray(np.tile(I, (reps, 1, 1))[:n_ch]); Qt = np.ascontiguousarray(np.tile(Q, (reps, 1, 1))[:n_ch])
+    b = gpu.AudioSDRpreProcessorBatch(n_ch)
+    orcs = [ao.OraclePreProcessor() for _ in range(uniq)]
+    b.startAutoI2SerrorDetection(); b.setI2SerrorCompensation(1)
+    for o in orcs:
+        o.startAutoI2SerrorDetection(); o.setI2SerrorCompensation(1)
+    gi, gq, k0 = [], [], 0
+    for T in (1, 3, 1):
+        a_i, a_q = b.update(It[:, k0:k0 + T], Qt[:, k0:k0 + T]); gi.append(a_i); gq.append(a_q); k0 += T
+    gi = np.concatenate(gi, axis=1); gq = np.concatenate(gq, axis=1)
+    for c, o in enumerate(orcs):
+        wi, wq = o.update(I[c], Q[c])
+        assert np.array_equal(gi[c].reshape(-1), wi) and np.array_equal(gq[c].reshape(-1), wq), c
+    _cmp_state(b, orcs)
+    ref_i = np.tile(gi[:uniq], (reps, 1, 1))[:n_ch]; ref_q = np.tile(gq[:uniq], (reps, 1, 1))[:n_ch]
+    bad = np.nonzero((gi != ref_i).any(axis=(1, 2)) | (gq != ref_q).any(axis=(1, 2)))[0]
+    assert bad.size == 0, "channels differ from their duplicates: %s" % bad[:10]
+    st = b.read_state()
+    for k in ("correction", "saved_sample", "failure_count", "success_count", "max_line"):
+        v = np.asarray(st[k]); assert np.array_equal(v, np.tile(v[:uniq], reps)[:n_ch]), k
+    b.close()
+
+
 def test_pre_device_pointers_in_place_and_strided(gpu, ao):
     """Caller-owned HBM: in place (out == in, as the reference rewrites its blocks) and out of place with strides."""
     n_ch, n_blk = 9, 6
@@ -208,6 +239,39 @@ def test_iqgen_parity(gpu, ao, n_ch, calls):
         assert np.array_equal(gi[c].reshape(-1), want[c][0]), "I ch %d" % c
         assert np.array_equal(gq[c].reshape(-1), want[c][1]), "Q ch %d" % c
     assert g.last_kernel_ms() > 0
+    g.close()
+
+
+def test_iqgen_more_channel_groups_than_resident_waves(gpu, ao):
+    """The IQ generator's waves are persistent: with more channel groups than the device holds waves, a wave walks over several groups
+    with the next group's rows requested ahead.  49,195 channels (2 full rounds of 3,072 waves + a partial one + a partial last group),
+    64 distinct inputs tiled over them: every channel equals its duplicate, the 64 distinct ones equal the oracle; calls of 1 + 2 + 1 blocks."""
+    n_ch, uniq, n_blk = 3072 * 8 * 2 + 8 * 5 + 3, 64, 4
+    rng = np.random.default_rng(11)
+    t = np.arange(n_blk * 128)
+    x = np.stack([np.clip(9000 * np.sin(2 * np.pi * (500.0 + 97.0 * c) * t / FS) + 2500 * rng.standard_normal(t.size), -32768, 32767)
+                  for c in range(uniq)]).astype(np.int16).reshape(uniq, n_blk, 128)
+    reps = (n_ch + uniq - 1) // uniq
+    xt = np.ascontiguousarray(np.tile(x, (reps, 1, 1))[:n_ch])
+    g = gpu.AudioIQgeneratorBatch(n_ch)
+    orcs = [ao.OracleIQgenerator() for _ in range(uniq)]
+    for c in range(uniq):
+        if c % 3:
+            bal = (1.0, 1.02, 0.97)[c % 3]
+            orcs[c].setGainBalance(bal)
+            for d in range(c, n_ch, uniq):
+                g.setGainBalance(bal, ch=d)
+    want = [o.update(x[c]) for c, o in enumerate(orcs)]
+    parts, k0 = [], 0
+    for T in (1, 2, 1):
+        parts.append(g.update(xt[:, k0:k0 + T])); k0 += T
+    gi = np.concatenate([p[0] for p in parts], axis=1); gq = np.concatenate([p[1] for p in parts], axis=1)
+    for c in range(uniq):
+        assert np.array_equal(gi[c].reshape(-1), want[c][0]), "I ch %d" % c
+        assert np.array_equal(gq[c].reshape(-1), want[c][1]), "Q ch %d" % c
+    ref_i = np.tile(gi[:uniq], (reps, 1, 1))[:n_ch]; ref_q = np.tile(gq[:uniq], (reps, 1, 1))[:n_ch]
+    bad = np.nonzero((gi != ref_i).any(axis=(1, 2)) | (gq != ref_q).any(axis=(1, 2)))[0]
+    assert bad.size == 0, "channels differ from their duplicates: %s" % bad[:10]
     g.close()
 
 
