@@ -1109,11 +1109,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                  DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6);
   constexpr bool TO_ALS = (ROLE == 6);
 #ifndef ASDR_ALS_FULL_OPT
-#define ASDR_ALS_FULL_OPT 0
+#define ASDR_ALS_FULL_OPT 2
 #endif
-  // The ALS instantiations used to give up two of the plain kernel's orderings for registers (IF rows consumed before the ring
-  // prefetches; the merged average + phase loop): experiments re-enable them for the compact rows with -DASDR_ALS_FULL_OPT=1.
-  constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && ASDR_COMPACT_ROWS(STRIDE), ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && ASDR_COMPACT_ROWS(STRIDE);
+  // The ALS instantiations gave up two of the plain kernel's orderings for registers (IF rows consumed before the ring prefetches; the
+  // merged average + phase loop).  Their LOOP-FREE compact-row forms have the registers for both (round 5: asdr_update_kernel_als_small_one
+  // 160 VGPRs, no spills; C4 share -1.3 %, on the lanes -2.5 %); the looped forms keep the old orderings.  Level 0 / 1: measurements.
+  constexpr bool ALS_LOOPFREE = (ASDR_ONEBLK_ALS != 0) && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
+  constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && ASDR_COMPACT_ROWS(STRIDE) && ALS_LOOPFREE,
+                 ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && ASDR_COMPACT_ROWS(STRIDE) && ALS_LOOPFREE;
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
   // biquad pipelines with packed products (biquad_pipe<true>), by instantiation: bit 0 = the ALS kinds, 1 = the plain kinds, 2 = the SAM roles, 3 = the block pipeline
   constexpr bool PIPE_PK = ((ASDR_PIPE_PK_MASK & 1) && HAS_ALS) || ((ASDR_PIPE_PK_MASK & 2) && !HAS_ALS && !HAS_SAM && ROLE == 0) ||
