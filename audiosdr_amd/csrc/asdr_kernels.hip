@@ -2551,6 +2551,20 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               gvv[u] = gv;
             }
             hc = hcb - 8u;
+          } else if (__all(hc == 0u && hang == 0u)) {
+            // No hang time at all (setAGChangTime(0)) and no counter running: the counter stays 0 whatever happens (an attack re-arms it with
+            // 0), so EVERY sample updates the envelope -- attack or release coefficients by the one comparison -- and governs its own gain.
+            // Half the general form's instructions per sample (round 5; `robustness.agc_general_form` in the bench line).
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float av = x[u];
+              const bool att = av > old_abs;
+              const float al = att ? al_a : al_r, be = att ? be_a : be_r;
+              const float pa = al * old_abs, pb = be * av;
+              old_abs = pa + pb;
+              gvv[u] = old_abs;
+            }
+            gv = old_abs;
           } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

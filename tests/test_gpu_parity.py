@@ -244,18 +244,20 @@ def test_agc_hanging_chunks_and_attacks(gpu, ao):
     taken (long hang: USB; tiny or zero hang: always (c); AM, whose |x| is the constant carrier level), wave 3 mixes all of
     them.  Amplitude steps up and down drive attacks, pure hang, the counter running out and release; AGC tap + int16 output."""
     from audiosdr_amd.synth import make_iq
-    n_ch, n_blk = 32, 40
+    n_ch, n_blk = 40, 40            # (wave 4: zero hang time in every channel -- the every-sample-updates form of (c))
     I, Q = make_iq(n_ch, n_blk, fc=6290.0, A=0.3, noise=0.002)
     env = np.ones(n_blk * 128)
     env[128 * 6:128 * 12] = 0.05; env[128 * 12:128 * 13] = 1.0; env[128 * 13:128 * 30] = 0.02; env[128 * 30:] = 0.6
     I = (I.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
     Q = (Q.reshape(n_ch, -1) * env).astype(np.int16).reshape(n_ch, n_blk, 128)
-    grp = lambda c: (c // 8) if c < 24 else (c % 3)
+    grp = lambda c: (c // 8) if c < 24 else ((c % 3) if c < 32 else 3)
     setters = [S("setDemodMode", 1), S("disableNoiseBlanker"),
                S("setAGChangTime", 7.0, sel=lambda c: grp(c) == 0 and c % 2 == 0),      # 308 samples: runs out inside chunks
                S("setAGCmode", 3, sel=lambda c: grp(c) == 0 and c % 4 == 1),
                S("setAGChangTime", 0.1, sel=lambda c: grp(c) == 1 and c % 2 == 0),      # 4 samples: below the chunk length
                S("setAGChangTime", 0.0, sel=lambda c: grp(c) == 1 and c % 2 == 1),
+               S("setAGChangTime", 0.0, sel=lambda c: grp(c) == 3),
+               S("setAGCmode", 1, sel=lambda c: grp(c) == 3 and c % 2 == 1),
                S("setDemodMode", 4, sel=lambda c: grp(c) == 2),
                S("setAGCmode", 1, sel=lambda c: grp(c) == 2 and c % 2 == 1)]
     batch, orcs = _mk(gpu, ao, n_ch, setters, taps=True)
