@@ -185,10 +185,18 @@ typedef struct {
   uint32_t *sam_lock;     /* ... and the PLL's lock flag of the block, one word per schedule slot of the launch, beside the tiles (not
                              through the status word: when the three roles of consecutive blocks overlap -- pre(k+1) | PLL(k+1) beside
                              post(k), asdr_launch_sam_role -- the status word may already hold block k+1's flag when post(k) reads it) */
+  float *als_stage;       /* ALS role streams (a small bank's multi-block call as chain | filter launches on two event-chained streams, asdr_host.cpp):
+                             [n_channels][ASDR_ALS_STAGE_SLOTS][128] post-AGC rows of the blocks in flight -- the chain launch of block b stores
+                             its row in slot b % S (and in the als_x ring as ever), the filter launch of block b reads slots b % S and (b - 1) % S
+                             = the previous block's, so that the chain launches run up to S - 1 blocks ahead of the filter launches without
+                             touching what those read; NULL = the als_x ring */
+  uint32_t als_stage_cur, als_stage_prev;   /* slots of the launch's first block and of the block in front of it (block k of the launch: + k, mod the slots) */
   LoEntry *lo_ring;       /* [ASDR_LO_RING] the streaming pipeline's oscillator role leaves block b's pairs in entry b % ASDR_LO_RING;
                              its progress counter is stream_prog[3 * stream_waves] */
   ChainConsts k;
 } UpdateArgs;
+#define ASDR_ALS_STAGE_SLOTS 32  /* ALS role streams: slots of UpdateArgs.als_stage per channel (16 KB) */
+#define ASDR_ALS_CHUNK 8         /* ... and blocks per chain / filter launch: the chain launches run up to STAGE_SLOTS / CHUNK - 2 chunks ahead */
 #define ASDR_STREAM_DEPTH 4
 #define ASDR_LO_RING 8
 #define ASDR_STREAM_SPIN_LIMIT (1u << 18)   /* bounded waits: a pipeline whose roles are not co-resident ends with the error flag set and is

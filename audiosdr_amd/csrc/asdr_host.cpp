@@ -28,6 +28,9 @@
 #include "asdr_tables.h"
 
 // batches of at least this many waves issue a multi-block call as one launch per block (asdr_update_device_strided)
+#ifndef ASDR_ALS_ROLE_MAX_WAVES
+#define ASDR_ALS_ROLE_MAX_WAVES 512   /* ALS role streams: banks of up to this many waves (4,096 channels: 64 MB of stage) */
+#endif
 #ifndef ASDR_PER_BLOCK_LAUNCH_WAVES
 #define ASDR_PER_BLOCK_LAUNCH_WAVES 1024
 #endif
@@ -53,6 +56,8 @@ extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream);
 extern "C" int asdr_kernels_upload_tables(void);
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
 extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int uniform, int role, hipStream_t stream);
+extern "C" int asdr_launch_als_role(const UpdateArgs *a, int role, hipStream_t stream);
+extern "C" int asdr_launch_als_stage_seed(const UpdateArgs *a, int ch0, int n, hipStream_t stream);
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream);
 
 namespace {
@@ -306,6 +311,13 @@ struct asdr_batch {
   hipEvent_t ev_role[6] = {};       // SAM role streams: [0..1] pre done, [2..3] PLL done, [4..5] post done, by block parity
   bool sam_role_streams = true;     // (ASDR_NO_SAM_ROLE_STREAMS: off, for measurements)
   long stat_sam_role_calls = 0;
+  // ALS role streams: a SMALL bank of channels with a short ALS filter (one uniform sub-range, below the one-launch-per-block size) runs a
+  // multi-block call as chain | filter launches on two event-chained streams, a chunk of blocks per launch -- the filter of a chunk (a
+  // 33-epoch dependent chain per block: ~13 us whatever the bank size) beside the chain of the next one -- through a stage of post-AGC rows.
+  float *d_als_stage = nullptr;     // [n][ASDR_ALS_STAGE_SLOTS][128], allocated at the first such call
+  hipEvent_t ev_als[2 * (ASDR_ALS_STAGE_SLOTS / ASDR_ALS_CHUNK)] = {};   // chain chunk k done [k % R], filter chunk k done [R + k % R]
+  bool als_role_streams = true;     // (ASDR_NO_ALS_ROLE_STREAMS: off, for measurements)
+  long stat_als_role_calls = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode or AM: the modes the block pipeline has roles for (checked when the schedule is built)
   bool stream_launched = false;     // a streaming launch is (or was) in flight: its error flag has not been read yet
   long stat_stream_launches = 0;
@@ -883,6 +895,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
       if (hipEventCreateWithFlags(&b->ev_lane[i], hipEventDisableTiming) != hipSuccess) ok = false;
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;   // (the overlap probe runs at the first call that would use the lanes: update_device_part)
     b->sam_role_streams = getenv("ASDR_NO_SAM_ROLE_STREAMS") == nullptr;
+    b->als_role_streams = getenv("ASDR_NO_ALS_ROLE_STREAMS") == nullptr;
     if (ok && (b->stream = pool_stream(device, 0)) == nullptr) ok = false;   // the pool's first stream (= lane 0: a batch runs on the lanes or on its own stream, never both at once)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
@@ -987,7 +1000,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
-                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap};
+                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap, b->d_als_stage};
   for (void *p : ptrs) if (p) hipFree(p);
   b->copy_pool.reset();
   for (int i = 0; i < 3; i++) if (b->h_io[i]) hipHostFree(b->h_io[i]);
@@ -1116,6 +1129,22 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   // ... and channels with a short ALS filter as two: the chain up to the AGC | the filter and the output stage (stage taps off: the taps
   // of the last two stages are the fused kernel's)
   const bool als_split = b->als_split && !b->taps_on && b->kind_uniform_slots[ASDR_KERNEL_ALS_SMALL] > 0;
+  // ALS role streams (asdr_batch::d_als_stage): the whole schedule is ONE uniform sub-range of short-filter channels of a known mode, small
+  // enough to be on the in-kernel block loop otherwise; not for in-place calls (the filter of a chunk writes output rows while the chain of
+  // the next one reads input rows), not with stage taps.
+  bool als_roles = b->als_role_streams && n_blocks >= 2 && parts == 1 && !use_lanes && !b->taps_on && !sam_split && !als_split && n_sub == 1 &&
+                   subs[0].kind == ASDR_KERNEL_ALS_SMALL && subs[0].uniform && total_slots <= 8 * ASDR_ALS_ROLE_MAX_WAVES &&
+                   b->sched[subs[0].first].mode <= 6u;
+  if (als_roles) {
+    const uintptr_t in_bytes = ((uintptr_t)(b->n - 1) * (uintptr_t)in_stride_blocks + (uintptr_t)n_blocks) * ASDR_N * sizeof(int16_t);
+    const uintptr_t out_bytes = ((uintptr_t)(b->n - 1) * (uintptr_t)out_stride_blocks + (uintptr_t)n_blocks) * ASDR_N * sizeof(int16_t);
+    const uintptr_t o0 = (uintptr_t)dOut, o1 = o0 + out_bytes;
+    for (uintptr_t i0 : {(uintptr_t)dI, (uintptr_t)dQ}) if (o0 < i0 + in_bytes && i0 < o1) als_roles = false;
+  }
+  if (als_roles && !b->d_als_stage) {   // first use (a failed allocation leaves the batch on the block loop)
+    float *st = nullptr;
+    if (hipMalloc(&st, (size_t)(b->n + 1) * ASDR_ALS_STAGE_SLOTS * ASDR_N * sizeof(float)) == hipSuccess) b->d_als_stage = st; else { (void)hipGetLastError(); als_roles = false; }
+  }
   const bool per_block = n_blocks > 1 && (sam_split || als_split || total_slots >= 8 * ASDR_PER_BLOCK_LAUNCH_WAVES);
   // Small batch, many blocks, one sub-range of uniform SSB-class waves, no taps: the block pipeline -- as a transaction: a snapshot of
   // the state in front of it, and behind it the launches that put the state back and run the call on the in-kernel block loop if a
@@ -1302,7 +1331,44 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     HIPCHK(hipStreamWaitEvent(s_pre, b->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_fork, 0));
     b->stat_sam_role_calls++;
   }
-  for (int lb = 0; lb < n_launch; lb++) {
+  const bool als_role_call = als_roles && n_items == 1 && taps == nullptr;
+  int parity_launches = n_launch;   // launches that flipped the oscillator cache's halves
+  if (als_role_call) {
+    // ALS role streams: chunks of ASDR_ALS_CHUNK blocks -- the chain up to the AGC (its block loop kept) on the helper stream, the filter + output
+    // on the caller's, chained by one event pair per chunk.  The chain's rows wait in the stage (slot = block % S); chain chunk k overwrites
+    // the slots filter chunk k - S / G + 1 reads its "previous block" from, so it waits for that launch -- the only back-pressure.  The two
+    // launches touch disjoint rows otherwise (the chain: filter states, rings, status; the filter: taps, output, the kept audio row).
+    constexpr int S = ASDR_ALS_STAGE_SLOTS, G = ASDR_ALS_CHUNK, R = S / G;
+    static_assert(S % G == 0 && R >= 3, "the stage holds at least three chunks");
+    hipStream_t s_chain = aux_stream(b, 0);
+    if (!s_chain) return fail("stream creation failed");
+    for (int i = 0; i < 2 * R; i++) if (!b->ev_als[i]) HIPCHK(hipEventCreateWithFlags(&b->ev_als[i], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(b->ev_fork, stream));
+    HIPCHK(hipStreamWaitEvent(s_chain, b->ev_fork, 0));
+    const int i0 = items[0].sub, first0 = items[0].first;
+    a.sched = b->d_sched + first0; a.n_sched = items[0].slots; a.direct_ch0 = -1; a.lo_write = 1u;
+    if (b->kind_direct[subs[i0].kind]) { const SlotInfo &s0 = b->sched[subs[i0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo; }
+    // the stage's "previous block" slot of the call's first block: the als_x ring's other slot as the last call left it
+    a.als_stage = b->d_als_stage; a.als_stage_cur = 0u; a.als_stage_prev = (uint32_t)(S - 1); a.als_phase = b->als_phase;
+    if (asdr_launch_als_stage_seed(&a, 0, b->n, s_chain) != 0) return fail("update kernel launch failed");
+    const int n_chunks = (n_blocks + G - 1) / G;
+    for (int k = 0; k < n_chunks; k++) {
+      const int b0 = k * G, g = (n_blocks - b0 < G) ? n_blocks - b0 : G;
+      a.in_i = dI + (size_t)b0 * ASDR_N; a.in_q = dQ + (size_t)b0 * ASDR_N; a.out = dOut + (size_t)b0 * ASDR_N; a.n_blocks = g;
+      a.nb_phase = (b->nb_phase + (uint32_t)(b0 % 3)) % 3u;
+      a.als_phase = (b->als_phase + (uint32_t)b0) & 1u;
+      a.lo_parity = b->lo_parity ^ (uint32_t)(k & 1);
+      a.als_stage_cur = (uint32_t)(b0 % S); a.als_stage_prev = (uint32_t)((b0 + S - 1) % S);
+      if (k >= R - 1) HIPCHK(hipStreamWaitEvent(s_chain, b->ev_als[R + (k + 1) % R], 0));
+      if (asdr_launch_als_role(&a, 0, s_chain) != 0) return fail("update kernel launch failed");
+      HIPCHK(hipEventRecord(b->ev_als[k % R], s_chain)); HIPCHK(hipStreamWaitEvent(stream, b->ev_als[k % R], 0));
+      if (asdr_launch_als_role(&a, 1, stream) != 0) return fail("update kernel launch failed");
+      HIPCHK(hipEventRecord(b->ev_als[R + k % R], stream));
+    }
+    parity_launches = n_chunks;
+    b->stat_als_role_calls++;
+  }
+  for (int lb = 0; lb < (als_role_call ? 0 : n_launch); lb++) {
     if (per_block) {
       a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
       a.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
@@ -1356,7 +1422,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   b->last_stream = stream; b->last_was_lanes = false;
   b->nb_phase = (b->nb_phase + (uint32_t)(n_blocks % 3)) % 3u;
   b->als_phase = (b->als_phase + (uint32_t)n_blocks) & 1u;
-  b->lo_parity ^= (uint32_t)(n_launch & 1);
+  b->lo_parity ^= (uint32_t)(parity_launches & 1);
   return 0;
 }
 
@@ -1765,6 +1831,10 @@ int asdr_lanes_enabled(asdr_batch_t *b) {
   if (!b->lanes_enabled) return 0;
   const int probe = (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe[b->device] : -1;
   return (probe == 0 && !b->lanes_forced) ? 0 : 1;   // (what the next lane-sized call will do, as far as is known now)
+}
+long asdr_als_role_calls(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_als_role_calls; return t; }
+  return b ? b->stat_als_role_calls : -1;
 }
 long asdr_sam_role_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_sam_role_calls; return t; }

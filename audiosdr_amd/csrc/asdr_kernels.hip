@@ -1105,16 +1105,17 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // ROLE 6: the whole chain up to and including the AGC for channels whose (short) ALS filter runs as a launch of its own
   // (asdr_als_kernel): the post-AGC row goes to the ALS input ring instead of through the filter and the output stage.
   constexpr bool C16 = (STRIDE == 320);   // the 16-waves-per-CU form (see below, where the block loop starts)
-  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4 || ROLE == 6), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5 || ROLE == 6),
-                 DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6);
-  constexpr bool TO_ALS = (ROLE == 6);
+  // ROLE 7: role 6 with the block loop kept (ALS role streams: a chunk of blocks per launch).
+  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4 || ROLE == 6 || ROLE == 7), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5 || ROLE == 6 || ROLE == 7),
+                 DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6 || ROLE == 7);
+  constexpr bool TO_ALS = (ROLE == 6 || ROLE == 7);
 #ifndef ASDR_ALS_FULL_OPT
 #define ASDR_ALS_FULL_OPT 2
 #endif
   // The ALS instantiations gave up two of the plain kernel's orderings for registers (IF rows consumed before the ring prefetches; the
   // merged average + phase loop).  Their LOOP-FREE compact-row forms have the registers for both (round 5: asdr_update_kernel_als_small_one
   // 160 VGPRs, no spills; C4 share -1.3 %, on the lanes -2.5 %); the looped forms keep the old orderings.  Level 0 / 1: measurements.
-  constexpr bool ALS_LOOPFREE = (ASDR_ONEBLK_ALS != 0) && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
+  constexpr bool ALS_LOOPFREE = (ASDR_ONEBLK_ALS != 0) && (ONEBLK_ || (ROLE >= 4 && ROLE != 7 && ASDR_ONEBLK_ROLES));
   constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && ASDR_COMPACT_ROWS(STRIDE) && ALS_LOOPFREE,
                  ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && ASDR_COMPACT_ROWS(STRIDE) && ALS_LOOPFREE;
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
@@ -1178,7 +1179,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
   // (The ALS instantiations' loop-free builds failed the ALS parity tests until the guard of the tap store-back was taken from an opaque copy
   // of the flag word: a compiler issue, see there.)
-  constexpr bool ONEBLK = (!HAS_ALS || ASDR_ONEBLK_ALS) && (ONEBLK_ || (ROLE >= 4 && ASDR_ONEBLK_ROLES));
+  constexpr bool ONEBLK = (!HAS_ALS || ASDR_ONEBLK_ALS) && (ONEBLK_ || (ROLE >= 4 && ROLE != 7 && ASDR_ONEBLK_ROLES));
   constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);
   // C16 (round 5, asdr_update_kernel_c16): the same chain on 320-float rows and <= 128 VGPRs -- 10,240 B of LDS per wave, FOUR waves per
   // SIMD = 16 per CU.  Direct one-block launches of ONE SSB-class settings group without stage taps (the launcher's choice: mode and
@@ -2351,7 +2352,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         store8(L + W0 + kA + 64 * h, vq);
       }
     }
-    if ((ROLE == 0 || ROLE == 6) && !is_ssb && !is_am && mode != ASDR_SAMmode) {
+    if ((ROLE == 0 || ROLE == 6 || ROLE == 7) && !is_ssb && !is_am && mode != ASDR_SAMmode) {
       // Unknown mode value: neither demodulator branch runs (AudioSDR.cpp:84, 122), _audioOut still holds what the PREVIOUS block
       // left in it -- its audio after the audio filter, AGC and ALS -- and those stages now process it again (:149-161).  The row
       // comes back from HBM (every block stores it, below).  Without the row (asdr_set_exact_unknown_mode(b, 0)): silence.
@@ -2724,8 +2725,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     if (TO_ALS && valid) {   // this block's ALS input (AudioSDR.cpp:326-329: _als_in[n_block + i] = buff[i]) -> its ring slot; the filter is the next launch
       float *gx = row_ptr(a.als_x, (uint32_t)ch * 1024u + ((a.als_phase + (uint32_t)blk) & 1u) * 512u + 4u * (uint32_t)kF);
+      float *gs = (a.als_stage != nullptr) ? row_ptr(a.als_stage, (uint32_t)ch * (uint32_t)(ASDR_ALS_STAGE_SLOTS * 512) + ((a.als_stage_cur + (uint32_t)blk) % ASDR_ALS_STAGE_SLOTS) * 512u + 4u * (uint32_t)kF) : nullptr;   // ALS role streams: the row the filter launch reads
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { float t[4]; load4(L + W0 + kF + 32 * m, t); store4(gx + 32 * m, t); }
+      for (int m = 0; m < 4; ++m) { float t[4]; load4(L + W0 + kF + 32 * m, t); store4(gx + 32 * m, t); if (gs != nullptr) store4(gs + 32 * m, t); }
     }
     if (DO3 && !TO_ALS && valid && a.audio_prev != nullptr) {   // _audioOut as this block leaves it: what an unknown mode value would re-process
       float *ap = row_ptr(a.audio_prev, (uint32_t)ch * 512u + 4u * (uint32_t)kF);
@@ -2908,6 +2910,11 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_als_pre
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 6>(a, lds);
 }
+// ... and with the block loop kept (ROLE 7): the chain launches of the ALS role streams take a chunk of blocks each
+extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_als_pre_loop_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 7>(a, lds);
+}
 // The ALS filter + the output stage of 8 channels per wave, from the ALS input ring (AudioSDR.cpp:324-352, 158-161).  The filter is 33
 // epochs of dependent work per block -- a 55-long chain of additions, then the tap update -- and its throughput follows the resident
 // waves (profiles/README.md: 9 -> 12 waves per CU gave -22 %): alone, it needs 268 floats of LDS per channel instead of the chain's 388
@@ -2943,6 +2950,10 @@ extern "C" __global__ __launch_bounds__(64, ASDR_ALS_K_WAVES_PER_EU) void asdr_a
     const float lam = Pp->als_lambda;
     const uint32_t as = (a.als_phase + (uint32_t)blk) & 1u;
     const float *gx_cur = a.als_x + (size_t)ch * (2 * ASDR_N) + as * ASDR_N + kF, *gx_prev = a.als_x + (size_t)ch * (2 * ASDR_N) + (as ^ 1u) * ASDR_N + kF;
+    if (a.als_stage != nullptr) {   // ALS role streams: this block's and the previous block's rows wait in the three-slot stage (the ring's slots belong to the chain launches running ahead)
+      const uint32_t sc = (a.als_stage_cur + (uint32_t)blk) % ASDR_ALS_STAGE_SLOTS, sp = (a.als_stage_prev + (uint32_t)blk) % ASDR_ALS_STAGE_SLOTS;
+      gx_cur = a.als_stage + (size_t)ch * (ASDR_ALS_STAGE_SLOTS * ASDR_N) + sc * ASDR_N + kF; gx_prev = a.als_stage + (size_t)ch * (ASDR_ALS_STAGE_SLOTS * ASDR_N) + sp * ASDR_N + kF;
+    }
     float *gw = a.als_w + (size_t)ch * ASDR_N + kF;
     {
       float tx[8], tw[8], tn[16];   // all row loads in flight together
@@ -3266,6 +3277,28 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
     else if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a);
   }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ALS role streams: the two launches of the chain | filter form on their own (role 0 = the chain up to the AGC, 1 = the filter + output),
+// and the kernel that seeds the stage's "previous block" slot from the als_x ring in front of a call's first block.
+extern "C" __global__ void asdr_als_stage_seed_kernel(UpdateArgs a, int ch0, int n) {
+  const int c = (int)blockIdx.x, t = (int)threadIdx.x;   // one workgroup of 128 threads per channel ch0 + c
+  if (c >= n) return;
+  const size_t ch = (size_t)(ch0 + c);
+  a.als_stage[ch * (ASDR_ALS_STAGE_SLOTS * ASDR_N) + a.als_stage_prev * ASDR_N + t] = a.als_x[ch * (2 * ASDR_N) + ((a.als_phase & 1u) ^ 1u) * ASDR_N + t];
+}
+extern "C" int asdr_launch_als_role(const UpdateArgs *a, int role, hipStream_t stream) {
+  const int n_waves = a->n_sched / 8;
+  if (n_waves <= 0) return 0;
+  if (role == 0 && a->n_blocks > 1) hipLaunchKernelGGL(asdr_als_pre_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  else if (role == 0) hipLaunchKernelGGL(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  else hipLaunchKernelGGL(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int asdr_launch_als_stage_seed(const UpdateArgs *a, int ch0, int n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(asdr_als_stage_seed_kernel, dim3(n), dim3(ASDR_N), 0, stream, *a, ch0, n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

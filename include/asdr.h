@@ -158,6 +158,12 @@ long asdr_lane_calls(asdr_batch_t *b);
  * state; tiles and lock words alternate between two sets).  asdr_sam_role_calls() = calls that ran that way; environment
  * ASDR_NO_SAM_ROLE_STREAMS=1 at asdr_create time switches it off.  (AudioSDR.cpp:688-749 is the chain.) */
 long asdr_sam_role_calls(asdr_batch_t *b);
+/* ALS role streams (round 5): a SMALL bank whose whole schedule is one settings group of channels with a short ALS filter (taps <= 64,
+ * delay + taps <= 65; a known mode; below the one-launch-per-block size) runs a multi-block call as two launches per block -- the chain up to
+ * the AGC | the filter + output -- on two event-chained streams, the filter of block b beside the chain of block b + 1, through a three-slot
+ * stage of post-AGC rows in HBM (1.5 KB per channel, allocated at the first such call).  Bit-identical to the block loop; not taken for in-place
+ * calls or with stage taps.  asdr_als_role_calls() = calls that ran that way; environment ASDR_NO_ALS_ROLE_STREAMS=1 turns it off. */
+long asdr_als_role_calls(asdr_batch_t *b);
 int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves);
 int asdr_synchronize(asdr_batch_t *b);
 

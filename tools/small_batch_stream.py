@@ -36,12 +36,12 @@ for n_ch in (512, 4096):
         for _ in range(2):
             b.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
         b.synchronize()
-        p0 = b.stream_pipeline_launches()
+        p0 = b.stream_pipeline_launches(); r0 = b.als_role_calls()
         t0 = time.perf_counter()
         for _ in range(4):
             b.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, 0)
         b.synchronize()
         ms = (time.perf_counter() - t0) / 4 * 1e3
         print(json.dumps({"family": name, "channels": n_ch, "T": T, "ms_per_call": round(ms, 3), "us_per_block": round(ms * 1e3 / T, 2),
-                          "times_real_time": round(T * 128 / 44100.0 / (ms * 1e-3), 1), "pipeline_calls": b.stream_pipeline_launches() - p0}), flush=True)
+                          "times_real_time": round(T * 128 / 44100.0 / (ms * 1e-3), 1), "pipeline_calls": b.stream_pipeline_launches() - p0, "als_role_calls": b.als_role_calls() - r0}), flush=True)
         b.close()
