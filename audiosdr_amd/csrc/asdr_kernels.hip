@@ -2911,7 +2911,8 @@ extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_als_pre
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 6>(a, lds);
 }
 // ... and with the block loop kept (ROLE 7): the chain launches of the ALS role streams take a chunk of blocks each
-extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_als_pre_loop_kernel(UpdateArgs a) {
+// (two waves per SIMD asked for: these launches are small banks' -- at most 512 waves on 1,024 SIMDs -- and the looped form wants the registers)
+extern "C" __global__ __launch_bounds__(64, 2) void asdr_als_pre_loop_kernel(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 7>(a, lds);
 }
