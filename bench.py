@@ -306,7 +306,9 @@ def other_configs(np, torch, dev, local_rank):
     """BASELINE configs 3, 4 and 5 (their single-GPU shares) ON THE DRIVER'S RECORD: the default `bench.py --gpus 1` line carries, beside
     C2's headline, one short measured region per config -- same method (one HIP-event pair on the launch stream, ASDR_STREAM_BATCH:
     lanes where the schedule has them), SURVEY 8(d)'s bytes, and a one-channel bit-for-bit spot check against the CPU oracle of the
-    blocks in front of the region.  Sized to add a few seconds to the command."""
+    blocks in front of the region.  C3 and C4 carry TWO regions, like the C2 line (its timed window | `roofline.steady_state`):
+    `fresh_bank_ms_per_step` = the steps right behind the spot check (a fresh bank: AGC attacking, PLLs settling) and `ms_per_step` /
+    `frac` = the same region 300 steps later.  Sized to add a few seconds to the command."""
     import audiosdr_amd as A
     from audiosdr_amd.synth import make_iq
     from oracle import asdr_oracle as ao
@@ -314,7 +316,7 @@ def other_configs(np, torch, dev, local_rank):
     stream = A.STREAM_BATCH
     res = {}
 
-    def run(name, n_ch, T, n_in, uniq, sig, configure_batch, configure_oracle, check_ch, warm, timed, algo, kernel, what, capture=False):
+    def run(name, n_ch, T, n_in, uniq, sig, configure_batch, configure_oracle, check_ch, warm, timed, algo, kernel, what, capture=False, settle=0):
         uniq = min(uniq, n_ch)
         I, Q = make_iq(uniq, n_in * T, **sig)                       # [uniq][n_in * T][128]
         reps = (n_ch + uniq - 1) // uniq
@@ -357,11 +359,17 @@ def other_configs(np, torch, dev, local_rank):
             extra["lock_fraction"] = float(batch.read_status()["sam_locked"].mean())
         if capture:
             batch.capture_rewind()
-        ms = measure_region(batch, step, stream, 0, timed)
+        ms_fresh = measure_region(batch, step, stream, 0, timed)   # blocks warm .. warm + timed - 1 of a FRESH bank (AGC attacking, locks settling)
+        ms = ms_fresh
+        if settle > 0:   # ... and the same region again once the bank has run `settle` more steps (what the C2 line calls its steady state)
+            for i in range(settle):
+                step(i)
+            ms = measure_region(batch, step, stream, 0, timed)
         ach = algo * n_ch * T / (ms * 1e-3) / 1e9
         d = {"workload": what, "channels": n_ch, "blocks_per_step": T, "ms_per_step": round(ms, 5), "Msamples_per_s": round(n_ch * T * BLOCK / ms / 1e3, 1),
              "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_channel_block": round(algo, 1), "dominant_kernel": kernel,
-             "steps_timed": timed, "steps_untimed": warm, "lane_calls": batch.lane_calls() - lc0,
+             "steps_timed": timed, "steps_untimed": warm + (timed + settle if settle > 0 else 0), "fresh_bank_ms_per_step": round(ms_fresh, 5),
+             "fresh_bank_region": "steps %d..%d of the bank" % (warm, warm + timed - 1), "lane_calls": batch.lane_calls() - lc0,
              "oracle_spot_check": {"channel": check_ch, "blocks": int(want.shape[0]) if capture else T, "bit_exact": ok}}
         if capture:
             d["times_real_time"] = round(T * BLOCK / 44100.0 / (ms * 1e-3), 1)
@@ -375,13 +383,13 @@ def other_configs(np, torch, dev, local_rank):
     fc3 = 6890.0 + (np.arange(uniq) % 7 - 3) * 50.0
     run("c3", 262144, 1, 16, uniq, dict(fc=fc3, A=0.3, m=0.5, fm=400.0), configure_c3, lambda o, c: configure_c3(o), 262143, 16, 96,
         C3_ALGO_BYTES_PER_BLOCK, "asdr_sam_pre_kernel_uniform | asdr_sam_pll_kernel | asdr_sam_post_kernel_uniform (three launches per block)",
-        "C3: SAM + PLL carrier lock + AGC, 262,144 channels x 1 block/step; carriers 6890 + (c mod 7 - 3) x 50 Hz, 50 % AM at 400 Hz")
+        "C3: SAM + PLL carrier lock + AGC, 262,144 channels x 1 block/step; carriers 6890 + (c mod 7 - 3) x 50 Hz, 50 % AM at 400 Hz", settle=300)
 
     def c4_oracle(o, c):
         o.setDemodMode(c % 7); o.enableALSfilter(); o.setNoiseBlankerThresholdDb(10.0)
     run("c4_share", 131072, 1, 12, uniq, dict(fc=6890.0 - 300, A=0.3, m=0.4, f2=7500.0, a2=0.15), lambda b: configure_c4(b, lib=L), c4_oracle, 100001, 12, 96,
         C4_ALGO_BYTES_PER_BLOCK, "asdr_update_kernel_als_small_one (+ the SAM pre | PLL | post-with-ALS launches and the remainders' launch beside it)",
-        "C4: one GPU's share (131,072 of 1,048,576 channels) of the mixed-mode batch: mode = channel mod 7, ALS notch, blanker at 10 dB; 1 block/step")
+        "C4: one GPU's share (131,072 of 1,048,576 channels) of the mixed-mode batch: mode = channel mod 7, ALS notch, blanker at 10 dB; 1 block/step", settle=300)
     run("c5_share", 512, C5_T, 1, 512, dict(fc=6890.0, A=0.02, noise=0.05), configure_c5, lambda o, c: configure_c5(o), 511, 2, 8,
         C5_ALGO_BYTES_PER_BLOCK, "asdr_stream_kernel (block pipeline)",
         "C5: one GPU's share (512 of 4,096 WSPR receivers, BareBonesWSPR.ino settings); one step = a 646-block call into the capture sink", capture=True)
