@@ -1015,6 +1015,7 @@ void asdr_destroy(asdr_batch_t *b) {
   for (int i = 0; i < ASDR_AUX_STREAMS; i++) if (b->ev_join[i]) hipEventDestroy(b->ev_join[i]);   // (the streams belong to the process-wide pool)
   for (int i = 0; i < ASDR_LANES + 1; i++) if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]);
   for (int i = 0; i < 6; i++) if (b->ev_role[i]) hipEventDestroy(b->ev_role[i]);
+  for (hipEvent_t e : b->ev_als) if (e) hipEventDestroy(e);
   // (b->stream and the helper streams belong to the process-wide pool)
   delete b;
 }
