@@ -87,3 +87,31 @@ def test_als_role_streams_keep_off_in_place_calls_and_mixed_schedules(gpu, ao):
         want2 = orcs[c].update(I[c, T:], Q[c, T:]).reshape(T, 128)
         assert np.array_equal(got[c], want1[c]) and np.array_equal(got2[c], want2), c
     b.close()
+
+
+def test_als_role_streams_on_the_shards_of_a_sharded_batch(gpu, ao):
+    """Two shards on device 0: device rows of a sharded batch go shard by shard; each shard's schedule is one short-filter settings group, so
+    each takes the role streams (they share the device's stream pool: the calls serialise, the results do not change)."""
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, T = 48, 10
+
+    def cfg(s):
+        s.setDemodMode(3); s.setNoiseBlankerThresholdDb(10.0); s.enableALSfilter()
+
+    I, Q = make_iq(n_ch, T, fc=6890.0 + (np.arange(n_ch) % 5 - 2) * 40.0, A=0.3, m=0.4, f2=7600.0, a2=0.12, noise=0.01)
+    sh = gpu.AudioSDRBatch(n_ch, devices=[0, 0])
+    cfg(sh)
+    orcs = []
+    for _ in range(n_ch):
+        o = ao.OracleSDR(); cfg(o); orcs.append(o)
+    dI = torch.from_numpy(I).cuda(); dQ = torch.from_numpy(Q).cuda()
+    dO = torch.zeros((n_ch, T, 128), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    sh.update_device_strided(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, T, T)
+    sh.synchronize()
+    assert sh.als_role_calls() == 2
+    got = dO.cpu().numpy()
+    for c in range(n_ch):
+        assert np.array_equal(got[c], orcs[c].update(I[c], Q[c]).reshape(T, 128)), c
+    sh.close()
