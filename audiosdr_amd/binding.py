@@ -60,7 +60,7 @@ EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read",
             "asdr_create_sharded", "asdr_n_shards", "asdr_shard", "asdr_shard_first_channel", "asdr_shard_device",
             "asdr_host_alloc", "asdr_host_free", "asdr_host_register", "asdr_host_unregister", "asdr_set_host_chunks",
-            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures", "asdr_set_launch_split", "asdr_order_after", "asdr_order_before", "asdr_lane_calls", "asdr_sam_role_calls", "asdr_als_role_calls", "asdr_set_lanes"] +
+            "asdr_host_path_info", "asdr_stream_pipeline_alloc_failures", "asdr_set_launch_split", "asdr_order_after", "asdr_order_before", "asdr_lane_calls", "asdr_sam_role_calls", "asdr_sam_chunk_calls", "asdr_als_role_calls", "asdr_set_lanes"] +
            ["asdr_" + n for n in _SETTERS_VOID + _SETTERS_F + _SETTERS_I + _GETTERS_F + _GETTERS_I])
 
 _lib = None
@@ -158,6 +158,7 @@ def load_library(path=None):
         L.asdr_lane_calls.argtypes = [vp]; L.asdr_lane_calls.restype = C.c_long
         L.asdr_sam_role_calls.argtypes = [vp]; L.asdr_sam_role_calls.restype = C.c_long
         L.asdr_als_role_calls.argtypes = [vp]; L.asdr_als_role_calls.restype = C.c_long
+        L.asdr_sam_chunk_calls.argtypes = [vp]; L.asdr_sam_chunk_calls.restype = C.c_long
         L.asdr_set_lanes.argtypes = [vp, _i, _i]; L.asdr_set_lanes.restype = _i
     if path is None or hasattr(L, "asdr_lanes_overlap_probe"):   # round 5
         L.asdr_lanes_overlap_probe.argtypes = [vp]; L.asdr_lanes_overlap_probe.restype = _i
@@ -224,6 +225,10 @@ class AudioSDRBatch:
     def sam_role_calls(self):
         """Multi-block calls that ran the SAM roles on three chained streams (include/asdr.h)."""
         return int(self._L.asdr_sam_role_calls(self._h))
+
+    def sam_chunk_calls(self):
+        """... of which ran the roles in chunks of 8 blocks per launch (include/asdr.h)."""
+        return int(self._L.asdr_sam_chunk_calls(self._h))
 
     def als_role_calls(self):
         """Multi-block calls of a small short-ALS-filter bank that ran as chain | filter launches on two chained streams (include/asdr.h)."""

@@ -185,6 +185,8 @@ typedef struct {
   uint32_t *sam_lock;     /* ... and the PLL's lock flag of the block, one word per schedule slot of the launch, beside the tiles (not
                              through the status word: when the three roles of consecutive blocks overlap -- pre(k+1) | PLL(k+1) beside
                              post(k), asdr_launch_sam_role -- the status word may already hold block k+1's flag when post(k) reads it) */
+  uint32_t sam_set, sam_sets;           /* chunked SAM role streams (launches of several blocks): block k of the launch uses tile set (sam_set + k) % sam_sets ... */
+  uint32_t sam_set_stride, sam_lock_stride;   /* ... sets sam_set_stride floats (tiles) / sam_lock_stride words (lock flags) apart; all 0 = one set */
   float *als_stage;       /* ALS role streams (a small bank's multi-block call as chain | filter launches on two event-chained streams, asdr_host.cpp):
                              [n_channels][ASDR_ALS_STAGE_SLOTS][128] post-AGC rows of the blocks in flight -- the chain launch of block b stores
                              its row in slot b % S (and in the als_x ring as ever), the filter launch of block b reads slots b % S and (b - 1) % S

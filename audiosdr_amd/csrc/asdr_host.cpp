@@ -28,6 +28,11 @@
 #include "asdr_tables.h"
 
 // batches of at least this many waves issue a multi-block call as one launch per block (asdr_update_device_strided)
+#ifndef ASDR_SAM_CHUNK
+#define ASDR_SAM_CHUNK 8         /* SAM role streams in chunks: blocks per launch ... */
+#define ASDR_SAM_CHUNK_SETS 32   /* ... and tile sets (blocks in flight between the pre role and the post role: four chunks) */
+#define ASDR_SAM_CHUNK_MAX_WAVES 512   /* ... for banks of up to this many waves (4,096 channels: 128 MB of tiles) */
+#endif
 #ifndef ASDR_ALS_ROLE_MAX_WAVES
 #define ASDR_ALS_ROLE_MAX_WAVES 512   /* ALS role streams: banks of up to this many waves (4,096 channels: 64 MB of stage) */
 #endif
@@ -314,6 +319,12 @@ struct asdr_batch {
   // ALS role streams: a SMALL bank of channels with a short ALS filter (one uniform sub-range, below the one-launch-per-block size) runs a
   // multi-block call as chain | filter launches on two event-chained streams, a chunk of blocks per launch -- the filter of a chunk (a
   // 33-epoch dependent chain per block: ~13 us whatever the bank size) beside the chain of the next one -- through a stage of post-AGC rows.
+  // SAM role streams in CHUNKS (round 5): a uniform SAM sub-range's multi-block call as pre | PLL | post launches of ASDR_SAM_CHUNK blocks each
+  // (the roles' block loops kept) -- one event pair per chunk and role instead of per block (every event between two kernels of a queue costs
+  // ~10 us of command-processor time: the per-block form ran 50 us per block for a PLL chain of 32).  Tile sets of ASDR_SAM_CHUNK_SETS blocks.
+  float *d_xch_sam_chunk = nullptr; size_t xch_sam_chunk_slots = 0;
+  long stat_sam_chunk_calls = 0;
+  hipEvent_t ev_samc[3 * (ASDR_SAM_CHUNK_SETS / ASDR_SAM_CHUNK)] = {};   // pre / PLL / post chunk k done, by k % R
   float *d_als_stage = nullptr;     // [n][ASDR_ALS_STAGE_SLOTS][128], allocated at the first such call
   hipEvent_t ev_als[2 * (ASDR_ALS_STAGE_SLOTS / ASDR_ALS_CHUNK)] = {};   // chain chunk k done [k % R], filter chunk k done [R + k % R]
   bool als_role_streams = true;     // (ASDR_NO_ALS_ROLE_STREAMS: off, for measurements)
@@ -1000,7 +1011,7 @@ void asdr_destroy(asdr_batch_t *b) {
   hipDeviceSynchronize();
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
-                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap, b->d_als_stage};
+                  b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap, b->d_als_stage, b->d_xch_sam_chunk};
   for (void *p : ptrs) if (p) hipFree(p);
   b->copy_pool.reset();
   for (int i = 0; i < 3; i++) if (b->h_io[i]) hipHostFree(b->h_io[i]);
@@ -1016,6 +1027,7 @@ void asdr_destroy(asdr_batch_t *b) {
   for (int i = 0; i < ASDR_LANES + 1; i++) if (b->ev_lane[i]) hipEventDestroy(b->ev_lane[i]);
   for (int i = 0; i < 6; i++) if (b->ev_role[i]) hipEventDestroy(b->ev_role[i]);
   for (hipEvent_t e : b->ev_als) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_samc) if (e) hipEventDestroy(e);
   // (b->stream and the helper streams belong to the process-wide pool)
   delete b;
 }
@@ -1332,6 +1344,48 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     HIPCHK(hipStreamWaitEvent(s_pre, b->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_fork, 0));
     b->stat_sam_role_calls++;
   }
+  // ... in chunks when the sub-range is uniform, plain SAM (no ALS) and small: see asdr_batch::d_xch_sam_chunk
+  bool sam_chunks = sam_roles && subs[items[0].sub].kind == ASDR_KERNEL_SAM && subs[items[0].sub].uniform && n_blocks >= 2 * ASDR_SAM_CHUNK &&
+                    items[0].slots <= 8 * ASDR_SAM_CHUNK_MAX_WAVES && getenv("ASDR_NO_SAM_CHUNKS") == nullptr;
+  if (sam_chunks && (size_t)items[0].slots > b->xch_sam_chunk_slots) {
+    HIPCHK(hipStreamSynchronize(stream));
+    float *grown = nullptr;
+    const size_t per_set = (size_t)items[0].slots * 2 * ASDR_N * sizeof(float) + (size_t)items[0].slots * sizeof(uint32_t);
+    if (hipMalloc(&grown, ASDR_SAM_CHUNK_SETS * per_set) == hipSuccess) { if (b->d_xch_sam_chunk) hipFree(b->d_xch_sam_chunk); b->d_xch_sam_chunk = grown; b->xch_sam_chunk_slots = (size_t)items[0].slots; }
+    else { (void)hipGetLastError(); sam_chunks = false; }
+  }
+  int parity_launches_sam = -1;
+  if (sam_chunks) {
+    constexpr int S = ASDR_SAM_CHUNK_SETS, G = ASDR_SAM_CHUNK, R = S / G;
+    static_assert(S % G == 0 && R >= 4, "tile sets for four chunks");
+    for (int i = 0; i < 3 * R; i++) if (!b->ev_samc[i]) HIPCHK(hipEventCreateWithFlags(&b->ev_samc[i], hipEventDisableTiming));
+    const int i0 = items[0].sub, first0 = items[0].first;
+    const size_t slots = b->xch_sam_chunk_slots;
+    a.sched = b->d_sched + first0; a.n_sched = items[0].slots; a.direct_ch0 = -1; a.lo_write = 1u;
+    if (b->kind_direct[subs[i0].kind]) { const SlotInfo &s0 = b->sched[subs[i0].first]; a.direct_ch0 = s0.ch; a.direct_mode = s0.mode; a.direct_flags = s0.flags; a.direct_lo = s0.lo; }
+    a.xch_sam = b->d_xch_sam_chunk; a.sam_lock = reinterpret_cast<uint32_t *>(b->d_xch_sam_chunk + (size_t)S * slots * 2 * ASDR_N);
+    a.sam_sets = (uint32_t)S; a.sam_set_stride = (uint32_t)(slots * 2 * ASDR_N); a.sam_lock_stride = (uint32_t)slots;
+    a.taps = nullptr;
+    const int n_chunks = (n_blocks + G - 1) / G;
+    for (int k = 0; k < n_chunks; k++) {
+      const int b0 = k * G, g = (n_blocks - b0 < G) ? n_blocks - b0 : G, kr = k % R;
+      a.in_i = dI + (size_t)b0 * ASDR_N; a.in_q = dQ + (size_t)b0 * ASDR_N; a.out = dOut + (size_t)b0 * ASDR_N; a.n_blocks = g;
+      a.nb_phase = (b->nb_phase + (uint32_t)(b0 % 3)) % 3u;
+      a.als_phase = (b->als_phase + (uint32_t)b0) & 1u;
+      a.lo_parity = b->lo_parity ^ (uint32_t)(k & 1);
+      a.sam_set = (uint32_t)(b0 % S);
+      // pre(k) writes the tile sets post(k - R) read: the only back-pressure; PLL(k) behind pre(k), post(k) behind PLL(k)
+      if (k >= R) HIPCHK(hipStreamWaitEvent(s_pre, b->ev_samc[2 * R + kr], 0));
+      if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 0, s_pre) != 0) return fail("update kernel launch failed");
+      HIPCHK(hipEventRecord(b->ev_samc[kr], s_pre)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_samc[kr], 0));
+      if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 1, s_pll) != 0) return fail("update kernel launch failed");
+      HIPCHK(hipEventRecord(b->ev_samc[R + kr], s_pll)); HIPCHK(hipStreamWaitEvent(stream, b->ev_samc[R + kr], 0));
+      if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 2, stream) != 0) return fail("update kernel launch failed");
+      HIPCHK(hipEventRecord(b->ev_samc[2 * R + kr], stream));
+    }
+    parity_launches_sam = n_chunks;
+    b->stat_sam_chunk_calls++;
+  }
   const bool als_role_call = als_roles && n_items == 1 && taps == nullptr;
   int parity_launches = n_launch;   // launches that flipped the oscillator cache's halves
   if (als_role_call) {
@@ -1369,7 +1423,8 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     parity_launches = n_chunks;
     b->stat_als_role_calls++;
   }
-  for (int lb = 0; lb < (als_role_call ? 0 : n_launch); lb++) {
+  if (parity_launches_sam >= 0) parity_launches = parity_launches_sam;
+  for (int lb = 0; lb < ((als_role_call || sam_chunks) ? 0 : n_launch); lb++) {
     if (per_block) {
       a.in_i = dI + (size_t)lb * ASDR_N; a.in_q = dQ + (size_t)lb * ASDR_N; a.out = dOut + (size_t)lb * ASDR_N; a.n_blocks = 1;
       a.nb_phase = (b->nb_phase + (uint32_t)(lb % 3)) % 3u;
@@ -1832,6 +1887,10 @@ int asdr_lanes_enabled(asdr_batch_t *b) {
   if (!b->lanes_enabled) return 0;
   const int probe = (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe[b->device] : -1;
   return (probe == 0 && !b->lanes_forced) ? 0 : 1;   // (what the next lane-sized call will do, as far as is known now)
+}
+long asdr_sam_chunk_calls(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_sam_chunk_calls; return t; }
+  return b ? b->stat_sam_chunk_calls : -1;
 }
 long asdr_als_role_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_als_role_calls; return t; }

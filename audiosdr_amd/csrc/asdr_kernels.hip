@@ -1105,9 +1105,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // ROLE 6: the whole chain up to and including the AGC for channels whose (short) ALS filter runs as a launch of its own
   // (asdr_als_kernel): the post-AGC row goes to the ALS input ring instead of through the filter and the output stage.
   constexpr bool C16 = (STRIDE == 320);   // the 16-waves-per-CU form (see below, where the block loop starts)
-  // ROLE 7: role 6 with the block loop kept (ALS role streams: a chunk of blocks per launch).
-  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || ROLE == 4 || ROLE == 6 || ROLE == 7), DO2 = (ROLE == 0 || ROLE == 2 || ROLE == 5 || ROLE == 6 || ROLE == 7),
-                 DO3 = (ROLE == 0 || ROLE == 3 || ROLE == 5 || ROLE == 6 || ROLE == 7);
+  // ROLE 7: role 6 with the block loop kept (ALS role streams: a chunk of blocks per launch).  ROLE 8 / 9: roles 4 / 5 with the block loop
+  // kept (SAM role streams in chunks): block k of the launch works on tile set (a.sam_set + k) % a.sam_sets.
+  constexpr bool PRE_ROLE = (ROLE == 4 || ROLE == 8), POST_ROLE = (ROLE == 5 || ROLE == 9), LOOPED_ROLE = (ROLE == 7 || ROLE == 8 || ROLE == 9);
+  constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || PRE_ROLE || ROLE == 6 || ROLE == 7), DO2 = (ROLE == 0 || ROLE == 2 || POST_ROLE || ROLE == 6 || ROLE == 7),
+                 DO3 = (ROLE == 0 || ROLE == 3 || POST_ROLE || ROLE == 6 || ROLE == 7);
   constexpr bool TO_ALS = (ROLE == 6 || ROLE == 7);
 #ifndef ASDR_ALS_FULL_OPT
 #define ASDR_ALS_FULL_OPT 2
@@ -1115,7 +1117,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // The ALS instantiations gave up two of the plain kernel's orderings for registers (IF rows consumed before the ring prefetches; the
   // merged average + phase loop).  Their LOOP-FREE compact-row forms have the registers for both (round 5: asdr_update_kernel_als_small_one
   // 160 VGPRs, no spills; C4 share -1.3 %, on the lanes -2.5 %); the looped forms keep the old orderings.  Level 0 / 1: measurements.
-  constexpr bool ALS_LOOPFREE = (ASDR_ONEBLK_ALS != 0) && (ONEBLK_ || (ROLE >= 4 && ROLE != 7 && ASDR_ONEBLK_ROLES));
+  constexpr bool ALS_LOOPFREE = (ASDR_ONEBLK_ALS != 0) && (ONEBLK_ || (ROLE >= 4 && !LOOPED_ROLE && ASDR_ONEBLK_ROLES));
   constexpr bool ALS_FULL_OPT = (ASDR_ALS_FULL_OPT >= 1) && ASDR_COMPACT_ROWS(STRIDE) && ALS_LOOPFREE,
                  ALS_FULL_OPT2 = (ASDR_ALS_FULL_OPT >= 2) && ASDR_COMPACT_ROWS(STRIDE) && ALS_LOOPFREE;
   constexpr bool STREAM = (ROLE >= 1 && ROLE <= 3);
@@ -1179,7 +1181,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 
   // (The ALS instantiations' loop-free builds failed the ALS parity tests until the guard of the tap store-back was taken from an opaque copy
   // of the flag word: a compiler issue, see there.)
-  constexpr bool ONEBLK = (!HAS_ALS || ASDR_ONEBLK_ALS) && (ONEBLK_ || (ROLE >= 4 && ROLE != 7 && ASDR_ONEBLK_ROLES));
+  constexpr bool ONEBLK = (!HAS_ALS || ASDR_ONEBLK_ALS) && (ONEBLK_ || (ROLE >= 4 && !LOOPED_ROLE && ASDR_ONEBLK_ROLES));
   constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);
   // C16 (round 5, asdr_update_kernel_c16): the same chain on 320-float rows and <= 128 VGPRs -- 10,240 B of LDS per wave, FOUR waves per
   // SIMD = 16 per CU.  Direct one-block launches of ONE SSB-class settings group without stage taps (the launcher's choice: mode and
@@ -1906,9 +1908,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // SAM as three launches: this wave's tile of the exchange buffer, [sample][I, Q][slot in tile] (8 KB, written / read whole)
     // The tile moves as 512 sixteen-byte pieces, lane l on pieces l, l + 64, ..: piece p = (sample p / 4, I or Q = (p / 2) % 2, slots
     // 4 (p % 2) .. + 3) -- one wave instruction moves 1 KB contiguous; the four values of a piece come from four channels' LDS rows.
-    float *const sam_tile = (ROLE >= 4) ? a.xch_sam + (size_t)wave_g * (2 * ASDR_N * 8) : nullptr;
+    // (the looped roles: tile set (a.sam_set + blk) % a.sam_sets; the others: a.sam_set_stride == 0, one set)
+    const uint32_t sam_set_k = (LOOPED_ROLE && a.sam_sets > 1u) ? (a.sam_set + (uint32_t)blk) % a.sam_sets : 0u;
+    float *const sam_tile = (ROLE >= 4) ? a.xch_sam + (size_t)sam_set_k * a.sam_set_stride + (size_t)wave_g * (2 * ASDR_N * 8) : nullptr;
     float *const sam_lds = lds + (4 * (lane_i & 1)) * STRIDE + (((lane_i >> 1) & 1) ? W1 : W0) + (lane_i >> 2);
-    if (ROLE == 4) {   // the IF output leaves for the PLL kernel; the rest of the chain is the post kernel's
+    if (PRE_ROLE) {   // the IF output leaves for the PLL kernel; the rest of the chain is the post kernel's
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float *src = sam_lds + 16 * k;
@@ -1956,7 +1960,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       WAVE_SYNC();
       if (is_sam) pll_locked = Li[SCR0] != 0;
     }
-    if (ROLE == 5) {   // the rows as the PLL kernel left them (rotated where it was locked), and its lock flag
+    if (POST_ROLE) {   // the rows as the PLL kernel left them (rotated where it was locked), and its lock flag
       float4 pc[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) pc[k] = *reinterpret_cast<const float4 *>(sam_tile + 4 * (lane_i + 64 * k));
@@ -1965,7 +1969,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         float *dst = sam_lds + 16 * k;
         dst[0] = pc[k].x; dst[STRIDE] = pc[k].y; dst[2 * STRIDE] = pc[k].z; dst[3 * STRIDE] = pc[k].w;
       }
-      if (is_sam) pll_locked = a.sam_lock[wave_g * 8 + c8] != 0u;   // (as the PLL kernel left it for THIS block: see UpdateArgs.sam_lock)
+      if (is_sam) pll_locked = a.sam_lock[(size_t)sam_set_k * a.sam_lock_stride + wave_g * 8 + c8] != 0u;   // (as the PLL kernel left it for THIS block: see UpdateArgs.sam_lock)
       WAVE_SYNC();
     }
     // envelope detector runs for AM, and for SAM when the PLL is unlocked at the end of the block (:132)
@@ -2766,7 +2770,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #endif
       }
     }
-    if (ROLE == 5) store_status_bits(ASDR_S_AGC_ACTIVE);   // (the pre role and the PLL of the NEXT block may be running beside this one)
+    if (POST_ROLE) store_status_bits(ASDR_S_AGC_ACTIVE);   // (the pre role and the PLL of the NEXT block may be running beside this one)
     else if (!STREAM) { if (lead) S->status = status; }
     else { store_status_bits(ASDR_S_AGC_ACTIVE); sig_pending = (uint32_t)blk + 1u; }
     WAVE_SYNC();
@@ -2890,6 +2894,16 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_sam_pre_kernel_uniform(
 extern "C" __global__ __launch_bounds__(64, ASDR_POST_BOUNDS) void asdr_sam_post_kernel_uniform(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 5>(a, lds);
+}
+// ... and with the block loop kept (ROLE 8 / 9): the chunked SAM role streams of small banks (asdr_launch_sam_role with n_blocks > 1; two waves
+// per SIMD asked for: at most a few hundred waves, and the looped forms want the registers)
+extern "C" __global__ __launch_bounds__(64, 2) void asdr_sam_pre_loop_kernel_uniform(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 8>(a, lds);
+}
+extern "C" __global__ __launch_bounds__(64, 2) void asdr_sam_post_loop_kernel_uniform(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 9>(a, lds);
 }
 // ... and for SAM channels with a short ALS filter (ASDR_KERNEL_SAM_ALS): the filter is the post role's last stage, on the compact rows
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_als_kernel(UpdateArgs a) {
@@ -3027,14 +3041,18 @@ extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs 
   const int4 sl = *reinterpret_cast<const int4 *>(a.sched + s);   // {channel, mode, flags, -}
   if (sl.x >= a.n_channels || (uint32_t)sl.y != ASDR_SAMmode) return;
   ChanSmall *Sc = a.small + sl.x;
-  float *const xt = a.xch_sam + (size_t)(s >> 3) * (2 * ASDR_N * 8) + (s & 7);
+  bool lk = false;
+#pragma unroll 1
+  for (int blk = 0; blk < a.n_blocks; ++blk) {   // (one block per launch but in the chunked role streams: tile set (a.sam_set + blk) % a.sam_sets)
+  const uint32_t set_k = (a.sam_sets > 1u) ? (a.sam_set + (uint32_t)blk) % a.sam_sets : 0u;
+  float *const xt = a.xch_sam + (size_t)set_k * a.sam_set_stride + (size_t)(s >> 3) * (2 * ASDR_N * 8) + (s & 7);
   // (The kernel is bound by its instruction count -- ~120 per sample and lane, 61 k wave instructions per SIMD for C3, as many as
   // the whole C2 chain -- not by these 32-byte accesses: 16-sample trips with the next trip's values requested ahead, and without
   // the stores altogether, changed its 0.18 ms by less than 0.01 / 0.04 ms.)
 #ifndef ASDR_PLL_NO_PREFETCH
-  const bool lk = pll_loop<false, 4, true>(Sc, a.k, sine, a.k.two_pi_f,
+  lk = pll_loop<false, 4, true>(Sc, a.k, sine, a.k.two_pi_f,
 #else
-  const bool lk = pll_loop<false, 4>(Sc, a.k, sine, a.k.two_pi_f,
+  lk = pll_loop<false, 4>(Sc, a.k, sine, a.k.two_pi_f,
 #endif
     [&](int i, float *xr, float *xi) {
 #pragma unroll
@@ -3042,7 +3060,8 @@ extern "C" __global__ __launch_bounds__(64) void asdr_sam_pll_kernel(UpdateArgs 
     [&](int i, const float *xr, const float *xi) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) { float *e = xt + (size_t)(i + u) * 16; e[0] = xr[u]; e[8] = xi[u]; } });
-  a.sam_lock[s] = lk ? 1u : 0u;
+  a.sam_lock[(size_t)set_k * a.sam_lock_stride + s] = lk ? 1u : 0u;
+  }
   if (((Sc->status & ASDR_S_PLL_LOCKED) != 0u) != lk) {   // (one bit of a word other roles update too; only this kernel writes this one)
     if (lk) atomicOr(&Sc->status, ASDR_S_PLL_LOCKED); else atomicAnd(&Sc->status, ~ASDR_S_PLL_LOCKED);
   }
@@ -3308,6 +3327,13 @@ extern "C" int asdr_launch_als_stage_seed(const UpdateArgs *a, int ch0, int n, h
 extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int uniform, int role, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
+  if (a->n_blocks > 1) {   // the chunked form: uniform SAM sub-ranges only (asdr_host.cpp)
+    if (!uniform || variant != ASDR_KERNEL_SAM) return -1;
+    if (role == 0) hipLaunchKernelGGL(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else if (role == 1) hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
+    else hipLaunchKernelGGL(asdr_sam_post_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (role == 0) {
     if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);

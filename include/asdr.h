@@ -158,6 +158,10 @@ long asdr_lane_calls(asdr_batch_t *b);
  * state; tiles and lock words alternate between two sets).  asdr_sam_role_calls() = calls that ran that way; environment
  * ASDR_NO_SAM_ROLE_STREAMS=1 at asdr_create time switches it off.  (AudioSDR.cpp:688-749 is the chain.) */
 long asdr_sam_role_calls(asdr_batch_t *b);
+/* ... of which (round 5) ran the three roles in CHUNKS of 8 blocks per launch (their block loops kept, 32 tile sets): uniform SAM banks
+ * without the ALS filter of up to 4,096 channels, calls of 16 blocks or more -- one event pair per chunk and role instead of per block.
+ * Environment ASDR_NO_SAM_CHUNKS=1 keeps the per-block form. */
+long asdr_sam_chunk_calls(asdr_batch_t *b);
 /* ALS role streams (round 5): a SMALL bank whose whole schedule is one settings group of channels with a short ALS filter (taps <= 64,
  * delay + taps <= 65; a known mode; below the one-launch-per-block size) runs a multi-block call as two launches per block -- the chain up to
  * the AGC | the filter + output -- on two event-chained streams, the filter of block b beside the chain of block b + 1, through a three-slot

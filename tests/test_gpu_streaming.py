@@ -408,6 +408,46 @@ def test_sam_role_streams(gpu, ao, als):
     hip.free_all(); batch.close()
 
 
+def test_sam_role_streams_in_chunks(gpu, ao):
+    """... and in CHUNKS (include/asdr.h asdr_sam_chunk_calls): calls of 16 blocks or more of a uniform SAM bank run pre | PLL | post launches
+    of 8 blocks each, their block loops kept, through 32 tile sets.  Same drive as above -- the lock flag changes from block to block at
+    channel-dependent splice points, so post(k) must read PLL(k)'s flag and tile of the RIGHT set while later chunks are in flight -- with calls
+    of 19, 1, 43 (more than the sets: the pre role waits for the post role) and 16 blocks handing the state to each other and to the
+    one-call-one-block form."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 512, (19, 1, 43, 16)
+    total = sum(plan)
+    near = 6890.0 + (np.arange(n_ch) % 7 - 3) * 40.0
+    Ia, Qa = make_iq(n_ch, total, fc=near, A=0.3, m=0.5, fm=400.0, noise=0.005)
+    Ib, Qb = make_iq(n_ch, total, fc=near + 2500.0, A=0.25, m=0.3, fm=300.0, noise=0.005)   # 2.5 kHz off: no lock
+    I, Q = Ia.copy(), Qa.copy()
+    for c in range(n_ch):
+        for b in range(total):
+            if ((b + c % 5) // 3) % 3 == 2:
+                I[c, b], Q[c, b] = Ib[c, b], Qb[c, b]
+    setters = [S("setDemodMode", 5), S("setNoiseBlankerThresholdDb", 10.0), S("enableAudioFilter"), S("setAudioFilter", 0)]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    hip = Hip()
+    pos, locks = 0, set()
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(0, n_ch, 3):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call of %d blocks at %d, ch %d: first differing block %d" % (T, pos, c, int(np.nonzero((got[c] != want).any(axis=1))[0][0]))
+        st = batch.read_status()
+        for c in range(0, n_ch, 21):
+            assert int(st["sam_locked"][c]) == orcs[c].getSAMphaseLockStatus(), "lock flag after block %d, ch %d" % (pos + T - 1, c)
+            locks.add(int(st["sam_locked"][c]))
+        pos += T
+    assert batch.sam_chunk_calls() == sum(1 for T in plan if T >= 16)
+    assert batch.sam_role_calls() == sum(1 for T in plan if T >= 2)
+    hip.free_all(); batch.close()
+
+
 def test_in_place_calls_never_take_the_pipeline(gpu, ao):
     """The pipeline's recovery restores channel state, not caller buffers: a call whose output rows alias its I rows (the reference's
     own convention, AudioSDR.cpp:158-165: the audio is written into blockI) keeps the in-kernel block loop -- also with injected
