@@ -326,7 +326,8 @@ struct asdr_batch {
   long stat_sam_chunk_calls = 0;
   hipEvent_t ev_samc[3 * (ASDR_SAM_CHUNK_SETS / ASDR_SAM_CHUNK)] = {};   // pre / PLL / post chunk k done, by k % R
   float *d_als_stage = nullptr;     // [n][ASDR_ALS_STAGE_SLOTS][128], allocated at the first such call
-  hipEvent_t ev_als[2 * (ASDR_ALS_STAGE_SLOTS / ASDR_ALS_CHUNK)] = {};   // chain chunk k done [k % R], filter chunk k done [R + k % R]
+  hipEvent_t ev_als[3 * (ASDR_ALS_STAGE_SLOTS / ASDR_ALS_CHUNK)] = {};   // chain (back half) chunk k done [k % R], filter chunk k done [R + k % R], front half chunk k done [2 R + k % R]
+  int als_role_stages = 3;          // 3: front half | back half | filter on three streams (ASDR_ALS_ROLE_STAGES=2: the whole chain | filter on two)
   bool als_role_streams = true;     // (ASDR_NO_ALS_ROLE_STREAMS: off, for measurements)
   long stat_als_role_calls = 0;
   bool plain_uniform_ssb = false;   // every uniform wave of the plain instantiation runs an SSB-class mode or AM: the modes the block pipeline has roles for (checked when the schedule is built)
@@ -757,7 +758,22 @@ hipStream_t pool_stream(int device, int i) {
   std::lock_guard<std::mutex> g(p.m);
   if (p.size == 0) { const char *e = getenv("ASDR_STREAM_POOL"); p.size = e ? std::max(1, std::min(atoi(e), kPoolMax)) : 3; }
   const int k = (i < 0) ? p.size - 1 : i % p.size;
-  if (!p.s[k] && hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (!p.s[k]) {
+    // The pool's streams are created at the HIGHEST stream priority (round 5).  The runtime keeps its hardware queues per priority level, so the
+    // pool no longer shares queues with whatever streams the application creates at the default priority: with two application streams
+    // created in front of the pool the lanes' overlap probe read "serialised" (lanes off: 0.110 instead of 0.099 ms per C2 step), and the
+    // role streams of a caller with a stream of its own ran 57 instead of 37 us per SAM block -- both gone at either other priority
+    // (profiles/README.md).  ASDR_POOL_PRIORITY=normal | low: the default level (round 4's behaviour) / the lowest.
+    static const char *pe = getenv("ASDR_POOL_PRIORITY");
+    hipError_t rc;
+    if (pe == nullptr || pe[0] != 'n') {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      rc = hipStreamCreateWithPriority(&p.s[k], hipStreamNonBlocking, (pe != nullptr && pe[0] == 'l') ? least : greatest);
+      if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking); }
+    } else rc = hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking);
+    if (rc != hipSuccess) { (void)hipGetLastError(); p.s[k] = nullptr; return nullptr; }
+  }
   return p.s[k];
 }
 // Do two streams of the pool really run at the same time?  The lanes rest on it: HIP maps the streams of a process onto a
@@ -907,6 +923,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     b->lanes_enabled = getenv("ASDR_NO_LANES") == nullptr;   // (the overlap probe runs at the first call that would use the lanes: update_device_part)
     b->sam_role_streams = getenv("ASDR_NO_SAM_ROLE_STREAMS") == nullptr;
     b->als_role_streams = getenv("ASDR_NO_ALS_ROLE_STREAMS") == nullptr;
+    if (getenv("ASDR_ALS_ROLE_STAGES")) b->als_role_stages = atoi(getenv("ASDR_ALS_ROLE_STAGES")) == 2 ? 2 : 3;
     if (ok && (b->stream = pool_stream(device, 0)) == nullptr) ok = false;   // the pool's first stream (= lane 0: a batch runs on the lanes or on its own stream, never both at once)
     if (ok && hipEventCreate(&b->ev0) != hipSuccess) ok = false;
     if (ok && hipEventCreate(&b->ev1) != hipSuccess) ok = false;
@@ -1347,13 +1364,17 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
   // ... in chunks when the sub-range is uniform, plain SAM (no ALS) and small: see asdr_batch::d_xch_sam_chunk
   bool sam_chunks = sam_roles && subs[items[0].sub].kind == ASDR_KERNEL_SAM && subs[items[0].sub].uniform && n_blocks >= 2 * ASDR_SAM_CHUNK &&
                     items[0].slots <= 8 * ASDR_SAM_CHUNK_MAX_WAVES && getenv("ASDR_NO_SAM_CHUNKS") == nullptr;
-  if (sam_chunks && (size_t)items[0].slots > b->xch_sam_chunk_slots) {
-    HIPCHK(hipStreamSynchronize(stream));
+  auto chunk_tiles = [&](int slots) -> bool {   // ASDR_SAM_CHUNK_SETS tile sets (+ lock words) for `slots` schedule slots; false: no memory
+    if ((size_t)slots <= b->xch_sam_chunk_slots) return true;
+    if (hipStreamSynchronize(stream) != hipSuccess) return false;
     float *grown = nullptr;
-    const size_t per_set = (size_t)items[0].slots * 2 * ASDR_N * sizeof(float) + (size_t)items[0].slots * sizeof(uint32_t);
-    if (hipMalloc(&grown, ASDR_SAM_CHUNK_SETS * per_set) == hipSuccess) { if (b->d_xch_sam_chunk) hipFree(b->d_xch_sam_chunk); b->d_xch_sam_chunk = grown; b->xch_sam_chunk_slots = (size_t)items[0].slots; }
-    else { (void)hipGetLastError(); sam_chunks = false; }
-  }
+    const size_t per_set = (size_t)slots * 2 * ASDR_N * sizeof(float) + (size_t)slots * sizeof(uint32_t);
+    if (hipMalloc(&grown, ASDR_SAM_CHUNK_SETS * per_set) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (b->d_xch_sam_chunk) hipFree(b->d_xch_sam_chunk);
+    b->d_xch_sam_chunk = grown; b->xch_sam_chunk_slots = (size_t)slots;
+    return true;
+  };
+  if (sam_chunks && !chunk_tiles(items[0].slots)) sam_chunks = false;
   int parity_launches_sam = -1;
   if (sam_chunks) {
     constexpr int S = ASDR_SAM_CHUNK_SETS, G = ASDR_SAM_CHUNK, R = S / G;
@@ -1367,21 +1388,32 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     a.sam_sets = (uint32_t)S; a.sam_set_stride = (uint32_t)(slots * 2 * ASDR_N); a.sam_lock_stride = (uint32_t)slots;
     a.taps = nullptr;
     const int n_chunks = (n_blocks + G - 1) / G;
-    for (int k = 0; k < n_chunks; k++) {
-      const int b0 = k * G, g = (n_blocks - b0 < G) ? n_blocks - b0 : G, kr = k % R;
+    // TWO streams: the pre and post roles share the caller's stream -- pre(k + 1), then post(k) -- and the PLL has the helper stream to itself:
+    // its 32 us per block bound the call either way (pre + post are ~24), and a third stream is one too many for a process whose caller
+    // has a stream of its own (HIP's four hardware queues: 49 instead of 37 us per block measured with three, asdr.h "what the lanes rest on").
+    // Tile sets: pre(k) overwrites those of chunk k - R, whose post role is earlier in the same stream.
+    auto chunk_args = [&](int k) {
+      const int b0 = k * G, g = (n_blocks - b0 < G) ? n_blocks - b0 : G;
       a.in_i = dI + (size_t)b0 * ASDR_N; a.in_q = dQ + (size_t)b0 * ASDR_N; a.out = dOut + (size_t)b0 * ASDR_N; a.n_blocks = g;
       a.nb_phase = (b->nb_phase + (uint32_t)(b0 % 3)) % 3u;
       a.als_phase = (b->als_phase + (uint32_t)b0) & 1u;
       a.lo_parity = b->lo_parity ^ (uint32_t)(k & 1);
       a.sam_set = (uint32_t)(b0 % S);
-      // pre(k) writes the tile sets post(k - R) read: the only back-pressure; PLL(k) behind pre(k), post(k) behind PLL(k)
-      if (k >= R) HIPCHK(hipStreamWaitEvent(s_pre, b->ev_samc[2 * R + kr], 0));
-      if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 0, s_pre) != 0) return fail("update kernel launch failed");
-      HIPCHK(hipEventRecord(b->ev_samc[kr], s_pre)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_samc[kr], 0));
-      if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 1, s_pll) != 0) return fail("update kernel launch failed");
-      HIPCHK(hipEventRecord(b->ev_samc[R + kr], s_pll)); HIPCHK(hipStreamWaitEvent(stream, b->ev_samc[R + kr], 0));
-      if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 2, stream) != 0) return fail("update kernel launch failed");
-      HIPCHK(hipEventRecord(b->ev_samc[2 * R + kr], stream));
+    };
+    for (int k = 0; k <= n_chunks; k++) {
+      if (k < n_chunks) {
+        const int kr = k % R;
+        chunk_args(k);
+        if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 0, stream) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_samc[kr], stream)); HIPCHK(hipStreamWaitEvent(s_pll, b->ev_samc[kr], 0));
+        if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 1, s_pll) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_samc[R + kr], s_pll));
+      }
+      if (k >= 1) {
+        chunk_args(k - 1);
+        HIPCHK(hipStreamWaitEvent(stream, b->ev_samc[R + (k - 1) % R], 0));
+        if (asdr_launch_sam_role(&a, ASDR_KERNEL_SAM, 1, 2, stream) != 0) return fail("update kernel launch failed");
+      }
     }
     parity_launches_sam = n_chunks;
     b->stat_sam_chunk_calls++;
@@ -1407,6 +1439,21 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     a.als_stage = b->d_als_stage; a.als_stage_cur = 0u; a.als_stage_prev = (uint32_t)(S - 1); a.als_phase = b->als_phase;
     if (asdr_launch_als_stage_seed(&a, 0, b->n, s_chain) != 0) return fail("update kernel launch failed");
     const int n_chunks = (n_blocks + G - 1) / G;
+    // Three stages (default): the chain itself is cut where the SAM roles cut it -- front half (scale, blanker, IF band-pass: the looped SAM
+    // pre role, into tile sets) | back half (mixer .. AGC, ROLE 10, from the tiles into the stage) | filter -- on three streams: the chain as
+    // ONE stage is 23 us per block for a lone wave and bounds the two-stage form; its halves are ~11 and ~13, the filter 18.
+    static_assert(ASDR_SAM_CHUNK == ASDR_ALS_CHUNK, "the two chunked forms share the tile sets");
+    constexpr int RT = ASDR_SAM_CHUNK_SETS / G;
+    hipStream_t s_front = nullptr;
+    bool three = b->als_role_stages == 3 && chunk_tiles(items[0].slots);
+    if (three) { s_front = aux_stream(b, 1); if (!s_front) three = false; }
+    if (three) {
+      for (int i = 2 * R; i < 3 * R; i++) if (!b->ev_als[i]) HIPCHK(hipEventCreateWithFlags(&b->ev_als[i], hipEventDisableTiming));
+      HIPCHK(hipStreamWaitEvent(s_front, b->ev_fork, 0));
+      const size_t slots = b->xch_sam_chunk_slots;
+      a.xch_sam = b->d_xch_sam_chunk; a.sam_lock = reinterpret_cast<uint32_t *>(b->d_xch_sam_chunk + (size_t)ASDR_SAM_CHUNK_SETS * slots * 2 * ASDR_N);
+      a.sam_sets = (uint32_t)ASDR_SAM_CHUNK_SETS; a.sam_set_stride = (uint32_t)(slots * 2 * ASDR_N); a.sam_lock_stride = (uint32_t)slots;
+    }
     for (int k = 0; k < n_chunks; k++) {
       const int b0 = k * G, g = (n_blocks - b0 < G) ? n_blocks - b0 : G;
       a.in_i = dI + (size_t)b0 * ASDR_N; a.in_q = dQ + (size_t)b0 * ASDR_N; a.out = dOut + (size_t)b0 * ASDR_N; a.n_blocks = g;
@@ -1414,8 +1461,14 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
       a.als_phase = (b->als_phase + (uint32_t)b0) & 1u;
       a.lo_parity = b->lo_parity ^ (uint32_t)(k & 1);
       a.als_stage_cur = (uint32_t)(b0 % S); a.als_stage_prev = (uint32_t)((b0 + S - 1) % S);
+      a.sam_set = (uint32_t)(b0 % ASDR_SAM_CHUNK_SETS);
+      if (three) {   // front(k) writes the tile sets back(k - RT) read
+        if (k >= RT) HIPCHK(hipStreamWaitEvent(s_front, b->ev_als[(k - RT) % R], 0));
+        if (asdr_launch_als_role(&a, 2, s_front) != 0) return fail("update kernel launch failed");
+        HIPCHK(hipEventRecord(b->ev_als[2 * R + k % R], s_front)); HIPCHK(hipStreamWaitEvent(s_chain, b->ev_als[2 * R + k % R], 0));
+      }
       if (k >= R - 1) HIPCHK(hipStreamWaitEvent(s_chain, b->ev_als[R + (k + 1) % R], 0));
-      if (asdr_launch_als_role(&a, 0, s_chain) != 0) return fail("update kernel launch failed");
+      if (asdr_launch_als_role(&a, three ? 3 : 0, s_chain) != 0) return fail("update kernel launch failed");
       HIPCHK(hipEventRecord(b->ev_als[k % R], s_chain)); HIPCHK(hipStreamWaitEvent(stream, b->ev_als[k % R], 0));
       if (asdr_launch_als_role(&a, 1, stream) != 0) return fail("update kernel launch failed");
       HIPCHK(hipEventRecord(b->ev_als[R + k % R], stream));

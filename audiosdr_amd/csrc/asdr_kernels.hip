@@ -1107,10 +1107,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   constexpr bool C16 = (STRIDE == 320);   // the 16-waves-per-CU form (see below, where the block loop starts)
   // ROLE 7: role 6 with the block loop kept (ALS role streams: a chunk of blocks per launch).  ROLE 8 / 9: roles 4 / 5 with the block loop
   // kept (SAM role streams in chunks): block k of the launch works on tile set (a.sam_set + k) % a.sam_sets.
-  constexpr bool PRE_ROLE = (ROLE == 4 || ROLE == 8), POST_ROLE = (ROLE == 5 || ROLE == 9), LOOPED_ROLE = (ROLE == 7 || ROLE == 8 || ROLE == 9);
+  // ROLE 10: role 9 whose post-AGC row goes to the ALS stage instead of through the output stage (the three-stage ALS role streams).
+  constexpr bool PRE_ROLE = (ROLE == 4 || ROLE == 8), POST_ROLE = (ROLE == 5 || ROLE == 9 || ROLE == 10), LOOPED_ROLE = (ROLE == 7 || ROLE == 8 || ROLE == 9 || ROLE == 10);
   constexpr bool DO1 = (ROLE == 0 || ROLE == 1 || PRE_ROLE || ROLE == 6 || ROLE == 7), DO2 = (ROLE == 0 || ROLE == 2 || POST_ROLE || ROLE == 6 || ROLE == 7),
                  DO3 = (ROLE == 0 || ROLE == 3 || POST_ROLE || ROLE == 6 || ROLE == 7);
-  constexpr bool TO_ALS = (ROLE == 6 || ROLE == 7);
+  constexpr bool TO_ALS = (ROLE == 6 || ROLE == 7 || ROLE == 10);
 #ifndef ASDR_ALS_FULL_OPT
 #define ASDR_ALS_FULL_OPT 2
 #endif
@@ -2905,6 +2906,12 @@ extern "C" __global__ __launch_bounds__(64, 2) void asdr_sam_post_loop_kernel_un
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
   asdr_update_body<ASDR_STRIDE, false, false, true, 1, 9>(a, lds);
 }
+// ... and the back half of the chain as a role of its own (ROLE 10: mixer .. AGC from the tile the looped pre role left, the post-AGC row into
+// the ALS stage): the three-stage ALS role streams
+extern "C" __global__ __launch_bounds__(64, 2) void asdr_als_back_loop_kernel(UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  asdr_update_body<ASDR_STRIDE, false, false, true, 1, 10>(a, lds);
+}
 // ... and for SAM channels with a short ALS filter (ASDR_KERNEL_SAM_ALS): the filter is the post role's last stage, on the compact rows
 extern "C" __global__ __launch_bounds__(64, ASDR_WAVES_PER_EU) void asdr_sam_post_als_kernel(UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_ALS_STRIDE];
@@ -3311,7 +3318,9 @@ extern "C" __global__ void asdr_als_stage_seed_kernel(UpdateArgs a, int ch0, int
 extern "C" int asdr_launch_als_role(const UpdateArgs *a, int role, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (role == 0 && a->n_blocks > 1) hipLaunchKernelGGL(asdr_als_pre_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  if (role == 2) hipLaunchKernelGGL(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);      // three stages: the front half (scale, blanker, IF) -> tiles
+  else if (role == 3) hipLaunchKernelGGL(asdr_als_back_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);       // ... the back half (mixer .. AGC) -> stage
+  else if (role == 0 && a->n_blocks > 1) hipLaunchKernelGGL(asdr_als_pre_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   else if (role == 0) hipLaunchKernelGGL(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   else hipLaunchKernelGGL(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -131,6 +131,9 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
  * bit-identical either way (the halves touch disjoint channels; each lane has its own local-oscillator cache entries).
  * asdr_lane_calls() = calls that ran on the lanes so far; asdr_set_lanes(b, on, min_waves) switches them off / moves the smallest
  * batch (in waves of 8 channels, default 1024) that uses them; environment ASDR_NO_LANES=1 at asdr_create time = default off.
+ * Since round 5 the pool's streams are created at the HIGHEST stream priority: the runtime keeps hardware queues per priority level, so the
+ * pool does not share queues with streams the application creates at the default priority (measured: what follows, gone; environment
+ * ASDR_POOL_PRIORITY=normal restores the default level, =low picks the lowest).
  * WHAT THE LANES REST ON, and what breaks them.  The batch's own streams come from ONE pool of three non-blocking streams per device and
  * process, shared by every batch of the process on that device (asdr_synchronize / the host path of one batch therefore also waits for
  * other batches' work on those streams; device ordinals 0..15).  HIP maps the streams a process uses onto a few hardware queues (four by

@@ -1,6 +1,6 @@
 """ALS role streams (include/asdr.h, asdr_host.cpp): a SMALL bank whose schedule is one settings group of channels with a short ALS filter runs
 a multi-block call as chain | filter launches per block on two event-chained streams, the filter of block b beside the chain of block b + 1,
-through a three-slot stage of post-AGC rows.  Everything against the oracle, bit for bit; the form must leave the als_x ring as the fused
+through a stage of post-AGC rows (and, in the three-stage form, tile sets between the chain's halves), a chunk of 8 blocks per launch.  Everything against the oracle, bit for bit; the form must leave the als_x ring as the fused
 kernel expects it (single-block calls in between), honour setters between calls, and keep off in-place calls."""
 import os
 
@@ -19,8 +19,10 @@ def _bank(gpu, ao, n_ch, cfg):
     return b, orcs
 
 
+@pytest.mark.parametrize("stages", [3, 2])
 @pytest.mark.parametrize("mode,params", [(1, None), (0, (64, 0.5, 1)), (4, (33, 0.7, 32))])
-def test_als_role_streams_equal_the_oracle(gpu, ao, mode, params):
+def test_als_role_streams_equal_the_oracle(gpu, ao, mode, params, stages, monkeypatch):
+    monkeypatch.setenv("ASDR_ALS_ROLE_STAGES", str(stages))   # (read at asdr_create: 3 = front half | back half | filter on three streams, 2 = chain | filter)
     import torch
     from audiosdr_amd.synth import make_iq
     n_ch, plan = 72, (1, 6, 1, 5, 2, 9)

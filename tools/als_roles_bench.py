@@ -12,7 +12,10 @@ for n_ch in (512,):
         st = torch.cuda.Stream() if use_stream else None
         h = st.cuda_stream if st else 0
         b = A.AudioSDRBatch(n_ch)
-        b.setDemodMode(1); b.enableALSfilter(); b.setNoiseBlankerThresholdDb(10.0)
+        if os.environ.get("BENCH_SAM"):
+            b.setDemodMode(5); b.setNoiseBlankerThresholdDb(10.0); b.enableAudioFilter(); b.setAudioFilter(0)
+        else:
+            b.setDemodMode(1); b.enableALSfilter(); b.setNoiseBlankerThresholdDb(10.0)
         torch.cuda.synchronize()
         for _ in range(2): b.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, h)
         b.synchronize()
@@ -20,5 +23,5 @@ for n_ch in (512,):
         for _ in range(4): b.update_device(dI.data_ptr(), dQ.data_ptr(), dO.data_ptr(), T, h)
         b.synchronize()
         ms = (time.perf_counter() - t0) / 4 * 1e3
-        print(json.dumps({"stream": "created" if use_stream else "null", "us_per_block": round(ms * 1e3 / T, 2), "als_role_calls": b.als_role_calls()}), flush=True)
+        print(json.dumps({"stream": "created" if use_stream else "null", "us_per_block": round(ms * 1e3 / T, 2), "als_role_calls": b.als_role_calls(), "sam_chunk_calls": b.sam_chunk_calls()}), flush=True)
         b.close()
