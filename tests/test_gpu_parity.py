@@ -428,12 +428,14 @@ def test_device_pointer_entry_point_and_stream(gpu, ao):
         batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
     ms = batch.kernel_timing_end(3)
     assert len(ms) == 3 and (ms > 0).all()
-    # one pair around a region of calls (bench.py's kernel_ms): not less than the kernels inside it
+    # one pair around a region of calls (bench.py's kernel_ms): the four kernels' time.  (Compared loosely: a per-launch pair above carries
+    # its own event packets -- 0.24-0.34 ms per call here against 0.19 inside a region -- so "4 x the fastest timed launch" is no lower bound;
+    # the 0.8 factor this line had failed 4 runs of 14 on one box.)
     batch.region_timing_begin(stream.value)
     for _ in range(4):
         batch.update_device(dI.value, dQ.value, dO.value, n_blk, stream.value)
     total, calls = batch.region_timing_end()
-    assert calls == 4 and total > 0.8 * 4 * float(ms.min())
+    assert calls == 4 and total > 1.5 * float(ms.min()) and total < 4 * 4 * float(ms.max())
     for p_ in (dI, dQ, dO):
         hip.hipFree(p_)
     batch.close()
