@@ -1444,6 +1444,7 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     // ONE stage is 23 us per block for a lone wave and bounds the two-stage form; its halves are ~11 and ~13, the filter 18.
     static_assert(ASDR_SAM_CHUNK == ASDR_ALS_CHUNK, "the two chunked forms share the tile sets");
     constexpr int RT = ASDR_SAM_CHUNK_SETS / G;
+    static_assert(RT == R, "the front stage's wait indexes ev_als[(k - RT) % R]: the event of back chunk k - RT only while tile sets and stage slots hold the same number of chunks");
     hipStream_t s_front = nullptr;
     bool three = b->als_role_stages == 3 && chunk_tiles(items[0].slots);
     if (three) { s_front = aux_stream(b, 1); if (!s_front) three = false; }

@@ -349,6 +349,9 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 #ifndef ASDR_PIPE_CHUNK
 #define ASDR_PIPE_CHUNK 8   /* samples per lane per pipeline step: 4 (35 steps) or 8 (19 steps, less per-step overhead) */
 #endif
+#ifndef ASDR_PIPE_BANK_SELECT
+#define ASDR_PIPE_BANK_SELECT 0   /* the stage-0 select of the pipelines as a bank-masked DPP move (see the step); 0: round 5's v_cndmask_b32_dpp on VCC */
+#endif
 template <bool PK = false>
 __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const float *cf, float *sv) {
   constexpr int C = ASDR_PIPE_CHUNK, NSTEP = ASDR_N / C + 3;
@@ -365,7 +368,15 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
     constexpr bool EDGE = decltype(edge_tag)::value;   // a step of the systolic fill / drain: some stages have no chunk
     const int cn = c - st;
     float x[C], p[C], y[C];
-#if defined(ASDR_PIPE_PLAIN_SELECT) || ASDR_PIPE_CHUNK != 8
+#if ASDR_PIPE_BANK_SELECT
+    // Round 6.  Every caller runs stage `st` on the lanes (lane & 15) >> 2 == st (PipeMap below): the four cascades of a row of 16 lanes have
+    // their stage-0 lanes in BANK 0 (lanes 0..3 of the row), stage s hands its chunk to the lane FOUR places on.  The DPP move `row_shr:4` writes
+    // banks 1..3 only (bank_mask 0xE) on top of the LDS chunk, which stays where it is on the stage-0 lanes -- one v_mov_b32_dpp per sample, no
+    // mask register.  (The v_cndmask_b32_dpp form below reads VCC: a run of eight of them costs a lone wave 3 x and a busy SIMD 7 x a
+    // plain instruction each -- profiles/r05_op_cost.txt -- and under three resident waves that run was a third of a pipeline step.)
+#pragma unroll
+    for (int j = 0; j < C; ++j) x[j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xn[j]), __float_as_int(yo[j]), 0x114, 0xF, 0xE, false));   // row_shr:4, banks 1..3
+#elif defined(ASDR_PIPE_PLAIN_SELECT) || ASDR_PIPE_CHUNK != 8
 #pragma unroll
     for (int j = 0; j < C; ++j) { const float d = dpp_row_shr1(yo[j]); x[j] = s0 ? xn[j] : d; }
 #else
@@ -1136,8 +1147,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   constexpr bool MW = (WAVES > 1) && !HAS_SAM && (ROLE == 0);
   constexpr int MW_SHARE = MW ? ASDR_MW_SHARE : 0;   // bit 0: audio cascades, bit 1: blanker / phase chains, bit 2: AGC chain (measurements: any subset)
   const int wave = (WAVES > 1) ? (int)(threadIdx.x >> 6) : 0;
-  const int mw_rel = MW ? ((wave - (int)blockIdx.x) & (WAVES - 1)) : 0;
-  float *const mwx = lds_wg + WAVES * 8 * STRIDE;   // MW: [8 * WAVES][8] floats of hand-off scratch behind the rows
+#ifndef ASDR_MW_ROT
+#define ASDR_MW_ROT 0
+#endif
+  const uint32_t mw_b = blockIdx.x;
+  const uint32_t mw_rot = (ASDR_MW_ROT == 0) ? mw_b : (ASDR_MW_ROT == 1) ? (mw_b >> 3) : (ASDR_MW_ROT == 2) ? ((mw_b >> 3) + (mw_b >> 8)) :
+                          (ASDR_MW_ROT == 3) ? ((mw_b * 0x9E3779B1u) >> 30) : (ASDR_MW_ROT == 4) ? ((mw_b >> 3) % 3u) : (mw_b >> 5);
+  const int mw_rel = MW ? (int)(((uint32_t)wave - mw_rot) & (uint32_t)(WAVES - 1)) : 0;
+  float *const mwx = lds_wg + WAVES * 8 * STRIDE;   // MW: [8 * WAVES][MWX] floats of hand-off scratch behind the rows
+  constexpr int MWX = 16;   // per channel: 0 blanker average in / out, 1 mixer phase in / "a phase sequence was computed" out, 2 increment, 3 flags, 4 phase after the block,
+                            // 5 AGC quiet flag, 6 AM level, 7 gain after the block, 8 envelope in / out, 9 hang counter in / out, 10 gain in, 11..14 attack / release alpha, beta, 15 hang count
   // schedule slot / channel index of the workgroup's channel q (0 .. 8 * WAVES - 1), for the lanes that work on other waves' channels
   auto mw_channel = [&](int q) -> int { const int sidx = (int)blockIdx.x * (8 * WAVES) + q; return (sidx < a.n_sched) ? a.direct_ch0 + sidx : a.n_channels; };
   // this wave's index in the launched schedule sub-range (the streaming pipeline launches its three roles one after the other)
@@ -1217,6 +1236,36 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     ChanSmall *S = row_ptr(a.small, (uint32_t)ch * (uint32_t)sizeof(ChanSmall));
     float *L = lds + loff;
     int *Li = reinterpret_cast<int *>(L);
+    // Lanes of the biquad pipelines (biquad_pipe): with the bank-masked select, a row of 16 lanes = 2 channels runs its four cascades (channel
+    // 2r / 2r + 1, I / Q) with stage s on lanes 4s .. 4s + 3 of the row: lane (lane & 3) of every group of four = cascade k, stage = (lane & 15) >> 2.
+    // pl_c = the wave's channel (0..7) whose cascade this lane works on, pl_iq = its row (I / Q); the audio cascade (one per channel) runs on
+    // cascades k = 0, 1 of the row, k = 2, 3 repeat them without writing.  The channel's state / parameter rows come through its index.
+    constexpr bool PLB = (ASDR_PIPE_BANK_SELECT != 0);
+#define pl_st (PLB ? ((lane_i & 15) >> 2) : (s8 & 3))
+#define pl_iq (PLB ? (lane_i & 1) : (s8 >> 2))
+#define pl_c (PLB ? (2 * (lane_i >> 4) + ((lane_i >> 1) & 1)) : (lane_i >> 3))
+#define pa_c (PLB ? (2 * (lane_i >> 4) + (lane_i & 1)) : (lane_i >> 3))   /* audio cascade: the channel, and whether this lane's cascade is a real one */
+#define pa_real (PLB ? ((lane_i & 3) < 2) : ((lane_i & 7) < 4))
+    // (everything below is formed where it is used, from the lane index and the channel index: as variables of the whole block they cost the
+    // looped instantiations eight registers and spills)
+#if ASDR_PIPE_BANK_SELECT
+#define PL_CH(c) (__builtin_amdgcn_ds_bpermute((c) << 5, ch))   /* lane 8 c holds channel c's index */
+#define Sp row_ptr(a.small, (uint32_t)PL_CH(pl_c) * (uint32_t)sizeof(ChanSmall))
+#define Spa row_ptr(a.small, (uint32_t)PL_CH(pa_c) * (uint32_t)sizeof(ChanSmall))
+#define Ppl row_ptr(a.params, (uint32_t)PL_CH(pl_c) * (uint32_t)sizeof(ChanParams))
+#define Ppa row_ptr(a.params, (uint32_t)PL_CH(pa_c) * (uint32_t)sizeof(ChanParams))
+#define Lp (lds + pl_c * STRIDE)
+#define Lpa (lds + pa_c * STRIDE)
+#else   /* round 5's lanes: a channel's cascades on its own eight lanes */
+#define PL_CH(c) ch
+#define Sp S
+#define Spa S
+#define Ppl Pp
+#define Ppa Pp
+#define Lp L
+#define Lpa L
+#endif
+    const bool af_en_pa = (PLB && !UNIFORM) ? (__builtin_amdgcn_ds_bpermute(pa_c << 5, af_en ? 1 : 0) != 0) : af_en;   // the audio filter's enable of THAT channel (uniform waves: one value)
     // Sample ownership.  Global rows are always touched in whole 16-byte pieces with the 8 lanes of a channel on 8 ADJACENT
     // pieces, so that one wave-instruction reads or writes 128 contiguous bytes of each of its 8 rows (lanes on every second
     // or fourth piece make every instruction touch every line of the rows: 2.9 instead of 7 TB/s, tools/ubench/mem_pattern.hip):
@@ -1227,12 +1276,17 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const bool lead = (s8 == 0);
 #ifdef ASDR_TIMELINE
     // profiling build (tools/timeline.py): lane 0 of a few waves timestamps the phase boundaries into the taps buffer
+    // (the four-wave form: all four waves of workgroups 0, 683, 1365, 2047 -> slots 4 i + wave; entries 17..28 = arrival at / departure from the
+    // six workgroup barriers, see TL(17) ff.)
+    const int tl_wg = ((int)blockIdx.x == 0) ? 0 : (((int)blockIdx.x == 683) ? 1 : (((int)blockIdx.x == 1365) ? 2 : (((int)blockIdx.x == 2047) ? 3 : -1)));
     const int tl_slot = STREAM ? ((wave_g == 0) ? 2 * (3 + ROLE) + (blk & 1) : -1)
-                               : ((wave_g == 0) ? 0 : ((wave_g == 2731) ? 1 : ((wave_g == 5461) ? 2 : ((wave_g == 8191) ? 3 : -1))));
+                               : (MW ? ((tl_wg < 0) ? -1 : 4 * tl_wg + wave)
+                                     : ((wave_g == 0) ? 0 : ((wave_g == 2731) ? 1 : ((wave_g == 5461) ? 2 : ((wave_g == 8191) ? 3 : -1)))));
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(a.taps) + 32 * (tl_slot < 0 ? 0 : tl_slot);
 #define TL(i) do { if (a.taps != nullptr && tl_slot >= 0 && lane == 0) tl[i] = clock64(); } while (0)
     const bool tap_on = false;
     TL(0);
+    if (MW && a.taps != nullptr && tl_slot >= 0 && lane == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); tl[29] = hw; }   // SIMD / wave slot / CU of the wave
 #else
 #define TL(i) do { } while (0)
     const bool tap_on = (a.taps != nullptr) && valid && (blk == a.n_blocks - 1);
@@ -1357,8 +1411,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     float if_cf[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     bool if_pre = false;
     auto load_if_rows_early = [&]() {
-      if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
-      const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
+      if_s4 = *reinterpret_cast<const float4 *>(&Sp->if_state[pl_iq][4 * pl_st]);
+      const float *cf = &c_bq_pool[Ppl->if_table][5 * pl_st];
 #pragma unroll
       for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
       if_pre = true;
@@ -1472,10 +1526,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       TL(2);
-      if (DO1 && ABL_ON(ABL_IF) && WAVES == 1 && !C16) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
+#ifndef ASDR_MW_IF_PRE
+#define ASDR_MW_IF_PRE 1
+#endif
+      if (DO1 && ABL_ON(ABL_IF) && (WAVES == 1 || (MW && ASDR_MW_IF_PRE)) && !C16) {   // the IF pipeline's state and coefficient row are requested here: they arrive during the sequential pass
                                             // (not in the multi-wave SAM instantiation: no registers to spare)
-        if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
-        const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
+        if_s4 = *reinterpret_cast<const float4 *>(&Sp->if_state[pl_iq][4 * pl_st]);
+        const float *cf = &c_bq_pool[Ppl->if_table][5 * pl_st];
 #pragma unroll
         for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
         if_pre = true;
@@ -1486,6 +1543,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // The two recurrences of one channel on ONE lane (`Lc` = the channel's rows, avg0 / phase0 / inc = its carried average, mixer phase
       // and increment, Sc = its state row, chain_phase = the phase sequence is wanted (wave-uniform: a lane that does not need it computes
       // and drops it), en = the blanker is on).  Returns the phase after the block.
+#ifndef ASDR_MW_OWN_STORES
+#define ASDR_MW_OWN_STORES 1   /* the four-wave form: a chain's results go back to HBM from the channel's OWN wave (its lead lanes: stores beside its other state), not from the duty wave's 32 lanes */
+#endif
+      float nb_avg_end = 0.0f;   // (MW with ASDR_MW_OWN_STORES: the duty wave's lane leaves the average here instead of storing it)
       auto nb_chain = [&](float *Lc, ChanSmall *Sc, float avg0, float phase0, float inc, bool chain_phase, bool want_phase, bool en, bool ssb) -> float {
         float avg = avg0, phase = phase0;
         // `if (t > twoPI) t -= twoPI; else if (t < 0) t += twoPI;` (.h:514-517) with one test per sample: the phase stays in
@@ -1591,8 +1652,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           }
         }
         }   // !C16
-        if (en) Sc->nb_avg = avg;
-        if (want_phase && c_tail != 0) {
+        constexpr bool OWN_STORES = MW && ((MW_SHARE & 2) != 0) && (ASDR_MW_OWN_STORES != 0);
+        if (OWN_STORES) nb_avg_end = avg;
+        if (!OWN_STORES && en) Sc->nb_avg = avg;
+        if (!OWN_STORES && want_phase && c_tail != 0) {
           // (the word's offset is formed HERE: hoisted in front of the block loop as a 64-bit select it costs the multi-wave SAM instantiation a spill)
           uint32_t off = (uint32_t)offsetof(ChanSmall, phase_am);
           asm volatile("" : "+v"(off));
@@ -1604,20 +1667,31 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const bool chain_phase_own = !lo_hit && (DO2 || !UNIFORM);
       if constexpr ((MW_SHARE & 2) != 0) {
         // every channel's lead lane publishes its chain inputs; the duty wave (rel 0) runs the chains of all 8 * WAVES channels, one per lane
-        if (lead) *reinterpret_cast<float4 *>(mwx + 8 * (wave * 8 + c8)) = make_float4(nb_avg0, mphase, minc, __int_as_float((chain_phase_own ? 1 : 0) | ((mix_early && !lo_hit) ? 2 : 0)));
+        if (lead) *reinterpret_cast<float4 *>(mwx + MWX * (wave * 8 + c8)) = make_float4(nb_avg0, mphase, minc, __int_as_float((chain_phase_own ? 1 : 0) | ((mix_early && !lo_hit) ? 2 : 0)));
+        TL(17);
         __syncthreads();
+        TL(18);
         if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
         if (mw_rel == 0 && lane_i < 8 * WAVES) {
           const int q = lane_i;
-          const float4 in4 = *reinterpret_cast<const float4 *>(mwx + 8 * q);
+          const float4 in4 = *reinterpret_cast<const float4 *>(mwx + MWX * q);
           const int fl = __float_as_int(in4.w);
           const bool any_phase = __any((fl & 1) != 0);
           const float pe = nb_chain(lds_wg + q * STRIDE, row_ptr(a.small, (uint32_t)mw_channel(q) * (uint32_t)sizeof(ChanSmall)), in4.x, in4.y, in4.z, any_phase, (fl & 2) != 0, nb_en, is_ssb);
-          mwx[8 * q + 4] = pe;
+          mwx[MWX * q + 4] = pe;
+          if (ASDR_MW_OWN_STORES) { mwx[MWX * q] = nb_avg_end; mwx[MWX * q + 1] = __int_as_float(any_phase ? 1 : 0); }
         }
         if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(0);
+        TL(19);
         __syncthreads();
-        if (lead) mphase_end = mwx[8 * (wave * 8 + c8) + 4];
+        TL(20);
+        if (lead) {
+          mphase_end = mwx[MWX * (wave * 8 + c8) + 4];
+          if (ASDR_MW_OWN_STORES) {   // the chain's results back to the channel's state row, from its own wave
+            if (nb_en) S->nb_avg = mwx[MWX * (wave * 8 + c8)];
+            if (mix_early && !lo_hit && __float_as_int(mwx[MWX * (wave * 8 + c8) + 1]) != 0) { if (is_ssb) S->phase_ssb = mphase_end; else S->phase_am = mphase_end; }
+          }
+        }
       } else {
         CHAIN_PRIO_ON();
         if (lead) mphase_end = nb_chain(L, S, nb_avg0, mphase, minc, chain_phase_own, mix_early && !lo_hit, nb_en, is_ssb);
@@ -1817,8 +1891,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // count loads in order, and a wait for these values placed after the (conditional) prefetches would be a wait for everything
     // -- the first pipeline step would sit out the prefetches' HBM latency (it did: vmcnt(0) inside the pipeline loop).
     auto load_if_rows = [&]() {
-      if_s4 = *reinterpret_cast<const float4 *>(&S->if_state[s8 >> 2][4 * (s8 & 3)]);
-      const float *cf = &c_bq_pool[P.if_table][5 * (s8 & 3)];
+      if_s4 = *reinterpret_cast<const float4 *>(&Sp->if_state[pl_iq][4 * pl_st]);
+      const float *cf = &c_bq_pool[Ppl->if_table][5 * pl_st];
 #pragma unroll
       for (int z = 0; z < 5; ++z) if_cf[z] = cf[z];
     };
@@ -1869,14 +1943,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
     if (DO1 && ABL_ON(ABL_IF)) {
-      const int iq = s8 >> 2, st = s8 & 3;
+      const int iq = pl_iq, st = pl_st;
       float sv[4];
       if (HAS_ALS && !ALS_FULL_OPT && !if_pre) load_if_rows();
       sv[0] = if_s4.x; sv[1] = if_s4.y; sv[2] = if_s4.z; sv[3] = if_s4.w;
       CHAIN_PRIO_ON();
-      biquad_pipe<PIPE_PK>(L + (iq ? W1 : W0), true, st, if_cf, sv);
+      biquad_pipe<PIPE_PK>(Lp + (iq ? W1 : W0), true, st, if_cf, sv);
       CHAIN_PRIO_OFF();
-      *reinterpret_cast<float4 *>(&S->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+      *reinterpret_cast<float4 *>(&Sp->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
     }
     if (C16 && lo_hit) store4(lds + (lane_i >> 4) * STRIDE + PH + ((4 * lane_i) & 63), lo4);   // word i of [cos | sin]: row i >> 6, place i & 63
     WAVE_SYNC();
@@ -2141,21 +2215,23 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     int agc_tab_idx = 0;
     // MW: the two audio-duty waves (rel 1, 2) run the cascades of 16 channels each, lane = (channel of the half) x 4 + stage
     const bool mw_audio_duty = (MW_SHARE & 1) && (mw_rel == 1 || mw_rel == 2);
+    const int mw_casc = PLB ? (4 * (lane_i >> 4) + (lane_i & 3)) : (lane_i >> 2);   // which of the duty wave's 16 cascades this lane works on (stage pl_st)
     ChanSmall *mw_af_S = S;
     auto load_af_agc_state = [&]() {
-    if (ABL_ON(ABL_AF) && af_en) {
+    ChanSmall *const Saf = PLB ? Spa : S; const ChanParams *const Paf = PLB ? Ppa : Pp;   // (formed by all lanes, see the AM image filter)
+    if (ABL_ON(ABL_AF) && (((MW_SHARE & 1) != 0) ? af_en : af_en_pa)) {
       if constexpr ((MW_SHARE & 1) != 0) {
         if (mw_audio_duty) {
-          const int chq = mw_channel(16 * (mw_rel - 1) + (lane_i >> 2));
+          const int chq = mw_channel(16 * (mw_rel - 1) + mw_casc);
           mw_af_S = row_ptr(a.small, (uint32_t)chq * (uint32_t)sizeof(ChanSmall));
-          af_s4 = *reinterpret_cast<const float4 *>(&mw_af_S->af_state[4 * (lane_i & 3)]);
-          const float *cf = &c_bq_pool[row_ptr(a.params, (uint32_t)chq * (uint32_t)sizeof(ChanParams))->audio_table][5 * (lane_i & 3)];
+          af_s4 = *reinterpret_cast<const float4 *>(&mw_af_S->af_state[4 * pl_st]);
+          const float *cf = &c_bq_pool[row_ptr(a.params, (uint32_t)chq * (uint32_t)sizeof(ChanParams))->audio_table][5 * pl_st];
 #pragma unroll
           for (int z = 0; z < 5; ++z) af_cf[z] = cf[z];
         }
       } else {
-      af_s4 = *reinterpret_cast<const float4 *>(&S->af_state[4 * (s8 & 3)]);
-      const float *cf = &c_bq_pool[P.audio_table][5 * (s8 & 3)];
+      af_s4 = *reinterpret_cast<const float4 *>(&Saf->af_state[4 * pl_st]);
+      const float *cf = &c_bq_pool[Paf->audio_table][5 * pl_st];
 #pragma unroll
       for (int z = 0; z < 5; ++z) af_cf[z] = cf[z];
       }
@@ -2311,12 +2387,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (ABL_ON(ABL_ENV) && __any(do_env)) {
       WAVE_SYNC();
       {
-        const int iq = s8 >> 2, st = s8 & 3;
+        const int iq = pl_iq, st = pl_st;
+        const bool do_env_p = PLB ? (__builtin_amdgcn_ds_bpermute(pl_c << 5, do_env ? 1 : 0) != 0) : do_env;   // (of the channel this lane's cascade belongs to)
         float sv[4];
-        const float4 s4 = *reinterpret_cast<const float4 *>(&S->img_state[iq][4 * st]);
+        ChanSmall *const Simg = Sp;   // (formed by ALL lanes: the channel index comes through ds_bpermute, which reads 0 from a lane that is switched off)
+        const float4 s4 = *reinterpret_cast<const float4 *>(&Simg->img_state[iq][4 * st]);
         sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
-        biquad_pipe<PIPE_PK>(L + (iq ? W1 : W0), do_env, st, &c_bq_pool[ASDR_TBL_AM_IMAGE][5 * st], sv);
-        if (do_env) *reinterpret_cast<float4 *>(&S->img_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        biquad_pipe<PIPE_PK>(Lp + (iq ? W1 : W0), do_env_p, st, &c_bq_pool[ASDR_TBL_AM_IMAGE][5 * st], sv);
+        if (do_env_p) *reinterpret_cast<float4 *>(&Simg->img_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       }
       WAVE_SYNC();
       if (do_env) {
@@ -2420,28 +2498,33 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // ---- audio IIR filter, AudioSDR.cpp:149, 280-286: lanes s8 = 0..3 are the four stages ---------------------
     if constexpr ((MW_SHARE & 1) != 0) {
       if (ABL_ON(ABL_AF) && af_en) {   // (launch-uniform: all four waves or none)
+        TL(21);
         __syncthreads();               // every wave's demodulated audio is in its W0 rows
+        TL(22);
         if (mw_audio_duty) {           // 16 cascades x 4 stages: the whole wave works
           if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
-          const int st = lane_i & 3;
+          const int st = pl_st;
           float sv[4];
           sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
-          biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + (lane_i >> 2)) * STRIDE + W0, true, st, af_cf, sv);
+          biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + mw_casc) * STRIDE + W0, true, st, af_cf, sv);
           *reinterpret_cast<float4 *>(&mw_af_S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
           if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(0);
         }
+        TL(23);
         __syncthreads();
+        TL(24);
       }
     } else
     if (ABL_ON(ABL_AF) && __any(af_en)) {
-      const int st = s8 & 3;
-      const bool on = af_en && (s8 < 4);
+      const int st = pl_st;
+      const bool on = af_en_pa && pa_real;   // (the enable of the channel this lane's cascade belongs to)
       float sv[4];
       sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
+      ChanSmall *const Saf = Spa;   // (by all lanes)
       CHAIN_PRIO_ON();
-      biquad_pipe<PIPE_PK>(L + W0, on, st, af_cf, sv);
+      biquad_pipe<PIPE_PK>(Lpa + W0, on, st, af_cf, sv);
       CHAIN_PRIO_OFF();
-      if (on) *reinterpret_cast<float4 *>(&S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+      if (on) *reinterpret_cast<float4 *>(&Saf->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
       WAVE_SYNC();
     }
     TL(11);
@@ -2501,7 +2584,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       {
       // One channel's envelope / hang recurrence on ONE lane: Lc = the channel's rows (|x| row at AGC_GV, replaced in place by the governing
       // envelope values; gain table at AGC_TAB), Sc = its state row.  Returns the gain after the block.
-      auto agc_chain = [&](float *Lc, ChanSmall *Sc, float old0, uint32_t hc0, float g_in, float al_a, float be_a, float al_r, float be_r, uint32_t hang,
+      float agc_old_end = 0.0f; uint32_t agc_hc_end = 0u;
+      auto agc_chain = [&](auto own_tag, float *Lc, ChanSmall *Sc, float old0, uint32_t hc0, float g_in, float al_a, float be_a, float al_r, float be_r, uint32_t hang,
                            bool am, float am_lvl) -> float {
         float old_abs = old0;
         uint32_t hc = hc0;
@@ -2590,35 +2674,55 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           store8(Lc + AGC_GV + i, gvv);
         }
         }
-        Sc->agc_old_abs = old_abs;
-        Sc->agc_hang_counter = hc;
         const float g_end = (gv < 0.0f) ? g_in : agc_compress(C16 ? tab : Lc + AGC_TAB, gv);
-        Sc->agc_gain = g_end;
+        if constexpr (decltype(own_tag)::value) { agc_old_end = old_abs; agc_hc_end = hc; }   // (the four-wave form: the channel's own wave stores them)
+        else { Sc->agc_old_abs = old_abs; Sc->agc_hang_counter = hc; Sc->agc_gain = g_end; }
         return g_end;
       };
       if constexpr ((MW_SHARE & 4) != 0) {
         // MW: every wave says whether its block is quiet; the AGC-duty wave (rel 3) runs the chains of the other waves' channels, one per lane
         // (the |x| rows and the gain tables are in the channels' LDS rows; the scalars come from the channels' state / parameter rows)
-        if (lead) { mwx[8 * (wave * 8 + c8) + 5] = __int_as_float(agc_quiet ? 1 : 0); mwx[8 * (wave * 8 + c8) + 6] = am_clamped; }
+        if (lead) {
+          float *mq = mwx + MWX * (wave * 8 + c8);
+          mq[5] = __int_as_float(agc_quiet ? 1 : 0); mq[6] = am_clamped;
+          if (ASDR_MW_OWN_STORES && !agc_quiet) {   // the chain's scalars: this wave has loaded them for the quiet test (the duty wave asked for them again: 8 scattered loads per lane in front of its chain)
+            *reinterpret_cast<float4 *>(mq + 8) = make_float4(agc_old0, __uint_as_float(agc_hc0), gain_in, agc_al_a);
+            *reinterpret_cast<float4 *>(mq + 12) = make_float4(agc_be_a, agc_al_r, agc_be_r, __uint_as_float(agc_hang));
+          }
+        }
+        TL(25);
         __syncthreads();
+        TL(26);
         if (ASDR_MW_PRIO && mw_rel == 3) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
         if (mw_rel == 3 && lane_i < 8 * WAVES) {
           const int q = lane_i;
-          if (__float_as_int(mwx[8 * q + 5]) == 0) {
+          if (__float_as_int(mwx[MWX * q + 5]) == 0) {
+            if (ASDR_MW_OWN_STORES) {
+              const float4 i0 = *reinterpret_cast<const float4 *>(mwx + MWX * q + 8), i1 = *reinterpret_cast<const float4 *>(mwx + MWX * q + 12);
+              mwx[MWX * q + 7] = agc_chain(std::true_type{}, lds_wg + q * STRIDE, nullptr, i0.x, __float_as_uint(i0.y), i0.z, i0.w, i1.x, i1.y, i1.z, __float_as_uint(i1.w), is_am, mwx[MWX * q + 6]);
+              mwx[MWX * q + 8] = agc_old_end; mwx[MWX * q + 9] = __uint_as_float(agc_hc_end);
+            } else {
             const int chq = mw_channel(q);
             ChanSmall *Sq = row_ptr(a.small, (uint32_t)chq * (uint32_t)sizeof(ChanSmall));
             const ChanParams *Pq = row_ptr(a.params, (uint32_t)chq * (uint32_t)sizeof(ChanParams));
-            mwx[8 * q + 7] = agc_chain(lds_wg + q * STRIDE, Sq, Sq->agc_old_abs, Sq->agc_hang_counter, Sq->agc_gain, Pq->agc_alpha_att, Pq->agc_beta_att,
-                                       Pq->agc_alpha_rel, Pq->agc_beta_rel, Pq->agc_hang_count, is_am, mwx[8 * q + 6]);
+            mwx[MWX * q + 7] = agc_chain(std::false_type{}, lds_wg + q * STRIDE, Sq, Sq->agc_old_abs, Sq->agc_hang_counter, Sq->agc_gain, Pq->agc_alpha_att, Pq->agc_beta_att,
+                                       Pq->agc_alpha_rel, Pq->agc_beta_rel, Pq->agc_hang_count, is_am, mwx[MWX * q + 6]);
+            }
           }
         }
         if (ASDR_MW_PRIO && mw_rel == 3) __builtin_amdgcn_s_setprio(0);
+        TL(27);
         __syncthreads();
-        if (!agc_quiet && lead) { const float g_end = mwx[8 * (wave * 8 + c8) + 7]; status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u); }
+        TL(28);
+        if (!agc_quiet && lead) {
+          const float *mq = mwx + MWX * (wave * 8 + c8);
+          const float g_end = mq[7]; status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
+          if (ASDR_MW_OWN_STORES && agc_en) { S->agc_old_abs = mq[8]; S->agc_hang_counter = __float_as_uint(mq[9]); S->agc_gain = g_end; }
+        }
       } else {
         if (!agc_quiet) CHAIN_PRIO_ON();
         if (!agc_quiet && agc_en && lead) {
-          const float g_end = agc_chain(L, S, agc_old0, agc_hc0, gain_in, agc_al_a, agc_be_a, agc_al_r, agc_be_r, agc_hang, is_am, am_clamped);
+          const float g_end = agc_chain(std::false_type{}, L, S, agc_old0, agc_hc0, gain_in, agc_al_a, agc_be_a, agc_al_r, agc_be_r, agc_hang, is_am, am_clamped);
           status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
         }
         if (!agc_quiet) CHAIN_PRIO_OFF();
@@ -2813,6 +2917,18 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   }
   if (STREAM && sig_pending) stream_signal(my_prog, sig_pending, lane);
 #undef P
+#undef PL_CH
+#undef Sp
+#undef Spa
+#undef Ppl
+#undef Ppa
+#undef Lp
+#undef Lpa
+#undef pl_st
+#undef pl_iq
+#undef pl_c
+#undef pa_c
+#undef pa_real
 }
 
 // Three instantiations by what a channel needs (the host launches each sub-range of its sorted schedule with its own):
@@ -2845,7 +2961,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_update_kernel_c16(Updat
 // = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
 #define ASDR_MW_WAVES 4
 extern "C" __global__ __launch_bounds__(64 * ASDR_MW_WAVES, ASDR_WAVES_PER_EU) void asdr_update_kernel_mw(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 8];
+  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16];
   asdr_update_body<ASDR_STRIDE, false, false, true, ASDR_MW_WAVES, 0, true>(a, lds);
 }
 // SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
@@ -3336,7 +3452,10 @@ extern "C" int asdr_launch_als_stage_seed(const UpdateArgs *a, int ch0, int n, h
 extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int uniform, int role, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (a->n_blocks > 1) {   // the chunked form: uniform SAM sub-ranges only (asdr_host.cpp)
+  // The chunked form is named by the TILE SETS, not by the block count: a call's last chunk may hold ONE block (n_blocks % 8 == 1), and the
+  // one-block pre / post kernels know nothing of tile sets (they work on set 0 while the PLL kernel reads set sam_set: round 5's 17- and
+  // 25-block calls ended with a wrong last block).  The looped kernels run a one-block chunk like any other.
+  if (a->n_blocks > 1 || a->sam_sets > 1u) {   // uniform SAM sub-ranges only (asdr_host.cpp)
     if (!uniform || variant != ASDR_KERNEL_SAM) return -1;
     if (role == 0) hipLaunchKernelGGL(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     else if (role == 1) hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);

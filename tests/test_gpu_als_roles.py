@@ -60,6 +60,39 @@ def test_als_role_streams_equal_the_oracle(gpu, ao, mode, params, stages, monkey
     b.close()
 
 
+@pytest.mark.parametrize("stages", [3, 2])
+def test_als_role_streams_long_calls_wrap_every_ring(gpu, ao, stages, monkeypatch):
+    """Calls of 40, 1, 70 and 9 blocks: 70 blocks = 9 chunks, i.e. more than the stage's 32 slots and the 32 tile sets, so
+    the back-pressure wait (chain chunk k behind filter chunk k - 3), the stage ring wrapping onto the seeded slot 31, the front stage's wait for
+    the back stage (k >= 4) and the tile-set wrap are all exercised -- and compared bit for bit, every channel, every block."""
+    monkeypatch.setenv("ASDR_ALS_ROLE_STAGES", str(stages))
+    import torch
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 40, (40, 1, 70, 9)
+    total = sum(plan)
+    I, Q = make_iq(n_ch, total, fc=6890.0 + (np.arange(n_ch) % 9 - 4) * 35.0, A=0.3, m=0.4, f2=7600.0, a2=0.12, noise=0.01, impulse_every=900)
+
+    def cfg(s):
+        s.setDemodMode(1); s.setNoiseBlankerThresholdDb(10.0); s.enableAudioFilter(); s.enableALSfilter()
+
+    b, orcs = _bank(gpu, ao, n_ch, cfg)
+    dI = torch.from_numpy(I).cuda(); dQ = torch.from_numpy(Q).cuda()
+    dO = torch.zeros((n_ch, total, 128), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    pos = 0
+    for T in plan:
+        b.update_device_strided(dI.data_ptr() + pos * 256, dQ.data_ptr() + pos * 256, dO.data_ptr() + pos * 256, T, total, total)
+        b.synchronize()
+        pos += T
+    if not os.environ.get("ASDR_NO_ALS_ROLE_STREAMS"):
+        assert b.als_role_calls() == sum(1 for T in plan if T >= 2)
+    got = dO.cpu().numpy()
+    for c in range(n_ch):
+        w = orcs[c].update(I[c], Q[c]).reshape(total, 128)
+        assert np.array_equal(got[c], w), "channel %d: first differing block %d" % (c, int(np.nonzero((got[c] != w).any(axis=1))[0][0]))
+    b.close()
+
+
 def test_als_role_streams_keep_off_in_place_calls_and_mixed_schedules(gpu, ao):
     import torch
     from audiosdr_amd.synth import make_iq

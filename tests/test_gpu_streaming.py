@@ -448,6 +448,44 @@ def test_sam_role_streams_in_chunks(gpu, ao):
     hip.free_all(); batch.close()
 
 
+def test_sam_role_streams_chunk_tail_of_one_block(gpu, ao):
+    """Calls whose LAST chunk holds one block (17 = 2 x 8 + 1, 25, 41 blocks): round 5 launched the one-block pre / post kernels for that chunk,
+    which know nothing of tile sets -- the pre role wrote set 0 while the PLL kernel read set (first block of the chunk) % 32, so the call's last
+    block and the PLL state behind it were wrong unless that set happened to be 0.  The looped kernels run every chunk of
+    a chunked call now, whatever its length; the calls hand the state to each other, so a wrong PLL state would also show in the next call."""
+    from audiosdr_amd.synth import make_iq
+    n_ch, plan = 512, (17, 25, 41, 2)   # (512 channels: the smallest bank that runs SAM as three launches)
+    total = sum(plan)
+    near = 6890.0 + (np.arange(n_ch) % 7 - 3) * 40.0
+    Ia, Qa = make_iq(n_ch, total, fc=near, A=0.3, m=0.5, fm=400.0, noise=0.005)
+    Ib, Qb = make_iq(n_ch, total, fc=near + 2500.0, A=0.25, m=0.3, fm=300.0, noise=0.005)   # 2.5 kHz off: no lock
+    I, Q = Ia.copy(), Qa.copy()
+    for c in range(n_ch):
+        for b in range(total):
+            if ((b + c % 5) // 3) % 3 == 2:
+                I[c, b], Q[c, b] = Ib[c, b], Qb[c, b]
+    setters = [S("setDemodMode", 5), S("setNoiseBlankerThresholdDb", 10.0), S("enableAudioFilter"), S("setAudioFilter", 0)]
+    batch, orcs = _mk(gpu, ao, n_ch, setters)
+    hip = Hip()
+    pos = 0
+    for T in plan:
+        dI, dQ = hip.upload(I[:, pos:pos + T]), hip.upload(Q[:, pos:pos + T])
+        dO = hip.malloc(n_ch * T * 256)
+        batch.update_device(dI, dQ, dO, T)
+        batch.synchronize()
+        got = hip.download(dO, (n_ch, T, 128), np.int16)
+        for c in range(0, n_ch, 3):
+            want = orcs[c].update(I[c, pos:pos + T], Q[c, pos:pos + T]).reshape(T, 128)
+            assert np.array_equal(got[c], want), "call of %d blocks at %d, ch %d: first differing block %d of %d" % (T, pos, c, int(np.nonzero((got[c] != want).any(axis=1))[0][0]), T)
+        st = batch.read_status()
+        for c in range(0, n_ch, 3):
+            assert int(st["sam_locked"][c]) == orcs[c].getSAMphaseLockStatus(), "lock flag after block %d, ch %d" % (pos + T - 1, c)
+            assert np.float32(st["sam_frequency"][c]) == np.float32(orcs[c].getSAMfrequency()), "PLL frequency after block %d, ch %d" % (pos + T - 1, c)
+        pos += T
+    assert batch.sam_chunk_calls() == sum(1 for T in plan if T >= 16)
+    hip.free_all(); batch.close()
+
+
 def test_in_place_calls_never_take_the_pipeline(gpu, ao):
     """The pipeline's recovery restores channel state, not caller buffers: a call whose output rows alias its I rows (the reference's
     own convention, AudioSDR.cpp:158-165: the audio is written into blockI) keeps the in-kernel block loop -- also with injected
