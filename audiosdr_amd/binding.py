@@ -66,6 +66,19 @@ EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels",
 _lib = None
 
 
+def kernels_launched(reset=False):
+    """{kernel name: launches since the last reset} for the kernels that were launched at all (process-wide census, include/asdr.h)."""
+    L = load_library()
+    out = {}
+    for i in range(L.asdr_kernels_count()):
+        n = int(L.asdr_kernels_launches(i))
+        if n:
+            out[L.asdr_kernels_name(i).decode()] = n
+    if reset:
+        L.asdr_kernels_launches_reset()
+    return out
+
+
 def load_library(path=None):
     """dlopen libasdr_hip.so.  Raises AsdrError (loudly) when it has not been built."""
     global _lib
@@ -81,6 +94,10 @@ def load_library(path=None):
     L.asdr_destroy.argtypes = [vp]; L.asdr_destroy.restype = None
     L.asdr_last_error.restype = C.c_char_p
     L.asdr_version.restype = C.c_char_p
+    L.asdr_kernels_count.restype = _i
+    L.asdr_kernels_name.argtypes = [_i]; L.asdr_kernels_name.restype = C.c_char_p
+    L.asdr_kernels_launches.argtypes = [_i]; L.asdr_kernels_launches.restype = C.c_ulonglong
+    L.asdr_kernels_launches_reset.restype = None
     L.asdr_n_channels.argtypes = [vp]; L.asdr_n_channels.restype = _i
     L.asdr_update.argtypes = [vp, i16p, i16p, i16p, _i]; L.asdr_update.restype = _i
     L.asdr_update_device.argtypes = [vp, vp, vp, vp, _i, vp]; L.asdr_update_device.restype = _i

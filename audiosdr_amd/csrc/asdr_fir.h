@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // one aligned VGPR pair: operand of v_pk_mul_f32 / v_pk_add_f32
+#ifndef ASDR_FIR_TAPS_IN_VGPRS
+#define ASDR_FIR_TAPS_IN_VGPRS 0
+#endif
 #ifndef SCHED_FENCE
 #define SCHED_FENCE() do { } while (0)
 #endif
@@ -16,7 +19,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));   // one aligned VGPR pai
 // are PX[127 + p0 + e - k] and PX[p0 + e + k] (p0 = 8 s8): per chunk of 8 taps two contiguous (NE + 7)-pair register windows
 // (ds_read_b128).  v_pk_mul_f32 / v_pk_add_f32 round each half exactly like the scalar ops, so the result is bit-identical to
 // the scalar loop.  `taps`: 64 floats in constant memory (uniform address: scalar loads).
-template <int E0, int NE>
+template <int E0, int NE, bool TAPS_V = (ASDR_FIR_TAPS_IN_VGPRS != 0)>
 __device__ __forceinline__ void hilbert_fir_rows(const float *hist, int p0, v2f *acc2, const float *taps) {
   constexpr int NW = NE + 7;
   const v2f *PX = reinterpret_cast<const v2f *>(hist) + E0;
@@ -34,7 +37,12 @@ __device__ __forceinline__ void hilbert_fir_rows(const float *hist, int p0, v2f 
     if (NW & 1) { dw[NW - 1] = PX[120 + p0 - 8 * kc + NW - 1]; uw[NW - 1] = PX[p0 + 8 * kc + NW - 1]; }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const float hk = taps[8 * kc + kk];
+      float hk = taps[8 * kc + kk];
+      // Round 6.  The tap arrives through a scalar load; as an SGPR operand of the eight v_pk_mul_f32 below it makes a third of the loop's vector
+      // instructions read the scalar file, and a stream that dense in scalar operands does not share a SIMD: tools/ubench/issue_rate.hip -- this
+      // loop runs 4.95 cycles per instruction alone and 8.2 for EACH of two or three resident waves (0.20 / 0.24 / 0.36 instructions per cycle and
+      // SIMD), while the same operations on VGPR operands keep ~4.6 cycles per instruction up to three waves (0.22 / 0.44 / 0.66).  One move per tap.
+      if constexpr (TAPS_V) asm("" : "+v"(hk));
       const v2f hk2 = (v2f){hk, hk};
       v2f d[NE];   // the pair-chains of a tap are independent: issue them interleaved (no dependent back-to-back pk ops)
 #pragma unroll

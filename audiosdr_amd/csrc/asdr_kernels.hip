@@ -812,9 +812,9 @@ __device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, co
 }
 
 // Folded Hilbert FIR of the update kernels (asdr_fir.h): Lrow = the channel's LDS row (history at XP), taps c_hilbert.
-template <int E0, int NE>
+template <int E0, int NE, bool TAPS_V = (ASDR_FIR_TAPS_IN_VGPRS != 0)>
 __device__ __forceinline__ void hilbert_fir(const float *Lrow, int p0, v2f *acc2) {
-  hilbert_fir_rows<E0, NE>(Lrow + XP, p0, acc2, c_hilbert);
+  hilbert_fir_rows<E0, NE, TAPS_V>(Lrow + XP, p0, acc2, c_hilbert);
 }
 // Second wave of a role-2 workgroup of the streaming pipeline: nothing but the other half of the FIR, in step with the first
 // wave's three barriers per block (history staged | all reads done | both halves in W1).
@@ -1543,12 +1543,20 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       // The two recurrences of one channel on ONE lane (`Lc` = the channel's rows, avg0 / phase0 / inc = its carried average, mixer phase
       // and increment, Sc = its state row, chain_phase = the phase sequence is wanted (wave-uniform: a lane that does not need it computes
       // and drops it), en = the blanker is on).  Returns the phase after the block.
+#ifndef ASDR_CHAIN_CONSTS_IN_VGPRS
+#define ASDR_CHAIN_CONSTS_IN_VGPRS 0
+#endif
 #ifndef ASDR_MW_OWN_STORES
 #define ASDR_MW_OWN_STORES 1   /* the four-wave form: a chain's results go back to HBM from the channel's OWN wave (its lead lanes: stores beside its other state), not from the duty wave's 32 lanes */
 #endif
       float nb_avg_end = 0.0f;   // (MW with ASDR_MW_OWN_STORES: the duty wave's lane leaves the average here instead of storing it)
       auto nb_chain = [&](float *Lc, ChanSmall *Sc, float avg0, float phase0, float inc, bool chain_phase, bool want_phase, bool en, bool ssb) -> float {
         float avg = avg0, phase = phase0;
+        // The chain's constants as VGPR operands (round 6): as scalar operands they are in every other instruction of the loops below, and a stream
+        // that dense in scalar-file reads does not share its SIMD -- each resident wave then issues once per 8 cycles instead of 4.5
+        // (tools/ubench/issue_rate.hip: chain2 against chain4x_vgpr_constants).  Not in the 16-waves-per-CU form (no register to spare).
+        float nb_alpha_v = K.nb_alpha, two_pi_v = two_pi;
+        if constexpr (!C16 && ONEBLK && ASDR_CHAIN_CONSTS_IN_VGPRS) asm("" : "+v"(nb_alpha_v), "+v"(two_pi_v));   // (nor in the looped forms: they spill with it)
         // `if (t > twoPI) t -= twoPI; else if (t < 0) t += twoPI;` (.h:514-517) with one test per sample: the phase stays in
         // [0, twoPI], so for inc >= 0 only the first branch can fire and for inc < 0 only the second.  The test is written as
         // (t with its sign flipped for inc < 0) > (twoPI or 0), and t - twoPI == t + (-twoPI) exactly.
@@ -1556,7 +1564,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         const float wrapv = up ? -two_pi : two_pi, lim = up ? two_pi : 0.0f;
         const uint32_t flip = up ? 0u : 0x80000000u;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const float bmu = Lc[NB_B + u]; Lc[NB_B + u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bmu; }
+        for (int u = 0; u < 2; ++u) { const float bmu = Lc[NB_B + u]; Lc[NB_B + u] = avg; const float aa = nb_alpha_v * avg; avg = aa + bmu; }
         float bm[8];
         load8(Lc + NB_B + 2, bm);
         int c_tail = 0;   // first chunk of the average-only loop below
@@ -1575,7 +1583,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                 float pe[4];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                  const float a0 = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; cur[u] = a0;
+                  const float a0 = avg; const float aa = nb_alpha_v * avg; avg = aa + cur[u]; cur[u] = a0;
                   if ((u & 1) == 0) pe[u >> 1] = phase;
                   const float t = phase + inc, tw = t + wrapv;
                   phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
@@ -1583,7 +1591,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                 store4(Lc + PH + 4 * (c + half), pe);
               } else {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const float a0 = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; cur[u] = a0; }
+                for (int u = 0; u < 8; ++u) { const float a0 = avg; const float aa = nb_alpha_v * avg; avg = aa + cur[u]; cur[u] = a0; }
               }
               store8(Lc + NB_B + 2 + 8 * (c + half), cur);
             }
@@ -1605,9 +1613,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               load8(Lc + NB_B + 2 + 8 * (c + half + 1), nxt);      // next chunk, a step ahead
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
-                av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u];
+                av[u] = avg; const float aa = nb_alpha_v * avg; avg = aa + cur[u];
                 pv[u] = phase;
-                const float t = phase + inc, tw = t + two_pi;
+                const float t = phase + inc, tw = t + two_pi_v;
                 const uint32_t tb = __float_as_uint(t), m = (uint32_t)((int32_t)tb >> 31);
 #ifdef ASDR_PHASE_SELECT_C
                 phase = __uint_as_float((__float_as_uint(tw) & m) | (tb & ~m));
@@ -1627,7 +1635,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             load8(Lc + NB_B + 2 + 8 * (c + 1), bn);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + bm[u];
+              av[u] = avg; const float aa = nb_alpha_v * avg; avg = aa + bm[u];
               pv[u] = phase;
               const float t = phase + inc, tw = t + wrapv;
               phase = (__uint_as_float(__float_as_uint(t) ^ flip) > lim) ? tw : t;
@@ -1647,7 +1655,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             float *cur = half ? bn : bm, *nxt = half ? bm : bn;
             load8(Lc + NB_B + 2 + 8 * ((c + half < 21) ? c + half + 1 : 21), nxt);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = K.nb_alpha * avg; avg = aa + cur[u]; }
+            for (int u = 0; u < 8; ++u) { av[u] = avg; const float aa = nb_alpha_v * avg; avg = aa + cur[u]; }
             store8(Lc + NB_B + 2 + 8 * (c + half), av);
           }
         }
@@ -2273,7 +2281,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         v2f fa[4], fb[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { fa[e] = (v2f){0.0f, 0.0f}; fb[e] = (v2f){0.0f, 0.0f}; }
-        if (ABL_ON(ABL_HIL)) hilbert_fir<0, 4>(L, 4 * s8, fa);   // outputs 8 s8 + 2e, + 1
+        if (ABL_ON(ABL_HIL)) hilbert_fir<0, 4, false>(L, 4 * s8, fa);   // outputs 8 s8 + 2e, + 1  (taps as scalar operands: this form has no register for them)
         WAVE_SYNC();                                               // pass 1 has read everything it needs
         {
           float t[32];
@@ -2289,7 +2297,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           for (int j = 0; j < 4; ++j) { const int k = kF + 32 * m + j; if (k >= 63 && k < 127) L[XP + 191 + k] = qn[4 * m + j]; }   // x[256 + k] at word 256 + k - 65
         }
         WAVE_SYNC();
-        if (ABL_ON(ABL_HIL)) hilbert_fir<0, 4>(L, 4 * s8, fb);   // the same window 64 samples on: outputs 64 + 8 s8 + 2e, + 1
+        if (ABL_ON(ABL_HIL)) hilbert_fir<0, 4, false>(L, 4 * s8, fb);   // the same window 64 samples on: outputs 64 + 8 s8 + 2e, + 1
         WAVE_SYNC();                                               // all history reads done: W1 may overwrite it
         TL(9);
         load_af_agc_state();
@@ -3278,9 +3286,58 @@ extern "C" __global__ __launch_bounds__(128, ASDR_WAVES_PER_EU) void asdr_stream
   else if (role == 1) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 2>(a, lds);
   else asdr_update_body<ASDR_STRIDE, false, false, true, 1, 3>(a, lds);
 }
+
+// ---- launch census (round 6): every kernel launch of this file goes through ASDR_LAUNCH, which counts it under the kernel's name -- so that a
+// measurement can say WHICH instantiation it timed (bench.py's `roofline.kernel` was a hard-coded string that had gone stale).  The table is the
+// list of this file's kernels: tests/test_build_properties.py checks it against the __global__ definitions and the launch sites.
+static const char *const k_kernel_names[] = {
+  "asdr_als_back_loop_kernel",
+  "asdr_als_kernel",
+  "asdr_als_pre_kernel",
+  "asdr_als_pre_loop_kernel",
+  "asdr_als_stage_seed_kernel",
+  "asdr_reset_kernel",
+  "asdr_sam_pll_kernel",
+  "asdr_sam_post_als_kernel",
+  "asdr_sam_post_als_kernel_uniform",
+  "asdr_sam_post_kernel",
+  "asdr_sam_post_kernel_uniform",
+  "asdr_sam_post_loop_kernel_uniform",
+  "asdr_sam_pre_kernel",
+  "asdr_sam_pre_kernel_uniform",
+  "asdr_sam_pre_loop_kernel_uniform",
+  "asdr_spin_kernel",
+  "asdr_stream_ack_kernel",
+  "asdr_stream_kernel",
+  "asdr_stream_restore_kernel",
+  "asdr_stream_snapshot_kernel",
+  "asdr_update_kernel",
+  "asdr_update_kernel_als",
+  "asdr_update_kernel_als_mixed",
+  "asdr_update_kernel_als_small",
+  "asdr_update_kernel_als_small_mixed",
+  "asdr_update_kernel_als_small_one",
+  "asdr_update_kernel_c16",
+  "asdr_update_kernel_mixed",
+  "asdr_update_kernel_mw",
+  "asdr_update_kernel_one",
+  "asdr_update_kernel_sam"
+};
+#define ASDR_N_KERNEL_NAMES ((int)(sizeof k_kernel_names / sizeof k_kernel_names[0]))
+static unsigned long long g_kernel_launches[ASDR_N_KERNEL_NAMES];
+static inline void count_launch(const char *name) {
+  for (int i = 0; i < ASDR_N_KERNEL_NAMES; ++i)
+    if (strcmp(k_kernel_names[i], name) == 0) { __atomic_fetch_add(&g_kernel_launches[i], 1ull, __ATOMIC_RELAXED); return; }
+}
+#define ASDR_LAUNCH(kernel, ...) do { count_launch(#kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
+extern "C" int asdr_kernels_count(void) { return ASDR_N_KERNEL_NAMES; }
+extern "C" const char *asdr_kernels_name(int i) { return (i >= 0 && i < ASDR_N_KERNEL_NAMES) ? k_kernel_names[i] : nullptr; }
+extern "C" unsigned long long asdr_kernels_launches(int i) { return (i >= 0 && i < ASDR_N_KERNEL_NAMES) ? __atomic_load_n(&g_kernel_launches[i], __ATOMIC_RELAXED) : 0ull; }
+extern "C" void asdr_kernels_launches_reset(void) { for (int i = 0; i < ASDR_N_KERNEL_NAMES; ++i) __atomic_store_n(&g_kernel_launches[i], 0ull, __ATOMIC_RELAXED); }
+
 extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
   if (a->stream_waves <= 0) return 0;
-  hipLaunchKernelGGL(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(128), 0, stream, *a);
+  ASDR_LAUNCH(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(128), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // How many workgroups of the pipeline kernel the device can hold at once (occupancy x compute units): the pipeline's roles wait
@@ -3336,12 +3393,12 @@ extern "C" __global__ void asdr_stream_ack_kernel(uint32_t *err) {
 extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int restore, hipStream_t stream) {
   const int groups = a->n_sched / 8;
   if (groups <= 0) return 0;
-  if (restore) hipLaunchKernelGGL(asdr_stream_restore_kernel, dim3(groups), dim3(256), 0, stream, *a, reinterpret_cast<uint4 *>(snap));
-  else hipLaunchKernelGGL(asdr_stream_snapshot_kernel, dim3(groups), dim3(256), 0, stream, *a, reinterpret_cast<uint4 *>(snap));
+  if (restore) ASDR_LAUNCH(asdr_stream_restore_kernel, dim3(groups), dim3(256), 0, stream, *a, reinterpret_cast<uint4 *>(snap));
+  else ASDR_LAUNCH(asdr_stream_snapshot_kernel, dim3(groups), dim3(256), 0, stream, *a, reinterpret_cast<uint4 *>(snap));
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream) {
-  hipLaunchKernelGGL(asdr_stream_ack_kernel, dim3(1), dim3(64), 0, stream, err);
+  ASDR_LAUNCH(asdr_stream_ack_kernel, dim3(1), dim3(64), 0, stream, err);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -3381,25 +3438,25 @@ extern "C" __global__ void asdr_reset_kernel(UpdateArgs a, const uint32_t *reset
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (variant == ASDR_KERNEL_ALS || (variant == ASDR_KERNEL_SAM_ALS && a->xch_sam == nullptr)) { if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  if (variant == ASDR_KERNEL_ALS || (variant == ASDR_KERNEL_SAM_ALS && a->xch_sam == nullptr)) { if (uniform) ASDR_LAUNCH(asdr_update_kernel_als, dim3(n_waves), dim3(64), 0, stream, *a); else ASDR_LAUNCH(asdr_update_kernel_als_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if (variant == ASDR_KERNEL_ALS_SMALL && uniform == 2) {   // chain up to the AGC | the filter + output, two launches (one block per call: the host loops)
-    hipLaunchKernelGGL(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    ASDR_LAUNCH(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    ASDR_LAUNCH(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   }
-  else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform && ASDR_ONEBLK && ASDR_ONEBLK_ALS && a->n_blocks == 1 && a->run_if == nullptr) hipLaunchKernelGGL(asdr_update_kernel_als_small_one, dim3(n_waves), dim3(64), 0, stream, *a); else if (uniform) hipLaunchKernelGGL(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else hipLaunchKernelGGL(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
+  else if (variant == ASDR_KERNEL_ALS_SMALL) { if (uniform && ASDR_ONEBLK && ASDR_ONEBLK_ALS && a->n_blocks == 1 && a->run_if == nullptr) ASDR_LAUNCH(asdr_update_kernel_als_small_one, dim3(n_waves), dim3(64), 0, stream, *a); else if (uniform) ASDR_LAUNCH(asdr_update_kernel_als_small, dim3(n_waves), dim3(64), 0, stream, *a); else ASDR_LAUNCH(asdr_update_kernel_als_small_mixed, dim3(n_waves), dim3(64), 0, stream, *a); }
   else if ((variant == ASDR_KERNEL_SAM || variant == ASDR_KERNEL_SAM_ALS) && a->xch_sam != nullptr) {   // pre | PLL | post (one block per call: the host loops)
-    if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
+    if (uniform) ASDR_LAUNCH(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else ASDR_LAUNCH(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    ASDR_LAUNCH(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
     if (variant == ASDR_KERNEL_SAM_ALS) {
-      if (uniform) hipLaunchKernelGGL(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-      else hipLaunchKernelGGL(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+      if (uniform) ASDR_LAUNCH(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+      else ASDR_LAUNCH(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     } else {
-      if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-      else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+      if (uniform) ASDR_LAUNCH(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+      else ASDR_LAUNCH(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
     }
   }
-  else if (variant == ASDR_KERNEL_SAM) hipLaunchKernelGGL(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
+  else if (variant == ASDR_KERNEL_SAM) ASDR_LAUNCH(asdr_update_kernel_sam, dim3((n_waves + ASDR_SAM_WAVES - 1) / ASDR_SAM_WAVES), dim3(64 * ASDR_SAM_WAVES), 0, stream, *a);
   else {
     // the four-wave workgroup form: large direct one-block launches (ASDR_MW=0 / ASDR_MW_MIN_WAVES=<n> in the environment: measurements, tests)
     static int mw_on = -1, mw_min = ASDR_MW_MIN_WAVES, c16_on = ASDR_C16, c16_min = ASDR_C16_MIN_WAVES, c16_pad = 0;
@@ -3411,14 +3468,14 @@ extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform,
     const uint32_t dm = a->direct_mode;
     const bool ssb_class = dm == ASDR_USBmode || dm == ASDR_LSBmode || dm == ASDR_CW_USBmode || dm == ASDR_CW_LSBmode || dm == ASDR_WSPRmode;
     if (uniform && c16_on && a->n_blocks == 1 && a->run_if == nullptr && a->direct_ch0 >= 0 && a->taps == nullptr && ssb_class && n_waves >= c16_min)
-      hipLaunchKernelGGL(asdr_update_kernel_c16, dim3(n_waves), dim3(64), (size_t)c16_pad, stream, *a);   // (c16_pad: dynamic LDS that takes the occupancy back, measurements)
+      ASDR_LAUNCH(asdr_update_kernel_c16, dim3(n_waves), dim3(64), (size_t)c16_pad, stream, *a);   // (c16_pad: dynamic LDS that takes the occupancy back, measurements)
     else
     if (uniform && mw_on && a->n_blocks == 1 && a->run_if == nullptr && a->direct_ch0 >= 0 && n_waves >= mw_min)
-      hipLaunchKernelGGL(asdr_update_kernel_mw, dim3((n_waves + ASDR_MW_WAVES - 1) / ASDR_MW_WAVES), dim3(64 * ASDR_MW_WAVES), 0, stream, *a);
+      ASDR_LAUNCH(asdr_update_kernel_mw, dim3((n_waves + ASDR_MW_WAVES - 1) / ASDR_MW_WAVES), dim3(64 * ASDR_MW_WAVES), 0, stream, *a);
     else
-    if (uniform && ASDR_ONEBLK && a->n_blocks == 1 && a->run_if == nullptr) hipLaunchKernelGGL(asdr_update_kernel_one, dim3(n_waves), dim3(64), 0, stream, *a);
-    else if (uniform) hipLaunchKernelGGL(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (uniform && ASDR_ONEBLK && a->n_blocks == 1 && a->run_if == nullptr) ASDR_LAUNCH(asdr_update_kernel_one, dim3(n_waves), dim3(64), 0, stream, *a);
+    else if (uniform) ASDR_LAUNCH(asdr_update_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    else ASDR_LAUNCH(asdr_update_kernel_mixed, dim3(n_waves), dim3(64), 0, stream, *a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -3434,16 +3491,16 @@ extern "C" __global__ void asdr_als_stage_seed_kernel(UpdateArgs a, int ch0, int
 extern "C" int asdr_launch_als_role(const UpdateArgs *a, int role, hipStream_t stream) {
   const int n_waves = a->n_sched / 8;
   if (n_waves <= 0) return 0;
-  if (role == 2) hipLaunchKernelGGL(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);      // three stages: the front half (scale, blanker, IF) -> tiles
-  else if (role == 3) hipLaunchKernelGGL(asdr_als_back_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);       // ... the back half (mixer .. AGC) -> stage
-  else if (role == 0 && a->n_blocks > 1) hipLaunchKernelGGL(asdr_als_pre_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
-  else if (role == 0) hipLaunchKernelGGL(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
-  else hipLaunchKernelGGL(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  if (role == 2) ASDR_LAUNCH(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);      // three stages: the front half (scale, blanker, IF) -> tiles
+  else if (role == 3) ASDR_LAUNCH(asdr_als_back_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);       // ... the back half (mixer .. AGC) -> stage
+  else if (role == 0 && a->n_blocks > 1) ASDR_LAUNCH(asdr_als_pre_loop_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  else if (role == 0) ASDR_LAUNCH(asdr_als_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+  else ASDR_LAUNCH(asdr_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int asdr_launch_als_stage_seed(const UpdateArgs *a, int ch0, int n, hipStream_t stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(asdr_als_stage_seed_kernel, dim3(n), dim3(ASDR_N), 0, stream, *a, ch0, n);
+  ASDR_LAUNCH(asdr_als_stage_seed_kernel, dim3(n), dim3(ASDR_N), 0, stream, *a, ch0, n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -3457,22 +3514,22 @@ extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int unifor
   // 25-block calls ended with a wrong last block).  The looped kernels run a one-block chunk like any other.
   if (a->n_blocks > 1 || a->sam_sets > 1u) {   // uniform SAM sub-ranges only (asdr_host.cpp)
     if (!uniform || variant != ASDR_KERNEL_SAM) return -1;
-    if (role == 0) hipLaunchKernelGGL(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-    else if (role == 1) hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_sam_post_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (role == 0) ASDR_LAUNCH(asdr_sam_pre_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else if (role == 1) ASDR_LAUNCH(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
+    else ASDR_LAUNCH(asdr_sam_post_loop_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   if (role == 0) {
-    if (uniform) hipLaunchKernelGGL(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (uniform) ASDR_LAUNCH(asdr_sam_pre_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else ASDR_LAUNCH(asdr_sam_pre_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   } else if (role == 1) {
-    hipLaunchKernelGGL(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
+    ASDR_LAUNCH(asdr_sam_pll_kernel, dim3((a->n_sched + ASDR_PLL_LANES - 1) / ASDR_PLL_LANES), dim3(64), 0, stream, *a);
   } else if (variant == ASDR_KERNEL_SAM_ALS) {
-    if (uniform) hipLaunchKernelGGL(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (uniform) ASDR_LAUNCH(asdr_sam_post_als_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else ASDR_LAUNCH(asdr_sam_post_als_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   } else {
-    if (uniform) hipLaunchKernelGGL(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
-    else hipLaunchKernelGGL(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
+    if (uniform) ASDR_LAUNCH(asdr_sam_post_kernel_uniform, dim3(n_waves), dim3(64), 0, stream, *a);
+    else ASDR_LAUNCH(asdr_sam_post_kernel, dim3(n_waves), dim3(64), 0, stream, *a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -3484,11 +3541,11 @@ extern "C" __global__ void asdr_spin_kernel(unsigned long long ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 extern "C" int asdr_launch_spin(unsigned long long ticks, hipStream_t stream) {
-  hipLaunchKernelGGL(asdr_spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
+  ASDR_LAUNCH(asdr_spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 extern "C" int asdr_launch_reset(const UpdateArgs *a, const uint32_t *d_reset_bits, int first_row, int n_rows, hipStream_t stream) {
-  hipLaunchKernelGGL(asdr_reset_kernel, dim3(n_rows), dim3(128), 0, stream, *a, d_reset_bits, first_row, n_rows);
+  ASDR_LAUNCH(asdr_reset_kernel, dim3(n_rows), dim3(128), 0, stream, *a, d_reset_bits, first_row, n_rows);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -64,6 +64,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_INPUT_BLOCKS = 4                    # distinct resident input blocks cycled through by the steps
 PMC_FILE = os.path.join("profiles", "pmc_latest.json")
 ISSUE_FILE = os.path.join("profiles", "issue_latest.json")
+LATENCY_FILE = os.path.join("profiles", "roofline_latency_latest.json")
 
 # ---- algorithmic bytes per channel-block, SURVEY.md 8d (minimal carried state read AND written once per block at T = 1) ----
 B_IO, B_PARAMS = 768, 96
@@ -82,13 +83,22 @@ C5_ALGO_BYTES_PER_BLOCK = (B_IO * C5_T + B_PARAMS + 2.0 * C5_STATE) / C5_T      
 CONFIGS = {
     # name: (channels of the whole job or per GPU, scaling, blocks per step, default settle steps)
     "c2": dict(channels=65536, per_gpu=True, scaling="weak", blocks=1, settle=1500, algo=ALGO_BYTES_PER_BLOCK,
-               kernel="asdr_update_kernel_one"),
+               kernel="asdr_update_kernel_mw"),   # (the label comes from the library's launch census of the timed region: dominant_kernel; this is the dry-run fallback)
     "c4": dict(channels=1048576, per_gpu=False, scaling="strong", blocks=1, settle=300, algo=C4_ALGO_BYTES_PER_BLOCK,
                kernel="asdr_update_kernel_als_small_one (+ the SAM pre | PLL | post launches and the remainders' launch beside it)"),
     "c5": dict(channels=4096, per_gpu=False, scaling="strong", blocks=C5_T, settle=4, algo=C5_ALGO_BYTES_PER_BLOCK,
                kernel="asdr_stream_kernel"),
 }
 CHANNELS_PER_GPU = CONFIGS["c2"]["channels"]
+
+
+def dominant_kernel(launched, fallback):
+    """The kernel the roofline object is about: of the instantiations the library launched in the timed region (its launch census), the one the
+    region's time belongs to -- the chain kernel with the most launches (the PLL / role / snapshot launches beside it are named in the census)."""
+    chain = {k: n for k, n in launched.items() if k.startswith(("asdr_update_kernel", "asdr_stream_kernel"))}
+    if not chain:
+        return fallback if not launched else max(launched, key=launched.get)
+    return max(chain, key=chain.get)
 
 
 def configure_c2(sdr):
@@ -209,7 +219,9 @@ def cpu_baseline(seconds_budget=14.0):
                 "worth of arithmetic for %d threads of one process (register-only float loop, ao_spin_calibrate): "
                 "against that capacity the oracle scales %.2f x" % (scaling, cores, capacity, threads, rate_n / (rate1 * capacity)))
     return {"value": round(rate_n / 1e6, 3), "unit": "Msamples/s", "cores": threads, "physical_cores": phys, "cpu_model": model,
-            "kind": "port", "one_thread_value": round(rate1 / 1e6, 3), "sample_seconds": round(tn, 3),
+            "kind": "port", "one_thread_value": round(rate1 / 1e6, 3),
+            "one_thread_value_times_physical_cores": round(rate1 * cores / 1e6, 1),   # the scale to read the GPU figure against: what this host's cores would give if the box scheduled them all
+            "sample_seconds": round(tn, 3),
             "host_parallel_capacity_threads": round(capacity, 2),
             "sample": "CPU oracle (oracle/asdr_oracle.c, gcc -O2 -ffp-contract=off), C2 USB chain, %d channels x %d blocks on %d "
                       "threads, update() only in the timed region (instances created and configured before it)%s"
@@ -485,11 +497,13 @@ def main_single_process(args, cfg, settle_min, warm_req):
     for i in range(max(settle_min, 0) + args.warmup):
         step(i)
     sync()
+    A.binding.kernels_launched(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     sync()
     wall = time.perf_counter() - t0
+    launched = A.binding.kernels_launched()
     per_gpu_ms = wall / args.steps * 1e3
     algo = cfg["algo"] * total_ch
     ach = algo / G / (per_gpu_ms * 1e-3) / 1e9      # per GPU: each holds 1/G of the channels
@@ -501,7 +515,8 @@ def main_single_process(args, cfg, settle_min, warm_req):
                       "name": args.config, "launch": "single process, asdr_create_sharded, asynchronous asdr_update_device on every shard's stream",
                       "devices": devices, "warmup_requested": warm_req, "clock_settle_launches": settle_min, "channels_total": total_ch,
                       "sharding": "channels, no collective", "unmeasured_on_multi_gpu_hardware": len(set(devices)) < G},
-           "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": dominant_kernel(launched, cfg["kernel"]), "kernels_launched_in_the_timed_region": launched,
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(per_gpu_ms, 5),
                         "kernel_ms_method": "host clock around the timed steps (all shards' streams synchronised on both sides) / steps; per GPU when the shards are on different devices"}}
     print(json.dumps(out), flush=True)
@@ -654,6 +669,7 @@ def main():
     # that per-launch figure is taken AFTER the timed region, from 40 further launches, and reported beside it.)
     fence()
     if batch is not None:
+        A.binding.kernels_launched(reset=True)   # the launch census of the timed region names the kernel the roofline object is about
         batch.region_timing_begin(stream)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -663,6 +679,7 @@ def main():
     fence()
     t1 = time.perf_counter()
     wall = t1 - t0
+    launched = A.binding.kernels_launched() if batch is not None else {}
     if not args.dry_run and scratch is not None:
         scratch.close()
     k_ms = region_ms / max(1, region_calls) if batch is not None else 0.0
@@ -746,6 +763,26 @@ def main():
                                         "not arithmetic -- DESIGN.md 5")
         except Exception:
             pass
+        # The kernel against its LATENCY roofline (profiles/roofline_latency_latest.json, tools/latency_model.py: per phase, the dependent instruction
+        # stream -- what a lone workgroup needs for it -- x the measured issue interval of a wave that shares its SIMD with two others running
+        # the same mix, tools/ubench/issue_rate.hip).  Dropped when the file is from other sources.
+        latency = None
+        try:
+            with open(os.path.join(ROOT, LATENCY_FILE)) as f:
+                lj = json.load(f)
+            if args.config == "c2" and n_ch == CHANNELS_PER_GPU and not args.dry_run:
+                from audiosdr_amd import build as _build
+                if lj.get("source_sha256") == _build.source_sha256():
+                    latency = {k: lj.get(k) for k in ("kernel", "model", "wave_lifetime_cycles", "model_over_measured", "ms_per_step", "shader_clock_ghz_assumed",
+                                                      "waves", "resident_waves")}
+                    latency["phases"] = [{k: p.get(k) for k in ("phase", "mix", "instructions", "lone_cycles", "cycles_per_instruction_at_1_2_3_waves_per_simd",
+                                                                "three_active_waves_cycles", "full_launch_cycles") if k in p} for p in lj.get("phases", [])]
+                    latency["source"] = "%s (tools/latency_model.py on one GPU box: tools/ubench/issue_rate + tools/timeline.py mw as a lone workgroup and inside the full launch; the timeline build carries 28 marks per wave and runs on a caller's stream)" % LATENCY_FILE
+                    latency["reading"] = ("floor_lone_stream: every wave gets through its own dependent stream as if alone on its SIMD (nothing shortens that without removing instructions); "
+                                          "three_always_active_waves: the same streams at the issue interval measured for three waves sharing a SIMD; the measured lifetime lies between "
+                                          "the two, the north-star's 0.0891 ms needs it within 28 % of the lone stream -- DESIGN.md 5")
+        except Exception:
+            pass
         workload = {
             "c2": "C2: SSB (USB) demod, %d channels/GPU x 1 block/step, NB+IF+mixer+Hilbert+audio IIR+AGC" % n_ch,
             "c4": "C4: mixed modes (channel mod 7: LSB, USB, CW_LSB, CW_USB, AM, SAM, WSPR) + ALS notch + blanker at 10 dB, %d channels "
@@ -769,7 +806,8 @@ def main():
                        "warmup_requested": warm_req, "clock_settle_launches_on_a_scratch_batch": 0 if args.dry_run else settle_min,
                        "channels_per_gpu": n_ch, "channels_total": total_ch, "blocks_per_step": T, "block": BLOCK,
                        "sharding": "channels, no collective", "input": inputs},
-            "roofline": {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dominant_kernel(launched, cfg["kernel"]), "kernels_launched_in_the_timed_region": launched,
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 5),
                          "kernel_ms_method": "one HIP-event pair on the launch stream around the %d timed steps / %d" % (args.steps, args.steps),
@@ -783,6 +821,8 @@ def main():
         }
         if issue is not None:
             out["roofline_issue"] = issue
+        if latency is not None:
+            out["roofline_latency"] = latency
         if args.config == "c2":
             out["roofline"]["hbm_read_share_frac"] = round(ALGO_READ_BYTES_PER_BLOCK * n_ch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else 0.0
         if args.config == "c5":

@@ -377,6 +377,12 @@ int asdr_debug_set_stream_max_groups(asdr_batch_t *b, int groups);
 int asdr_schedule_layout(asdr_batch_t *b, int out[8]);
 /* Library / build identification string (contains "gfx950"). */
 const char *asdr_version(void);
+/* Launch census (process-wide): how often each kernel of the chain has been launched since the last reset -- so that a measurement can name the
+ * instantiation it timed (bench.py `roofline.kernel`, `kernels_launched`).  asdr_kernels_count() names, 0 <= i < count. */
+int asdr_kernels_count(void);
+const char *asdr_kernels_name(int i);
+unsigned long long asdr_kernels_launches(int i);
+void asdr_kernels_launches_reset(void);
 
 #ifdef __cplusplus
 }

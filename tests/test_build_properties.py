@@ -50,3 +50,24 @@ def test_the_16_waves_per_cu_kernel_fits_its_budget():
     10,240 B = the CU's 160 KB)."""
     r = _resources("asdr_kernels.hip")["asdr_update_kernel_c16"]
     assert r["VGPRs"] <= 128 and r.get("VGPRs Spill", 0) == 0 and r["LDS Size [bytes/block]"] <= 10240, r
+
+
+def test_launch_census_names_every_kernel_of_the_chain():
+    """The launch census (include/asdr.h asdr_kernels_*; bench.py's `roofline.kernel` comes from it) lists exactly the kernels asdr_kernels.hip
+    defines, and every launch site goes through ASDR_LAUNCH (a raw hipLaunchKernelGGL would be a launch the census never sees)."""
+    import re
+    from audiosdr_amd import build as b
+    import audiosdr_amd as A
+    src = open(os.path.join(b.CSRC, "asdr_kernels.hip")).read()
+    defined = set(re.findall(r'extern "C" __global__ (?:__launch_bounds__\([^)]*\) )?void (\w+)\(', src))
+    defined |= set(re.findall(r"^ASDR_KERNEL\((\w+),", src, flags=re.M))
+    defined -= {"name"}   # (the ASDR_KERNEL macro's own parameter)
+    launched = set(re.findall(r"ASDR_LAUNCH\((\w+),", src)) - {"kernel"}   # ("kernel" = the macro's own parameter)
+    raw = [m for m in re.findall(r"hipLaunchKernelGGL\((\w+)", src) if m != "kernel"]   # ("kernel" = the macro's own parameter)
+    assert not raw, "launches outside the census: %s" % raw
+    L = A.load_library()
+    names = {L.asdr_kernels_name(i).decode() for i in range(L.asdr_kernels_count())}
+    assert names == launched, (sorted(names - launched), sorted(launched - names))
+    assert launched <= defined, sorted(launched - defined)
+    assert defined - launched == set(), "kernels that nothing launches: %s" % sorted(defined - launched)
+    assert A.binding.kernels_launched() == {} or True   # (callable without a device)

@@ -43,5 +43,11 @@ for c in c3 c4; do
   f=$(find "$OUT/stats_$c" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${c}_kernel_stats.csv"
 done
+# round 6: the four-wave kernel's phase timeline (profiling build: audiosdr_amd/variants/libasdr_timeline.so, `python tools/latency_model.py build` here),
+# inside the full launch (steady and fresh bank) and as a lone workgroup, the per-mix issue intervals at 1..4 waves per SIMD, and the latency model made of them
+python3 tools/timeline.py mw > "$OUT/mw_timeline.txt" 2> "$OUT/mw_timeline.err"
+ASDR_MW_MIN_WAVES=1 python3 tools/timeline.py mw 300 32 >> "$OUT/mw_timeline.txt" 2>> "$OUT/mw_timeline.err"
+python3 tools/latency_model.py run "$OUT/roofline_latency.json" > /dev/null 2> "$OUT/roofline_latency.err"
+python3 tools/small_batch_stream.py 128 > "$OUT/small_batch_stream.jsonl" 2> "$OUT/small_batch_stream.err"
 rm -rf "$OUT/stats" "$OUT/stats_cs" "$OUT/stats_c3" "$OUT/stats_c4" "$OUT"/pmc/*/ "$OUT"/pmc_mix/*/ "$OUT"/pmc_c3/*/ "$OUT"/pmc_c4/*/
 cat "$OUT/bench.json"; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/configs_1gpu.jsonl"; cat "$OUT/bench_c4.json" "$OUT/bench_c5.json" "$OUT/bench_c5_share.json"

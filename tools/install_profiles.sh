@@ -15,6 +15,9 @@ cp $S/front_bench_16blk.jsonl profiles/${T}_front_bench_16blk.jsonl; cp $S/front
 cp $S/pmc_c3.json profiles/${T}_pmc_c3.json; cp $S/pmc_c4.json profiles/${T}_pmc_c4.json
 cp $S/bench_c4.json profiles/${T}_bench_c4.json; cp $S/bench_c5.json profiles/${T}_bench_c5.json; cp $S/bench_c5_share.json profiles/${T}_bench_c5_share.json
 cp $S/bench_single_process_2shards_1gpu.json profiles/${T}_bench_single_process_2shards_1gpu.json
+[ -f $S/mw_timeline.txt ] && grep -v "^/opt" $S/mw_timeline.txt > profiles/${T}_mw_timeline.txt
+[ -f $S/roofline_latency.json ] && cp $S/roofline_latency.json profiles/${T}_roofline_latency.json && cp $S/roofline_latency.json profiles/roofline_latency_latest.json
+[ -f $S/small_batch_stream.jsonl ] && cp $S/small_batch_stream.jsonl profiles/${T}_small_batch_stream.jsonl
 python3 tools/issue_model.py profiles/${T}_c2_pmc.json profiles/${T}_c2_pmc_mix.json profiles/${T}_c2_kernel_stats_caller_stream.csv profiles/issue_latest.json > /dev/null
 python3 - "$T" <<'PY'
 import json, sys

@@ -67,85 +67,105 @@ def run():
 
 
 MW_SEQ = [0, 1, 2, 17, 18, 19, 20, 3, 4, 5, 6, 7, 8, 9, 10, 21, 22, 23, 24, 11, 12, 25, 26, 27, 28, 13, 14, 15]
-MW_NAMES = ["prologue + loads issued", "NB: envelopes, ring store", "NB: publish chain inputs",
-            "  barrier 1 (chains may start): parked", "  NB chain duty (rel 0 works, others pass)", "  barrier 2 (chains done): parked",
-            "NB: threshold test", "NB: mask / output rows (quiet path)", "IF pipeline (+ ring prefetch issue)", "mixer phase / uniform test",
-            "mixer multiply, AF / AGC state loads", "Hilbert: stage history", "Hilbert: FIR", "sideband combine (+ delayed I wait)",
-            "  barrier 3 (audio rows ready): parked", "  audio cascade duty (rel 1, 2 work)", "  barrier 4 (cascades done): parked",
-            "(tap row)", "AGC: |x|, block maximum, quiet test", "  barrier 5 (AGC inputs): parked", "  AGC chain duty (rel 3 works)",
-            "  barrier 6 (AGC chains done): parked", "(status)", "AGC: apply", "output + status"]
+# the 27 intervals between consecutive marks of MW_SEQ; kind: c = the wave computes, b = parked at a workgroup barrier, d = a duty section (one or two
+# waves of the workgroup work, the others pass through), w = dominated by a memory wait
+MW_PHASES = [("prologue + loads issued (first HBM round trip)", "w"), ("NB: envelopes, ring store", "c"), ("NB: publish chain inputs", "c"),
+             ("  barrier 1 (chains may start): parked", "b"), ("  NB chain duty (rel 0 works, others pass)", "d"), ("  barrier 2 (chains done): parked", "b"),
+             ("NB: threshold test", "c"), ("NB: mask / output rows", "c"), ("IF pipeline (+ ring prefetch issue)", "c"), ("mixer phase / uniform test", "c"),
+             ("mixer multiply, AF / AGC state loads", "c"), ("Hilbert: stage history", "c"), ("Hilbert: FIR", "c"), ("sideband combine (+ delayed I wait)", "c"),
+             ("AGC table request", "c"), ("  barrier 3 (audio rows ready): parked", "b"), ("  audio cascade duty (rel 1, 2 work)", "d"),
+             ("  barrier 4 (cascades done): parked", "b"), ("(to the next mark)", "c"), ("AGC: |x|, block maximum, quiet test", "c"), ("AGC: publish", "c"),
+             ("  barrier 5 (AGC inputs): parked", "b"), ("  AGC chain duty (rel 3 works)", "d"), ("  barrier 6 (AGC chains done): parked", "b"),
+             ("(to the next mark)", "c"), ("AGC: apply", "c"), ("output + status", "c")]
+MW_WGS = (0, 683, 1365, 2047)
 
 
-def mw(warm=None):
-    """The four-wave workgroup form (asdr_update_kernel_mw) inside a full C2 launch: all four waves of workgroups 0, 683, 1365, 2047 write
-    clock64() at the 16 phase boundaries and on either side of the six workgroup barriers.  Prints, per duty (rel 0 = blanker / phase chains,
-    1 and 2 = audio cascades, 3 = AGC chain), shader-clock cycles per phase, the cycles parked at each barrier, and the sums."""
+def mw_measure(warm, n_ch=65536, launches=12):
+    """Raw marks [launch][workgroup][wave][32] of the four-wave form: all four waves of workgroups 0, 683, 1365, 2047 (a lone workgroup: 0 only)."""
     import audiosdr_amd as A
     from audiosdr_amd.synth import make_iq
     import torch
     L = A.binding.load_library(LIB)
-    n_ch = 65536
-    uniq = 2048
+    uniq = min(2048, n_ch)
     I, Q = make_iq(uniq, 6, fc=6290.0, A=0.25)
     I = np.tile(I, (n_ch // uniq, 1, 1)); Q = np.tile(Q, (n_ch // uniq, 1, 1))
-    for warm in ([int(warm)] if warm is not None else [300, 8]):
-        h = L.asdr_create(n_ch, 0)
-        L.asdr_setDemodMode(h, -1, 1); L.asdr_enableAudioFilter(h, -1); L.asdr_enable_taps(h, 1)
-        dOut = torch.empty((n_ch, 128), dtype=torch.int16, device="cuda")
-        dIs = [torch.from_numpy(np.ascontiguousarray(I[:, b])).cuda() for b in range(6)]
-        dQs = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).cuda() for b in range(6)]
-        for b in range(warm):
-            L.asdr_update_device(h, C.c_void_p(dIs[b % 6].data_ptr()), C.c_void_p(dQs[b % 6].data_ptr()), C.c_void_p(dOut.data_ptr()), 1, None)
-        rows = []
-        for b in range(12):
-            dI, dQ = dIs[(warm + b) % 6], dQs[(warm + b) % 6]
-            L.asdr_update_device(h, C.c_void_p(dI.data_ptr()), C.c_void_p(dQ.data_ptr()), C.c_void_p(dOut.data_ptr()), 1, None)
-            taps = np.zeros((12, n_ch, 128), dtype=np.float32)
-            L.asdr_read_taps(h, taps.ctypes.data_as(C.POINTER(C.c_float)))
-            tl = taps.reshape(-1).view(np.uint64)[:16 * 32].reshape(4, 4, 32).astype(np.int64)   # [workgroup][wave][entry]
-            rows.append(tl)
-        L.asdr_destroy(h)
-        raw = np.stack(rows)                            # [launch][wg][wave][32]
+    h = L.asdr_create(n_ch, 0)
+    L.asdr_setDemodMode(h, -1, 1); L.asdr_enableAudioFilter(h, -1); L.asdr_enable_taps(h, 1)
+    dOut = torch.empty((n_ch, 128), dtype=torch.int16, device="cuda")
+    dIs = [torch.from_numpy(np.ascontiguousarray(I[:, b])).cuda() for b in range(6)]
+    dQs = [torch.from_numpy(np.ascontiguousarray(Q[:, b])).cuda() for b in range(6)]
+    for b in range(warm):
+        L.asdr_update_device(h, C.c_void_p(dIs[b % 6].data_ptr()), C.c_void_p(dQs[b % 6].data_ptr()), C.c_void_p(dOut.data_ptr()), 1, None)
+    rows = []
+    n_wg = 4 if n_ch >= 65536 else 1
+    for b in range(launches):
+        dI, dQ = dIs[(warm + b) % 6], dQs[(warm + b) % 6]
+        L.asdr_update_device(h, C.c_void_p(dI.data_ptr()), C.c_void_p(dQ.data_ptr()), C.c_void_p(dOut.data_ptr()), 1, None)
+        taps = np.zeros((12, n_ch, 128), dtype=np.float32)
+        L.asdr_read_taps(h, taps.ctypes.data_as(C.POINTER(C.c_float)))
+        rows.append(taps.reshape(-1).view(np.uint64)[:16 * 32].reshape(4, 4, 32)[:n_wg].astype(np.int64))
+    L.asdr_destroy(h)
+    return np.stack(rows)
+
+
+def mw_table(raw, n_ch, warm):
+    """Per phase and duty: median cycles.  Returns the dict tools/latency_model.py works on."""
+    n_wg = raw.shape[1]
+    tl = raw[:, :, :, MW_SEQ]
+    d = np.diff(tl, axis=3).astype(np.float64)      # 27 intervals
+    rel = np.array([[(w - wg) & 3 for w in range(4)] for wg in MW_WGS[:n_wg]])   # duty of wave w of workgroup wg
+    life = (tl[..., -1] - tl[..., 0]).astype(np.float64)
+    wg_span = (tl[..., -1].max(axis=2) - tl[..., 0].min(axis=2)).astype(np.float64)
+    phases = []
+    for k, (nm, kind) in enumerate(MW_PHASES):
+        v = [float(np.median(d[:, rel == r, k])) for r in range(4)]
+        phases.append({"name": nm.strip(), "kind": kind, "cycles_by_duty": v, "cycles_mean": float(np.mean(v))})
+    return {"channels": n_ch, "warm_up_blocks": warm, "launches": int(raw.shape[0]), "workgroups_sampled": list(MW_WGS[:n_wg]),
+            "workgroup_span_cycles": float(np.median(wg_span)), "wave_lifetime_cycles_by_duty": [float(np.median(life[:, rel == r])) for r in range(4)],
+            "wave_lifetime_cycles": float(np.median(life)), "phases": phases}
+
+
+def mw_print(t):
+    print("== asdr_update_kernel_mw, %d channels%s, %d warm-up blocks (%s): shader-clock cycles, medians over %d launches x %d workgroup(s)" %
+          (t["channels"], " (a LONE workgroup: nothing else on the chip, one wave per SIMD)" if t["channels"] <= 32 else "", t["warm_up_blocks"],
+           "steady bank: AGC quiet path" if t["warm_up_blocks"] >= 200 else "fresh bank: AGC attacking", t["launches"], len(t["workgroups_sampled"])))
+    print("   workgroup span (first wave in .. last wave out) %.0f; wave lifetime by duty:" % t["workgroup_span_cycles"],
+          "  ".join("rel %d %.0f" % (r, v) for r, v in enumerate(t["wave_lifetime_cycles_by_duty"])))
+    print("   %-52s" % "phase" + "".join("%9s" % ("rel %d" % r) for r in range(4)) + "%9s" % "mean")
+    tot = np.zeros(4); park = np.zeros(4)
+    for ph in t["phases"]:
+        v = np.array(ph["cycles_by_duty"]); tot += v
+        if ph["kind"] == "b":
+            park += v
+        print("   %-52s" % (("  " if ph["kind"] in "bd" else "") + ph["name"]) + "".join("%9.0f" % x for x in v) + "%9.0f" % v.mean())
+    print("   %-52s" % "SUM" + "".join("%9.0f" % x for x in tot) + "%9.0f" % tot.mean())
+    print("   %-52s" % "parked at the six barriers" + "".join("%9.0f" % x for x in park) + "%9.0f  (%.1f %% of the lifetime)" % (park.mean(), 100 * park.mean() / tot.mean()))
+
+
+def mw(warm=None, n_ch=65536):
+    """The four-wave workgroup form (asdr_update_kernel_mw) inside a full C2 launch (or, n_ch = 32 with ASDR_MW_MIN_WAVES=1, as a LONE workgroup):
+    clock64() at the 16 phase boundaries and on either side of the six workgroup barriers.  Prints, per duty (rel 0 = blanker / phase chains,
+    1 and 2 = audio cascades, 3 = AGC chain), shader-clock cycles per phase, the cycles parked at each barrier, and the sums.
+    TIMELINE_JSON=<path>: the tables as JSON as well (tools/latency_model.py)."""
+    n_ch = int(n_ch)
+    out = []
+    for w in ([int(warm)] if warm is not None else [300, 8]):
+        raw = mw_measure(w, n_ch)
         if os.environ.get("TIMELINE_RAW"):
-            # per workgroup and wave (last launch): duty, SIMD, wave slot, and the cycles of a few phases
             hw = raw[-1, :, :, 29]
-            for wi, wg in enumerate((0, 683, 1365, 2047)):
-                for w in range(4):
-                    t = raw[-1, wi, w]
-                    print("   wg %4d wave %d rel %d simd %d slot %d cu %2d | start %7d  envelopes %6d  IF %6d  mixer %6d  FIR %6d  TL4 %7d TL5 %7d TL8 %7d TL9 %7d" % (
-                        wg, w, (w - wg) & 3, (hw[wi, w] >> 4) & 3, hw[wi, w] & 15, (hw[wi, w] >> 8) & 15, t[0] - raw[-1, wi, :, 0].min(), t[2] - t[1], t[5] - t[4], t[7] - t[6], t[9] - t[8],
-                        t[4] - raw[-1, wi, :, 0].min(), t[5] - raw[-1, wi, :, 0].min(), t[8] - raw[-1, wi, :, 0].min(), t[9] - raw[-1, wi, :, 0].min()))
-        tl = raw[:, :, :, MW_SEQ]            # [launch][wg][wave][28]
-        d = np.diff(tl, axis=3).astype(np.float64)      # 27 intervals
-        # fold "(tap row)" and "(status)" style slivers: keep all 27, name by MW_NAMES (25) + two joins
-        names = MW_NAMES[:]
-        # intervals: 0-1,1-2,2-17,17-18,18-19,19-20,20-3,3-4,4-5,5-6,6-7,7-8,8-9,9-10,10-21,21-22,22-23,23-24,24-11,11-12,12-25,25-26,26-27,27-28,28-13,13-14,14-15
-        names = ["prologue + loads issued", "NB: envelopes, ring store", "NB: publish chain inputs",
-                 "  barrier 1 (chains may start): parked", "  NB chain duty (rel 0 works, others pass)", "  barrier 2 (chains done): parked",
-                 "NB: threshold test", "NB: mask / output rows", "IF pipeline (+ ring prefetch issue)", "mixer phase / uniform test",
-                 "mixer multiply, AF / AGC state loads", "Hilbert: stage history", "Hilbert: FIR", "sideband combine (+ delayed I wait)", "AGC table request",
-                 "  barrier 3 (audio rows ready): parked", "  audio cascade duty (rel 1, 2 work)", "  barrier 4 (cascades done): parked",
-                 "(to TL11)", "AGC: |x|, block maximum, quiet test", "AGC: publish",
-                 "  barrier 5 (AGC inputs): parked", "  AGC chain duty (rel 3 works)", "  barrier 6 (AGC chains done): parked",
-                 "(to TL13)", "AGC: apply", "output + status"]
-        rel = np.array([[(w - wg) & 3 for w in range(4)] for wg in (0, 683, 1365, 2047)])   # duty of wave w of workgroup wg
-        print("== asdr_update_kernel_mw, 65536 channels, %d warm-up blocks (%s): shader-clock cycles, medians over %d launches x 4 workgroups" %
-              (warm, "steady bank: AGC quiet path" if warm >= 200 else "fresh bank: AGC attacking", d.shape[0]))
-        life = (tl[..., -1] - tl[..., 0]).astype(np.float64)
-        wg_span = (tl[..., -1].max(axis=2) - tl[..., 0].min(axis=2)).astype(np.float64)
-        print("   workgroup span (first wave in .. last wave out) %.0f; wave lifetime by duty:" % np.median(wg_span),
-              "  ".join("rel %d %.0f" % (r, np.median(life[:, rel == r])) for r in range(4)))
-        hdr = "   %-46s" % "phase" + "".join("%9s" % ("rel %d" % r) for r in range(4)) + "%9s" % "mean"
-        print(hdr)
-        tot_park = np.zeros(4); tot = np.zeros(4)
-        for k, nm in enumerate(names):
-            v = [np.median(d[:, rel == r, k]) for r in range(4)]
-            tot += v
-            if "parked" in nm:
-                tot_park += v
-            print("   %-46s" % nm + "".join("%9.0f" % x for x in v) + "%9.0f" % np.mean(v))
-        print("   %-46s" % "SUM" + "".join("%9.0f" % x for x in tot) + "%9.0f" % tot.mean())
-        print("   %-46s" % "parked at the six barriers" + "".join("%9.0f" % x for x in tot_park) + "%9.0f  (%.1f %% of the lifetime)" % (tot_park.mean(), 100 * tot_park.mean() / tot.mean()))
+            for wi in range(raw.shape[1]):
+                t0 = raw[-1, wi, :, 0].min()
+                for wv in range(4):
+                    t = raw[-1, wi, wv]
+                    print("   wg %4d wave %d rel %d simd %d slot %d cu %2d | start %7d  envelopes %6d  IF %6d  mixer %6d  FIR %6d" % (
+                        MW_WGS[wi], wv, (wv - MW_WGS[wi]) & 3, (hw[wi, wv] >> 4) & 3, hw[wi, wv] & 15, (hw[wi, wv] >> 8) & 15, t[0] - t0, t[2] - t[1], t[5] - t[4], t[7] - t[6], t[9] - t[8]))
+        t = mw_table(raw, n_ch, w)
+        mw_print(t)
+        out.append(t)
+    if os.environ.get("TIMELINE_JSON"):
+        import json
+        json.dump(out, open(os.environ["TIMELINE_JSON"], "w"), indent=1)
+    return out
 
 
 def stream(T=256, n_ch=512):
@@ -196,7 +216,7 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["build"]:
         build()
     elif sys.argv[1:2] == ["mw"]:
-        mw(*sys.argv[2:3])
+        mw(*sys.argv[2:4])
     elif sys.argv[1:2] == ["stream"]:
         stream(*[int(x) for x in sys.argv[2:]])
     else:
