@@ -66,6 +66,21 @@ EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels",
 _lib = None
 
 
+def host_autopin(on=-1):
+    """Switch the auto-pinning of recurring pageable caller buffers (include/asdr.h) on / off for the process; returns the previous setting."""
+    return int(load_library().asdr_host_autopin(int(on)))
+
+
+def host_autopin_clear():
+    load_library().asdr_host_autopin_clear()
+
+
+def host_autopin_info():
+    out = (C.c_long * 4)()
+    load_library().asdr_host_autopin_info(out)
+    return {"registered_now": int(out[0]), "registrations": int(out[1]), "released": int(out[2]), "refused": int(out[3])}
+
+
 def kernels_launched(reset=False):
     """{kernel name: launches since the last reset} for the kernels that were launched at all (process-wide census, include/asdr.h)."""
     L = load_library()
@@ -94,6 +109,9 @@ def load_library(path=None):
     L.asdr_destroy.argtypes = [vp]; L.asdr_destroy.restype = None
     L.asdr_last_error.restype = C.c_char_p
     L.asdr_version.restype = C.c_char_p
+    L.asdr_host_autopin.argtypes = [_i]; L.asdr_host_autopin.restype = _i
+    L.asdr_host_autopin_clear.restype = None
+    L.asdr_host_autopin_info.argtypes = [C.POINTER(C.c_long)]; L.asdr_host_autopin_info.restype = _i
     L.asdr_kernels_count.restype = _i
     L.asdr_kernels_name.argtypes = [_i]; L.asdr_kernels_name.restype = C.c_char_p
     L.asdr_kernels_launches.argtypes = [_i]; L.asdr_kernels_launches.restype = C.c_ulonglong

@@ -59,6 +59,7 @@ extern "C" int asdr_stream_capacity(int device, int *compute_units);
 extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int restore, hipStream_t stream);
 extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream);
 extern "C" int asdr_kernels_upload_tables(void);
+namespace { void autopin_batch_created(); void autopin_batch_gone(); }   // (the auto-pinned caller ranges live as long as the process has a device batch: host path, below)
 extern "C" int asdr_launch_update(const UpdateArgs *a, int variant, int uniform, hipStream_t stream);
 extern "C" int asdr_launch_sam_role(const UpdateArgs *a, int variant, int uniform, int role, hipStream_t stream);
 extern "C" int asdr_launch_als_role(const UpdateArgs *a, int role, hipStream_t stream);
@@ -898,6 +899,7 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
     if (device < 0 || device >= ndev) { delete b; fail("bad device ordinal"); return nullptr; }
     if (device >= 16) { delete b; fail("device ordinal >= 16: the per-device stream pool of this library has 16 entries"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { delete b; fail("hipSetDevice failed"); return nullptr; }
+    autopin_batch_created();   // (paired with asdr_destroy, which every later failure path goes through)
     bool ok = true;
     auto alloc = [&](void **p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
     alloc((void **)&b->d_params, rows * sizeof(ChanParams));
@@ -1026,6 +1028,7 @@ void asdr_destroy(asdr_batch_t *b) {
   if (b->device == ASDR_NO_DEVICE) { delete b; return; }
   hipSetDevice(b->device);
   hipDeviceSynchronize();
+  autopin_batch_gone();   // (the last device batch of the process takes the auto-pinned caller ranges with it)
   void *ptrs[] = {b->d_params, b->d_small, b->d_nb_hist, b->d_nb_mask, b->d_hil_q, b->d_hil_i, b->d_als_x, b->d_als_w,
                   b->d_agc_tab, b->d_taps, b->d_sched, b->d_reset, b->d_lo, b->d_io[0], b->d_io[1], b->d_io[2], b->d_capture,
                   b->d_xch_a, b->d_xch_b, b->d_stream_prog, b->d_lo_ring, b->d_xch_sam, b->d_audio_prev, b->d_stream_snap, b->d_als_stage, b->d_xch_sam_chunk};
@@ -1653,6 +1656,88 @@ bool is_pinned_host(const void *p, size_t bytes) {
   return bytes <= 1 || pinned_at(static_cast<const char *>(p) + bytes - 1);
 }
 
+// Auto-pinning of recurring caller buffers (round 6).  The reference's boundary hands ordinary memory (AudioSDR.cpp:46-47,
+// 158-167) and an application that reuses its buffers -- the usual case -- paid the staging copies in every call (1.4-2.5 ms per C2 call
+// against 0.94 pinned).  A process-wide cache remembers the (address, length) of pageable ranges it has been handed; the SECOND time a range
+// shows up it is registered in place (hipHostRegister, portable) and from then on hipPointerGetAttributes reports it pinned: the call
+// DMA-copies straight from / into it.  One-shot buffers keep the staged path (and cost one table entry).  Bounded: at most
+// ASDR_AUTOPIN_ENTRIES ranges / ASDR_AUTOPIN_BYTES bytes are kept registered, least recently used first out; everything is unregistered
+// when the process' last batch is destroyed and by asdr_host_autopin_clear().
+// OPT-IN (asdr_host_autopin(1) / ASDR_HOST_AUTOPIN=1), because of what was measured when it was on by default: a range that the application
+// UNMAPS while the cache holds its registration (free() of a large malloc block is a munmap) and gets back at the same address is still
+// reported page-locked by hipPointerGetAttributes, and the DMA through the stale registration ABORTS the process (ROCm 7.2, MI355X: the
+// first form of tests/test_gpu_host_path.py test_a_freed_and_reallocated_buffer... did exactly that).  Nothing in user space tells the
+// library that a range was unmapped, so pinning memory the caller may free cannot be made safe behind its back: an application that turns
+// this on promises to call asdr_host_autopin_clear() (or destroy its batches) before it frees buffers it has passed in.  By default
+// pageable buffers take the staged path in every call, freed-and-reallocated ones included (that test now holds THAT down).
+#ifndef ASDR_AUTOPIN_ENTRIES
+#define ASDR_AUTOPIN_ENTRIES 12
+#endif
+#ifndef ASDR_AUTOPIN_BYTES
+#define ASDR_AUTOPIN_BYTES ((size_t)2 << 30)
+#endif
+struct AutoPin {
+  struct Ent { const void *p; size_t bytes; unsigned long last_use; int seen; bool registered; };
+  std::mutex m;
+  std::vector<Ent> ents;
+  unsigned long tick = 0;
+  int enabled = -1;          // -1: read ASDR_HOST_AUTOPIN once (default OFF: see the hazard above)
+  long stat_registered = 0, stat_evicted = 0, stat_failed = 0;
+  int live_batches = 0;
+  bool on() { if (enabled < 0) { const char *e = getenv("ASDR_HOST_AUTOPIN"); enabled = (e && atoi(e) != 0) ? 1 : 0; } return enabled != 0; }
+  void drop(size_t i) {
+    if (ents[i].registered) { if (hipHostUnregister(const_cast<void *>(ents[i].p)) != hipSuccess) (void)hipGetLastError(); stat_evicted++; }
+    ents.erase(ents.begin() + (long)i);
+  }
+  void clear() { std::lock_guard<std::mutex> lk(m); while (!ents.empty()) drop(ents.size() - 1); }
+  // a pageable range was handed to asdr_update: note it; true = it has just been registered (the caller re-reads its attributes)
+  bool sighting(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!on()) return false;
+    tick++;
+    for (size_t i = 0; i < ents.size(); i++) {
+      Ent &e = ents[i];
+      if (e.p == p && e.bytes == bytes) {
+        e.last_use = tick; e.seen++;
+        if (e.registered) return false;                      // (registered by us and still reported pageable: the registration is gone; stay on the staged path)
+        if (e.seen < 2) return false;
+        size_t total = bytes; int n_reg = 1;
+        for (const Ent &o : ents) if (o.registered) { total += o.bytes; n_reg++; }
+        while ((total > ASDR_AUTOPIN_BYTES || n_reg > ASDR_AUTOPIN_ENTRIES) && n_reg > 1) {   // make room: least recently used registered range out
+          size_t lru = ents.size();
+          for (size_t k = 0; k < ents.size(); k++) if (ents[k].registered && (lru == ents.size() || ents[k].last_use < ents[lru].last_use)) lru = k;
+          if (lru == ents.size()) break;
+          total -= ents[lru].bytes; n_reg--;
+          drop(lru);
+        }
+        for (size_t k = 0; k < ents.size(); k++) if (ents[k].p == p && ents[k].bytes == bytes) {
+          if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); stat_failed++; ents[k].seen = -(1 << 20); return false; }   // (never again for this range)
+          ents[k].registered = true; stat_registered++;
+          return true;
+        }
+        return false;
+      }
+      // an entry that overlaps this range without being it: the application's buffers have moved -- forget the old one
+      const char *a0 = static_cast<const char *>(e.p), *a1 = a0 + e.bytes, *b0 = static_cast<const char *>(p), *b1 = b0 + bytes;
+      if (a0 < b1 && b0 < a1) { drop(i); i--; }
+    }
+    if (ents.size() >= 4 * ASDR_AUTOPIN_ENTRIES) {   // the table itself is bounded: the oldest unregistered sighting goes
+      size_t old = ents.size();
+      for (size_t k = 0; k < ents.size(); k++) if (!ents[k].registered && (old == ents.size() || ents[k].last_use < ents[old].last_use)) old = k;
+      if (old != ents.size()) drop(old);
+    }
+    ents.push_back(Ent{p, bytes, tick, 1, false});
+    return false;
+  }
+};
+AutoPin g_autopin;
+void autopin_batch_created() { std::lock_guard<std::mutex> lk(g_autopin.m); g_autopin.live_batches++; }
+void autopin_batch_gone() {
+  bool last;
+  { std::lock_guard<std::mutex> lk(g_autopin.m); last = (--g_autopin.live_batches <= 0); if (last) g_autopin.live_batches = 0; }
+  if (last) g_autopin.clear();
+}
+
 int host_parts(const asdr_batch *b, int n_blocks) {
   if (b->host_chunks_forced > 0) return std::min(b->host_chunks_forced, std::max(1, b->n / 8));
   const size_t row_bytes = (size_t)b->n * n_blocks * ASDR_N * sizeof(int16_t);   // one of I, Q, out
@@ -1704,7 +1789,12 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
     b->io_cap = count;
   }
   const size_t row_bytes_all = count * sizeof(int16_t);
-  const bool pinned = is_pinned_host(I, row_bytes_all) && is_pinned_host(Q, row_bytes_all) && is_pinned_host(out, row_bytes_all);
+  bool pin_i = is_pinned_host(I, row_bytes_all), pin_q = is_pinned_host(Q, row_bytes_all), pin_o = is_pinned_host(out, row_bytes_all);
+  // pageable ranges that recur are registered in place the second time they are seen (AutoPin above)
+  if (!pin_i && g_autopin.sighting(I, row_bytes_all)) pin_i = is_pinned_host(I, row_bytes_all);
+  if (!pin_q && g_autopin.sighting(Q, row_bytes_all)) pin_q = is_pinned_host(Q, row_bytes_all);
+  if (!pin_o && g_autopin.sighting(out, row_bytes_all)) pin_o = is_pinned_host(out, row_bytes_all);
+  const bool pinned = pin_i && pin_q && pin_o;
   if (!pinned && count > b->h_io_cap) {   // the pinned staging area, one row set per call
     b->h_io_cap = 0;
     for (int i = 0; i < 3; i++) {
@@ -1899,6 +1989,15 @@ int asdr_host_register(void *p, size_t bytes) {
 int asdr_host_unregister(void *p) {
   if (!p) return fail("asdr_host_unregister: null buffer");
   HIPCHK(hipHostUnregister(p));
+  return 0;
+}
+int asdr_host_autopin(int on) { std::lock_guard<std::mutex> lk(g_autopin.m); const int was = g_autopin.on() ? 1 : 0; if (on >= 0) g_autopin.enabled = on ? 1 : 0; return was; }
+void asdr_host_autopin_clear(void) { g_autopin.clear(); }
+int asdr_host_autopin_info(long out[4]) {
+  if (!out) return fail("null output");
+  std::lock_guard<std::mutex> lk(g_autopin.m);
+  long n_reg = 0; for (const AutoPin::Ent &e : g_autopin.ents) n_reg += e.registered ? 1 : 0;
+  out[0] = n_reg; out[1] = g_autopin.stat_registered; out[2] = g_autopin.stat_evicted; out[3] = g_autopin.stat_failed;
   return 0;
 }
 int asdr_order_before(asdr_batch_t *b, void *stream_) {   // everything enqueued on `stream` from now on runs after the batch's calls so far

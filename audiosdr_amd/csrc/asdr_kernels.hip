@@ -2638,8 +2638,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             for (int u = 0; u < 8; ++u) {
               const float av = x[u];
               const bool att = av > old_abs;
-              if (__any(att)) {   // rare: a sample above the envelope in some channel of the wave
-                asm volatile("");   // keeps this a branch (the compiler would otherwise flatten it into selects for every sample)
+#ifndef ASDR_AGC_ATTACK_BRANCHFREE
+#define ASDR_AGC_ATTACK_BRANCHFREE 1
+#endif
+              // The four-wave form's duty wave runs 32 channels' chains at once: in an attacking chunk some channel attacks at almost every sample, so the
+              // per-sample branch (right for the eight channels of a wave of its own: round 4) only adds its test -- straight-line selects there (round 6).
+              if ((MW && ASDR_AGC_ATTACK_BRANCHFREE) || __any(att)) {   // (one wave per workgroup: rare -- a sample above the envelope in some channel of the wave)
+                if (!(MW && ASDR_AGC_ATTACK_BRANCHFREE)) asm volatile("");   // keeps this a branch (the compiler would otherwise flatten it into selects for every sample)
                 const float pa = al_a * old_abs, pb = be_a * av;   // (:418)
                 const float v_new = pa + pb;
                 old_abs = att ? v_new : old_abs;

@@ -427,10 +427,12 @@ def host_path(np, local_rank, n_ch, calls=30):
         for b in range(N_INPUT_BLOCKS):
             bufs[2 * b][:] = np.tile(bI[:, b:b + 1], (reps, 1, 1))[:n_ch]
             bufs[2 * b + 1][:] = np.tile(bQ[:, b:b + 1], (reps, 1, 1))[:n_ch]
-    for name, bufs, chunks, n_calls in (("pinned", pin, 0, calls), ("pageable", pag, 0, max(6, calls // 3)), ("pinned_no_overlap", pin, 1, max(6, calls // 3))):
+    for name, bufs, chunks, n_calls in (("pinned", pin, 0, calls), ("pageable", pag, 0, max(6, calls // 3)), ("pageable_autopin", pag, 0, max(6, calls // 3)),
+                                        ("pinned_no_overlap", pin, 1, max(6, calls // 3))):
         batch = A.AudioSDRBatch(n_ch, device=local_rank)
         configure_c2(batch)
         batch.set_host_chunks(chunks)
+        A.binding.host_autopin(1 if name == "pageable_autopin" else 0)   # (opt-in: recurring pageable ranges are registered in place at their second call)
         for i in range(4):
             batch.update_into(bufs[2 * (i % N_INPUT_BLOCKS)], bufs[2 * (i % N_INPUT_BLOCKS) + 1], bufs[-1])
         t0 = time.perf_counter()
@@ -441,16 +443,18 @@ def host_path(np, local_rank, n_ch, calls=30):
         res[name] = {"ms_per_call": round(dt * 1e3, 4), "Msamples_per_s": round(n_ch * BLOCK / dt / 1e6, 1),
                      "pcie_GBps": round(768.0 * n_ch / dt / 1e9, 2), "chunks": info["chunks"], "calls_timed": n_calls}
         batch.close()
+        A.binding.host_autopin_clear(); A.binding.host_autopin(0)
     for a in pin:
         A.host_free(a)
     p = res["pinned"]
     return {"value": p["Msamples_per_s"], "unit": "Msamples/s", "ms_per_call": p["ms_per_call"], "pcie_GBps": p["pcie_GBps"],
             "frac_of_63GBps": round(p["pcie_GBps"] / PCIE_REF_GBS, 3), "chunks": p["chunks"],
-            "bytes_per_channel_block": 768, "pageable": res["pageable"], "no_overlap": res["pinned_no_overlap"],
+            "bytes_per_channel_block": 768, "pageable": res["pageable"], "pageable_autopin": res["pageable_autopin"], "no_overlap": res["pinned_no_overlap"],
             "method": "asdr_update() on %d channels x 1 block per call, caller buffers in page-locked host memory (asdr_host_alloc), "
                       "host clock around %d synchronous calls after 4 untimed ones; pcie_GBps = 768 B x channels / time (both directions "
                       "summed: 512 in + 256 out, which PCIe moves concurrently); `pageable`: ordinary numpy buffers staged by the "
-                      "library's copy threads; `no_overlap`: asdr_set_host_chunks(1)" % (n_ch, calls)}
+                      "library's copy threads (the default for memory the caller did not pin); `pageable_autopin`: the same buffers with asdr_host_autopin(1) "
+                      "-- registered in place at their second call, opt-in because the caller must then not free them behind the library's back; `no_overlap`: asdr_set_host_chunks(1)" % (n_ch, calls)}
 
 
 def main_single_process(args, cfg, settle_min, warm_req):

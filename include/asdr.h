@@ -96,13 +96,27 @@ int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *ou
  *   asdr_host_alloc / asdr_host_free          page-locked host memory (hipHostMalloc, portable across devices)
  *   asdr_host_register / asdr_host_unregister pin memory the caller already owns, in place (hipHostRegister); unregister before freeing it
  *   asdr_set_host_chunks(b, k)                k > 0 forces k chunks (1 = no overlap: the round-3 behaviour, for comparison), 0 = from the call's size
- *   asdr_host_path_info(b, out)               out[0] = chunks of the last asdr_update, out[1] = 1 if it used the caller's buffers directly */
+ *   asdr_host_path_info(b, out)               out[0] = chunks of the last asdr_update, out[1] = 1 if it used the caller's buffers directly
+ * Pageable buffers that RECUR can be pinned for the caller (round 6, OPT-IN): with asdr_host_autopin(1) the second time asdr_update is
+ * handed the same (address, length) of ordinary memory it registers the range in place, and every later call DMA-copies straight from /
+ * into it -- an application that reuses its buffers, as the reference's audio library does, pays the staging copies once (C2: 1.4 ->
+ * 0.94 ms per call).  At most 12 ranges / 2 GiB are kept registered (least recently used first out); all of them are released when the
+ * process' last batch is destroyed.  THE CONTRACT that makes it opt-in: a buffer the cache holds must not be freed (unmapped) behind the
+ * library's back -- a DMA through a registration whose range was unmapped and mapped again aborts the process (measured), and nothing
+ * tells a library that its caller unmapped a range.  Call asdr_host_autopin_clear() before freeing buffers you have passed in.
+ *   asdr_host_autopin(on)                     1 / 0 switches the behaviour on / off for the process (default off; environment ASDR_HOST_AUTOPIN=1: on),
+ *                                             -1 only asks; returns the previous setting
+ *   asdr_host_autopin_clear()                 unregister everything the cache holds
+ *   asdr_host_autopin_info(out)               out[0] = ranges registered now, out[1] = registrations so far, out[2] = released, out[3] = refused by the driver */
 void *asdr_host_alloc(size_t bytes);
 void asdr_host_free(void *p);
 int asdr_host_register(void *p, size_t bytes);
 int asdr_host_unregister(void *p);
 int asdr_set_host_chunks(asdr_batch_t *b, int chunks);
 int asdr_host_path_info(asdr_batch_t *b, int out[2]);
+int asdr_host_autopin(int on);
+void asdr_host_autopin_clear(void);
+int asdr_host_autopin_info(long out[4]);
 /* Test hooks (host logic only; they work on a control-plane-only batch after asdr_control_plane_flush): the chunk plan of the overlapped
  * host path for `chunks` chunks -- bound[0..chunks] channel boundaries, need_in[p] = the last input chunk kernel part p waits for,
  * last_part[j] = the part after which output chunk j is complete --, the schedule slots (first, count pairs, up to 16; returns their

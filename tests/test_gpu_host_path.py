@@ -2,6 +2,8 @@
 AudioSDR.cpp:46-47, 158-167) is overlapped in channel-range chunks -- H2D(k + 1) || kernels(k) || D2H(k - 1).  Chunking is by
 channels, so it must equal the device-pointer path bit for bit: for ragged chunk sizes, multi-block calls, settings mixes whose
 schedule is not in channel order (every kernel kind + remainders), pinned and pageable caller buffers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -58,6 +60,7 @@ def test_chunked_host_path_equals_the_device_path(gpu, kind, n, chunks):
         _mix(b, n, kind)
         b.set_host_chunks(chunks)
         pos = 0
+        was = gpu.binding.host_autopin(0 if not pinned else -1)   # (the staged path is what the pageable leg is about: no auto-pinning of temporaries that happen to recur)
         for k, T in enumerate(calls):
             if pinned:
                 hI, hQ, hO = (gpu.host_alloc((n, T, 128)) for _ in range(3))
@@ -78,6 +81,104 @@ def test_chunked_host_path_equals_the_device_path(gpu, kind, n, chunks):
         for key in st:
             assert st[key].tobytes() == want_st[key].tobytes(), key
         b.close()
+        gpu.binding.host_autopin(was)
+
+
+def _libc_mmap():
+    import ctypes as C
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p; libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    libc.munmap.restype = C.c_int; libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+    return libc
+
+
+def test_recurring_pageable_buffers_are_pinned_from_the_second_call(gpu):
+    """Ordinary (pageable) caller buffers that come back -- the reference's audio library reuses its blocks -- are registered in place the second
+    time asdr_update sees them and DMA-copied from then on (include/asdr.h "Pageable buffers that RECUR"); a one-shot buffer stays on the staged
+    path; asdr_host_autopin(0) switches it off; the cache is bounded and is emptied with the process' last batch."""
+    from audiosdr_amd.synth import make_iq
+    n, T = 2048, 2
+    I, Q = make_iq(n, 3 * T, fc=6290.0, A=0.25, impulse_every=900)
+    want, _ = _device_reference(gpu, n, "usb", I, Q, (T, T, T))
+    gpu.binding.host_autopin_clear()
+    gpu.binding.host_autopin(1)
+    base = gpu.binding.host_autopin_info()
+    b = gpu.AudioSDRBatch(n)
+    _mix(b, n, "usb")
+    hI, hQ, hO = (np.zeros((n, T, 128), np.int16) for _ in range(3))   # the application's own buffers, reused call after call
+    for k in range(3):
+        hI[:] = I[:, k * T:(k + 1) * T]; hQ[:] = Q[:, k * T:(k + 1) * T]; hO[:] = 0x1111
+        b.update_into(hI, hQ, hO)
+        assert b.host_path_info()["pinned"] == (k >= 1), "call %d" % k
+        assert np.array_equal(hO, want[k]), "call %d: %d samples differ" % (k, int((hO != want[k]).sum()))
+    info = gpu.binding.host_autopin_info()
+    assert info["registered_now"] == 3 and info["registrations"] - base["registrations"] == 3 and info["refused"] == base["refused"], info
+    # many other recurring ranges: the cache stays bounded (12 ranges), the oldest go
+    small = gpu.AudioSDRBatch(64)
+    bufs = [[np.zeros((64, 1, 128), np.int16) for _ in range(3)] for _ in range(8)]
+    for rep in range(2):
+        for tri in bufs:
+            small.update_into(*tri)
+    assert gpu.binding.host_autopin_info()["registered_now"] <= 12
+    small.close()
+    # off: a recurring buffer stays on the staged path
+    gpu.binding.host_autopin(0)
+    x = [np.zeros((n, T, 128), np.int16) for _ in range(3)]
+    for k in range(3):
+        b.update_into(*x)
+        assert not b.host_path_info()["pinned"]
+    gpu.binding.host_autopin(1)
+    b.close()
+    assert gpu.binding.host_autopin_info()["registered_now"] == 0   # (the last batch of the process took the registrations with it)
+    gpu.binding.host_autopin(0)                                      # the default
+
+
+def test_a_freed_and_reallocated_buffer_is_read_through_its_new_pages(gpu):
+    """The hazard of pinning for the caller: the application frees a buffer and gets the same address back for new data.  A range is mapped at a
+    fixed address, used twice, unmapped, mapped AGAIN at the same address with other samples, used again: the call must see the new samples and
+    produce the device path's result for them.  With the library's defaults no caller range is ever registered behind the caller's back
+    (asdr_host_autopin is opt-in BECAUSE this sequence, run with it on, aborted the process in the DMA through the stale registration), so
+    the recurring range stays on the staged path -- asserted -- and the third call is exact."""
+    import ctypes as C
+    import mmap
+    from audiosdr_amd.synth import make_iq
+    libc = _libc_mmap()
+    n, T = 4096, 2
+    nbytes = n * T * 128 * 2
+    I1, Q1 = make_iq(n, 2 * T, fc=6290.0, A=0.25)
+    I2, Q2 = make_iq(n, T, fc=6100.0, A=0.35, m=0.5)
+    want1, _ = _device_reference(gpu, n, "usb", I1, Q1, (T, T))
+    gpu.binding.host_autopin_clear()
+    assert gpu.binding.host_autopin(-1) == 0 or os.environ.get("ASDR_HOST_AUTOPIN"), "auto-pinning must be off unless the application asks for it"
+    gpu.binding.host_autopin(0)
+    PROT_RW, MAP_PRIVATE_ANON, MAP_FIXED = 3, 0x22, 0x10
+    size = 3 * nbytes
+    addr = libc.mmap(None, size, PROT_RW, MAP_PRIVATE_ANON, -1, 0)
+    assert addr not in (None, C.c_void_p(-1).value)
+    def views(a):
+        return [np.ctypeslib.as_array((C.c_int16 * (nbytes // 2)).from_address(a + i * nbytes)).reshape(n, T, 128) for i in range(3)]
+    hI, hQ, hO = views(addr)
+    b = gpu.AudioSDRBatch(n)
+    _mix(b, n, "usb")
+    for k in range(2):
+        hI[:] = I1[:, k * T:(k + 1) * T]; hQ[:] = Q1[:, k * T:(k + 1) * T]
+        b.update_into(hI, hQ, hO)
+        assert np.array_equal(hO, want1[k])
+    assert not b.host_path_info()["pinned"] and gpu.binding.host_autopin_info()["registered_now"] == 0   # nothing was registered behind the caller's back
+    del hI, hQ, hO
+    assert libc.munmap(addr, size) == 0                     # the application frees its buffers ...
+    addr2 = libc.mmap(addr, size, PROT_RW, MAP_PRIVATE_ANON | MAP_FIXED, -1, 0)   # ... and gets the same address back
+    assert addr2 == addr
+    hI, hQ, hO = views(addr2)
+    hI[:] = I2; hQ[:] = Q2; hO[:] = 0x2222
+    # the reference result: the same state (two calls of the first signal), then the new samples, all through device rows
+    want2, _ = _device_reference(gpu, n, "usb", np.concatenate([I1, I2], axis=1), np.concatenate([Q1, Q2], axis=1), (T, T, T))
+    b.update_into(hI, hQ, hO)
+    assert np.array_equal(hO, want2[2]), "%d samples differ: the call read or wrote pages of the old mapping" % int((hO != want2[2]).sum())
+    b.close()
+    gpu.binding.host_autopin_clear()
+    del hI, hQ, hO
+    libc.munmap(addr2, size)
 
 
 def test_default_chunking_of_a_large_call_and_registered_memory(gpu):
