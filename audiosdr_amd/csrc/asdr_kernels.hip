@@ -743,8 +743,19 @@ __device__ __forceinline__ const T *row_ptr(const T *base, uint32_t byte_off) {
 // CH = samples per loop trip (4 from LDS; 16 in the PLL kernel, whose accessor requests the next trip's samples from HBM first).
 // PF: the accessor reads HBM (the stand-alone PLL kernel): the NEXT trip's samples are requested before this trip's arithmetic, so
 // that the chain never waits for memory.
+#ifndef ASDR_PLL_CONSTS_IN_VGPRS
+#define ASDR_PLL_CONSTS_IN_VGPRS 1   /* the stand-alone PLL kernel keeps the loop's constants in VGPRs (a quarter of its vector instructions read the scalar file otherwise: tools/ubench/issue_rate.hip) */
+#endif
 template <bool TWO_SUMS, int CH, bool PF = false, typename LD, typename ST>
-__device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K, const float *sine, float two_pi, LD ld, ST st) {
+__device__ __forceinline__ bool pll_loop(ChanSmall *Sc, const ChainConsts &K_, const float *sine, float two_pi, LD ld, ST st) {
+    // PF = the stand-alone PLL kernel (51 VGPRs, four homogeneous waves per SIMD: exactly the situation of the issue-rate micro-benchmark): its
+    // constants as VGPR operands.  The fused kernels (no register to spare) keep them scalar.
+    ChainConsts K = K_;
+    if constexpr (PF && ASDR_PLL_CONSTS_IN_VGPRS) {
+      asm("" : "+v"(K.pll_a1), "+v"(K.pll_b0), "+v"(K.pll_b1), "+v"(K.half_pi_f), "+v"(two_pi), "+v"(K.pll_alpha_freq), "+v"(K.pll_beta_freq), "+v"(K.pll_f_conv),
+               "+v"(K.pll_lock_lo), "+v"(K.pll_lock_hi));
+      asm("" : "+v"(K.sin_index_scale_d), "+v"(K.half_pi_d));
+    }
     float y_re = Sc->pll_y_re, y_im = Sc->pll_y_im, prev_filt = Sc->pll_prev_filt;
     float d0 = Sc->pll_d0, d1 = Sc->pll_d1, phase_est = Sc->pll_phase_est, pfreq = Sc->pll_freq;
     bool locked = false;

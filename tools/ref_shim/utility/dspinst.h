@@ -1,0 +1,2 @@
+// STAND-IN (empty): tools/ref_shim/README.md
+#pragma once
