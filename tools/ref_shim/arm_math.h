@@ -36,3 +36,13 @@ static inline void arm_biquad_cascade_df1_f32(const arm_biquad_casd_df1_inst_f32
     pIn = pDst;
   }
 }
+// The pre-processor's image detector calls CMSIS's 128-point complex FFT and squared magnitudes (AudioSDRpreProcessor.cpp:91-92): neither is in
+// the reference tree in source form, so the stand-in build has NONE -- the front check below runs the paths that do not reach them (skew
+// correction, I/Q swap) and aborts loudly if they are ever called.  (The FFT itself is pinned where it can be: tests/test_cmsis_object.py runs
+// the reference's own Cortex-M4 objects.)
+#include <stdio.h>
+#include <stdlib.h>
+typedef struct { uint16_t fftLen; const float32_t *pTwiddle; const uint16_t *pBitRevTable; uint16_t bitRevLength; } arm_cfft_instance_f32;
+static const arm_cfft_instance_f32 arm_cfft_sR_f32_len128 = {128, NULL, NULL, 0};
+static inline void arm_cfft_f32(const arm_cfft_instance_f32 *, float32_t *, uint8_t, uint8_t) { fprintf(stderr, "stand-in build: arm_cfft_f32 is not available\n"); abort(); }
+static inline void arm_cmplx_mag_squared_f32(float32_t *, float32_t *, uint32_t) { fprintf(stderr, "stand-in build: arm_cmplx_mag_squared_f32 is not available\n"); abort(); }

@@ -150,6 +150,69 @@ def fuzz(say, tmp, seeds, n_ch=6, n_blk=24):
     return tot
 
 
+FRONT_EXE = os.path.join(OUT_DIR, "ref_front_driver")
+
+
+def build_front():
+    subprocess.check_call(["g++", "-std=gnu++14", "-fpermissive", "-w", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "tools", "ref_shim"), "-I", REF,
+                           os.path.join(ROOT, "tools", "ref_shim", "ref_front_driver.cpp"), os.path.join(REF, "AudioIQgenerator.cpp"),
+                           os.path.join(REF, "AudioGrabberComplex256.cpp"), os.path.join(REF, "AudioSDRpreProcessor.cpp"), "-o", FRONT_EXE])
+
+
+def front(say, tmp):
+    """The blocks either side of the path against oracle/asdr_front_oracle.c: the IQ generator (three gain balances), the
+    grabber (grab after 1..5 blocks), the pre-processor's skew correction and I/Q swap (the image detector needs CMSIS's FFT: not in this build)."""
+    from audiosdr_amd.synth import make_iq
+    from oracle import asdr_oracle as ao
+    tot = [0, 0]
+    rng = np.random.default_rng(7)
+    nb = 14
+    t = np.arange(nb * 128)
+    x = np.trunc(32767 * (0.3 * np.cos(2 * np.pi * 1500.0 / 44100.0 * t) * (1 + 0.4 * np.sin(2 * np.pi * 300.0 / 44100.0 * t)) + rng.uniform(-0.01, 0.01, t.size))).astype(np.int16)
+    for bal in (0.0, 1.02, 0.95):
+        xf = os.path.join(tmp, "x.bin"); of = os.path.join(tmp, "o.bin")
+        x.tofile(xf)
+        subprocess.check_call([FRONT_EXE, "iqgen", repr(bal), xf, str(nb), of])
+        ref = np.fromfile(of, dtype=np.int16).reshape(nb, 2, 128)
+        g = ao.OracleIQgenerator()
+        if bal != 0.0:
+            g.setGainBalance(bal)
+        I, Q = g.update(x)
+        bad = int((I.reshape(nb, 128) != ref[:, 0]).sum() + (Q.reshape(nb, 128) != ref[:, 1]).sum())
+        say("front: AudioIQgenerator, gain balance %-5s %2d blocks: %6d samples, %d differ" % ("unset" if bal == 0.0 else bal, nb, 2 * nb * 128, bad))
+        tot[0] += 2 * nb * 128; tot[1] += bad
+    I, Q = make_iq(1, 8, fc=6290.0, A=0.3, m=0.3)
+    iqf = os.path.join(tmp, "iq.bin")
+    np.stack([I[0], Q[0]], axis=1).astype(np.int16).tofile(iqf)
+    for after in range(0, 6):
+        of = os.path.join(tmp, "g.bin")
+        p = subprocess.run([FRONT_EXE, "grab", iqf, "8", str(after), of], capture_output=True, text=True, check=True)
+        ref = np.fromfile(of, dtype=np.int16)
+        new_ref = [int(l.split()[1]) for l in p.stdout.splitlines()]
+        g = ao.OracleGrabber()
+        g.update(I[0, :after + 1], Q[0, :after + 1])
+        new = [g.newDataAvailable()]
+        got = g.grab()
+        new.append(g.newDataAvailable())
+        bad = int((got != ref).sum()) + (0 if new == new_ref else 1)
+        say("front: AudioGrabberComplex256, grab after block %d: 512 samples + 2 flags, %d differ" % (after, bad))
+        tot[0] += 514; tot[1] += bad
+    for corr in (-1, 0, 1):
+        for swap in (0, 1):
+            of = os.path.join(tmp, "p.bin")
+            p = subprocess.run([FRONT_EXE, "pre", str(corr), str(swap), iqf, "8", of], capture_output=True, text=True, check=True)
+            ref = np.fromfile(of, dtype=np.int16).reshape(8, 2, 128)
+            gr = {l.split()[0]: int(l.split()[1]) for l in p.stdout.splitlines()}
+            o = ao.OraclePreProcessor()
+            o.stopAutoI2SerrorDetection(); o.setI2SerrorCompensation(corr); o.swapIQ(swap)
+            oi, oq = o.update(I[0], Q[0])
+            bad = int((oi.reshape(8, 128) != ref[:, 0]).sum() + (oq.reshape(8, 128) != ref[:, 1]).sum())
+            bad += int(o.getI2SerrorCompensation() != gr["getI2SerrorCompensation"]) + int(o.getAutoI2SerrorDetectionStatus() != gr["getAutoI2SerrorDetectionStatus"])
+            say("front: AudioSDRpreProcessor, correction %+d swap %d, 8 blocks: 2048 samples + 2 getters, %d differ" % (corr, swap, bad))
+            tot[0] += 2050; tot[1] += bad
+    return tot
+
+
 def main():
     from cases import CASES
     from audiosdr_amd.synth import make_iq
@@ -179,6 +242,10 @@ def main():
         if not sys.argv[1:]:
             t = fuzz(say, tmp, range(1, 25))
             tot_s += t[0]; tot_bad += t[1]; tot_g += t[2]; tot_gbad += t[3]
+            build_front()
+            ft = front(say, tmp)
+            say("front blocks: %d values, %d differ" % (ft[0], ft[1]))
+            tot_bad += ft[1]
     say("TOTAL: %d cases%s, %d samples, %d differ; %d getter values, %d differ" % (len(names), "" if sys.argv[1:] else " + 24 fuzz seeds", tot_s, tot_bad, tot_g, tot_gbad))
     say("(samples whose value in front of the output stage's (int) lies outside int32 -- an adaptive ALS filter that diverges with the AGC off reaches 1e10 -- are undefined in C: the"
         " reference's target (ARM) saturates, and so do the oracle and the product; this x86 build returns INT_MIN, int16 0: they are compared with 0 and counted in brackets)")
