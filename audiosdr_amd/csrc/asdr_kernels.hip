@@ -209,7 +209,10 @@ __device__ __forceinline__ float cos_f32(const float *sine, float phase, float t
 // cos_f32 / sin_f32 of NP phases (the mixer, AudioSDR.h:519-520): all 2 NP table phases first, then the 2 NP gathers TOGETHER, then the
 // interpolations.  Written lookup by lookup the compiler waits for every gather right behind its issue -- one exposed L1 round
 // trip per lookup.  Same operations per value as sin_f32 / cos_f32 above.
-template <int NP>
+typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;
+// LDS_TAB: `sine` is the workgroup's LDS copy of the table (named as an LDS pointer: through the generic `sine ? sine : c_sine` the compiler emits FLAT
+// loads, which wait for the outstanding global loads as well -- see sincos_pll).
+template <int NP, bool LDS_TAB = false>
 __device__ __forceinline__ void sincos_batch(const float *sine, const float *ph, float *cc, float *sn, float two_pi, SinIndexK inv_two_pi, double half_pi_d) {
   uint32_t ipc[NP], ips[NP];
 #pragma unroll
@@ -218,11 +221,20 @@ __device__ __forceinline__ void sincos_batch(const float *sine, const float *ph,
     ips[j] = sin_index<false, true>(ph[j], two_pi, inv_two_pi);   // (mixer phases are in [0, twoPI]: never negative)
   }
   float c1[NP], c2[NP], s1[NP], s2[NP];
+  if constexpr (LDS_TAB) {
+    lds_cfloat_ptr tab = (lds_cfloat_ptr)sine;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      lds_cfloat_ptr tc = tab + (ipc[j] >> 8), ts = tab + (ips[j] >> 8);
+      c1[j] = tc[0]; c2[j] = tc[1]; s1[j] = ts[0]; s2[j] = ts[1];
+    }
+  } else {
   const float *tab = sine ? sine : c_sine;
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const float *tc = tab + (ipc[j] >> 8), *ts = tab + (ips[j] >> 8);
     c1[j] = tc[0]; c2[j] = tc[1]; s1[j] = ts[0]; s2[j] = ts[1];
+  }
   }
   __builtin_amdgcn_sched_barrier(0);   // (every request is out before the first value is waited for)
 #pragma unroll
@@ -235,7 +247,6 @@ __device__ __forceinline__ void sincos_batch(const float *sine, const float *ph,
 // named as an LDS pointer: through the generic `sine ? sine : c_sine` form of sin_lut the compiler emits FLAT loads, which count
 // against the vector-memory counter as well -- every lookup then waited for the PLL kernel's outstanding global sample loads too.
 // Both table phases first, both reads together, then the interpolations (same operations per value as sin_f32 / cos_f32).
-typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;
 __device__ __forceinline__ void sincos_pll(const float *sine, float phase, float &c, float &s, float two_pi, SinIndexK inv_two_pi, double half_pi_d) {
   const uint32_t ipc = sin_index<true>((float)((double)phase + half_pi_d), two_pi, inv_two_pi);
   const uint32_t ips = sin_index<true>(phase, two_pi, inv_two_pi);
@@ -1174,8 +1185,17 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const int wave_g = STREAM ? (int)blockIdx.x % a.stream_waves : (int)blockIdx.x * WAVES + wave;
   float *const lds = lds_wg + wave * 8 * STRIDE;            // this wave's 8 channel rows
   const int lane = threadIdx.x & 63, c8 = lane >> 3, s8_ = lane & 7;
-  float *const sine = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : nullptr;
+#ifndef ASDR_MW_SINE_LDS
+#define ASDR_MW_SINE_LDS 0   /* measured (round 6): divergent mixer phases -1.3 %, steady state +0.3 % (the fill and its barrier): off */
+#endif
+  // Round 6: the four-wave form keeps a copy of the sine table in LDS as well (1 KB per workgroup of 32 channels: 3 workgroups per CU still fit) --
+  // waves whose channels carry DIFFERENT mixer phases (receivers tuned at different times: 2 x 16 lookups per lane) read it through the LDS
+  // instead of gathering from the constant table through L1; one barrier at the top of the kernel.
+  constexpr bool MW_SINE = MW && (ASDR_MW_SINE_LDS != 0);
+  constexpr bool SINE_LDS = HAS_SAM || MW_SINE;
+  float *const sine = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : (MW_SINE ? lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 : nullptr);
   if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
+  if (MW_SINE) { for (int i = (int)threadIdx.x; i < ASDR_SINE_TABLE_LEN; i += 64 * WAVES) sine[i] = c_sine[i]; __syncthreads(); }
 
   int4 slot = make_int4(a.n_channels, 0, 0, 0);
   const bool mw_pad = MW && (wave_g * 8 >= a.n_sched);   // a wave behind the sub-range's last one: works on the dummy channel, stores nothing outside it
@@ -2125,7 +2145,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if constexpr (C16) { ph2[0] = lds[PH + lane_i]; ph2[1] = phase_step(ph2[0], minc); WAVE_SYNC(); }   // (every lane has read channel 0's phases: the pairs below overwrite them)
       else { const float2 p2 = *reinterpret_cast<const float2 *>(lds + PH + 2 * lane); ph2[0] = p2.x; ph2[1] = p2.y; }
       float c2[2], s2[2];
-      sincos_batch<2>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
+      sincos_batch<2, SINE_LDS>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
       if constexpr (C16) {   // 128 cos in the 64-float phase areas of channels 0 and 1, 128 sin in those of channels 2 and 3
         *reinterpret_cast<float2 *>(lds + (lane_i >> 5) * STRIDE + PH + ((2 * lane_i) & 63)) = make_float2(c2[0], c2[1]);
         *reinterpret_cast<float2 *>(lds + (2 + (lane_i >> 5)) * STRIDE + PH + ((2 * lane_i) & 63)) = make_float2(s2[0], s2[1]);
@@ -2160,7 +2180,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
               float ph[4];                                                                                                                    \
               const float2 e2 = *reinterpret_cast<const float2 *>(L + PH + ((kF + 32 * m) >> 1));                                             \
               ph[0] = e2.x; ph[1] = phase_step(e2.x, minc); ph[2] = e2.y; ph[3] = phase_step(e2.y, minc);                                     \
-              sincos_batch<4>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);                         \
+              sincos_batch<4, SINE_LDS>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);                         \
             }                                                                                                                                 \
             _Pragma("unroll")                                                                                                                 \
             for (int j = 0; j < 4; ++j) {                                                                                                     \
@@ -2199,7 +2219,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           float ph[4];
           load4(L + PH + kF + 32 * m, ph);
 #ifndef ASDR_MIX_SERIAL_LOOKUPS
-          sincos_batch<4>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
+          sincos_batch<4, SINE_LDS>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
 #else
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -2932,7 +2952,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const float2 p2 = *reinterpret_cast<const float2 *>(lds + (C16 ? 0 : PH) + 2 * lane_i);
       const float ph2[2] = {p2.x, p2.y};
       float c2[2], s2[2];
-      sincos_batch<2>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
+      sincos_batch<2, SINE_LDS>(sine, ph2, c2, s2, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
       *reinterpret_cast<float2 *>(lo_wr->c + 2 * lane_i) = make_float2(c2[0], c2[1]);
       *reinterpret_cast<float2 *>(lo_wr->s + 2 * lane_i) = make_float2(s2[0], s2[1]);
       WAVE_SYNC();
@@ -2985,7 +3005,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_update_kernel_c16(Updat
 // = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
 #define ASDR_MW_WAVES 4
 extern "C" __global__ __launch_bounds__(64 * ASDR_MW_WAVES, ASDR_WAVES_PER_EU) void asdr_update_kernel_mw(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16];
+  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260];   // rows | hand-off scratch | sine table
   asdr_update_body<ASDR_STRIDE, false, false, true, ASDR_MW_WAVES, 0, true>(a, lds);
 }
 // SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
