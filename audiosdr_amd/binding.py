@@ -109,6 +109,7 @@ def load_library(path=None):
     L.asdr_destroy.argtypes = [vp]; L.asdr_destroy.restype = None
     L.asdr_last_error.restype = C.c_char_p
     L.asdr_version.restype = C.c_char_p
+    L.asdr_set_pool_priority.argtypes = [_i]; L.asdr_set_pool_priority.restype = _i
     L.asdr_host_autopin.argtypes = [_i]; L.asdr_host_autopin.restype = _i
     L.asdr_host_autopin_clear.restype = None
     L.asdr_host_autopin_info.argtypes = [C.POINTER(C.c_long)]; L.asdr_host_autopin_info.restype = _i

@@ -750,6 +750,8 @@ const Chan *get(asdr_batch *&b, int ch) {
 // per step, 0.404 with nine unused lane streams created beside them; a single back-to-back kernel stream: 0.122 -> 0.152).  Sharing
 // a pool stream between batches only adds ordering nobody needs; it never breaks the ordering somebody does (a stream is in-order).
 constexpr int kPoolMax = 16;
+int g_pool_priority = -1;   // -1: ASDR_POOL_PRIORITY or the default (highest); 0 normal, 1 highest, 2 lowest (asdr_set_pool_priority)
+bool g_pool_created = false;
 struct StreamPool { hipStream_t s[kPoolMax] = {}; int size = 0; std::mutex m; };
 StreamPool g_pool[16];   // [kPoolDevices]
 constexpr int kPoolDevices = 16;   // device ordinals 0 .. 15 (a node holds 8)
@@ -765,7 +767,11 @@ hipStream_t pool_stream(int device, int i) {
     // created in front of the pool the lanes' overlap probe read "serialised" (lanes off: 0.110 instead of 0.099 ms per C2 step), and the
     // role streams of a caller with a stream of its own ran 57 instead of 37 us per SAM block -- both gone at either other priority
     // (profiles/README.md).  ASDR_POOL_PRIORITY=normal | low: the default level (round 4's behaviour) / the lowest.
-    static const char *pe = getenv("ASDR_POOL_PRIORITY");
+    // (asdr_set_pool_priority, before the first batch of the process, overrides the environment: a library kernel on a highest-priority stream
+    // is scheduled in front of the application's default-priority work on the same device -- an application that runs latency-critical kernels
+    // of its own beside the receiver bank may prefer "normal" and live with shared hardware queues.)
+    static const char *pe_env = getenv("ASDR_POOL_PRIORITY");
+    const char *pe = (g_pool_priority == 0) ? "normal" : (g_pool_priority == 2) ? "low" : (g_pool_priority == 1) ? nullptr : pe_env;
     hipError_t rc;
     if (pe == nullptr || pe[0] != 'n') {
       int least = 0, greatest = 0;
@@ -774,16 +780,23 @@ hipStream_t pool_stream(int device, int i) {
       if (rc != hipSuccess) { (void)hipGetLastError(); rc = hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking); }
     } else rc = hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking);
     if (rc != hipSuccess) { (void)hipGetLastError(); p.s[k] = nullptr; return nullptr; }
+    g_pool_created = true;
   }
   return p.s[k];
 }
 // Do two streams of the pool really run at the same time?  The lanes rest on it: HIP maps the streams of a process onto a
 // few hardware queues, and two streams that share a queue run one after the other -- then two never-joined halves gain nothing and a
-// batch does better on its caller's stream order.  Probed once per device and process, at the first asdr_create that wants lanes: a
+// batch does better on its caller's stream order.  Probed at the first call that would use the lanes (not at asdr_create: round 5): a
 // 30-us spin kernel on each of the pool's first two streams; together they end after one duration (concurrent) or two (serialised).
 // 1 = concurrent, 0 = serialised (batches then stay on the ordinary path unless asdr_set_lanes asked for the lanes), -1 = not probed / the probe itself failed
 // (lanes stay at their default: an error here must not change behaviour).
+// Round 6: the verdict no longer rests on absolute microseconds -- ONE spin on one stream is timed first (duration + launch and event
+// latency of this box, this moment), the pair counts as concurrent when its later end is below 1.5 x that; three rounds, majority; and a
+// "serialised" verdict is not kept for the process: it holds for the batch that asked (asdr_lanes_enabled says so), the next batch's first
+// lane-sized call probes again, up to three times per device (streams created meanwhile may have re-mapped the queues either way).
 int g_lanes_probe[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int g_lanes_probe_last[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // the last verdict, cached or not (asdr_lanes_overlap_probe)
+int g_lanes_probe_tries[16] = {};
 extern "C" int asdr_launch_spin(unsigned long long ticks, hipStream_t stream);
 int lanes_overlap_probe(int device) {
   if (device < 0 || device >= kPoolDevices) return -1;
@@ -797,21 +810,30 @@ int lanes_overlap_probe(int device) {
   bool ok = true;
   for (hipEvent_t &e : ev) if (hipEventCreate(&e) != hipSuccess) ok = false;
   const unsigned long long ticks = 3000;   // 30 us at 100 MHz
-  float both = 0.0f, one = 0.0f;
-  if (ok) {
-    // warm both streams (first launches pay code-object loading), then the measured pair
-    ok = asdr_launch_spin(10, s0) == 0 && asdr_launch_spin(10, s1) == 0 && hipStreamSynchronize(s0) == hipSuccess && hipStreamSynchronize(s1) == hipSuccess;
-    ok = ok && hipEventRecord(ev[0], s0) == hipSuccess && hipStreamWaitEvent(s1, ev[0], 0) == hipSuccess;   // both start behind the same marker
+  int votes = 0, rounds = 0;
+  // warm both streams (first launches pay code-object loading)
+  ok = ok && asdr_launch_spin(10, s0) == 0 && asdr_launch_spin(10, s1) == 0 && hipStreamSynchronize(s0) == hipSuccess && hipStreamSynchronize(s1) == hipSuccess;
+  for (int r = 0; r < 3 && ok; r++) {
+    float alone = 0.0f, both = 0.0f, one = 0.0f;
+    // one spin on its own: the yardstick
+    ok = ok && hipEventRecord(ev[0], s0) == hipSuccess && asdr_launch_spin(ticks, s0) == 0 && hipEventRecord(ev[1], s0) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s0) == hipSuccess && hipEventElapsedTime(&alone, ev[0], ev[1]) == hipSuccess;
+    // the pair, both behind the same marker
+    ok = ok && hipEventRecord(ev[0], s0) == hipSuccess && hipStreamWaitEvent(s1, ev[0], 0) == hipSuccess;
     ok = ok && asdr_launch_spin(ticks, s0) == 0 && asdr_launch_spin(ticks, s1) == 0;
     ok = ok && hipEventRecord(ev[1], s0) == hipSuccess && hipEventRecord(ev[2], s1) == hipSuccess;
     ok = ok && hipStreamSynchronize(s0) == hipSuccess && hipStreamSynchronize(s1) == hipSuccess;
     ok = ok && hipEventElapsedTime(&one, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&both, ev[0], ev[2]) == hipSuccess;
+    if (!ok) break;
+    rounds++;
+    if (std::max(one, both) < 1.5f * alone) votes++;
   }
   for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-  if (!ok) { (void)hipGetLastError(); return -1; }
-  const float later = std::max(one, both);
-  g_lanes_probe[device] = (later < 1.6f * 0.030f + 0.02f) ? 1 : 0;   // one duration (+ launch latency) against two
-  return g_lanes_probe[device];
+  if (!ok || rounds == 0) { (void)hipGetLastError(); return -1; }
+  const int verdict = (2 * votes > rounds) ? 1 : 0;
+  g_lanes_probe_last[device] = verdict;
+  if (verdict == 1 || ++g_lanes_probe_tries[device] >= 3) g_lanes_probe[device] = verdict;   // "concurrent" is kept; "serialised" only after three batches found it
+  return verdict;
 }
 hipStream_t aux_stream(asdr_batch *b, int i) {
   if (!b->aux[i]) b->aux[i] = pool_stream(b->device, i + 1);   // (+ 1: a lane call's pieces and an ordinary call's helpers start on different pool streams)
@@ -1991,6 +2013,12 @@ int asdr_host_unregister(void *p) {
   HIPCHK(hipHostUnregister(p));
   return 0;
 }
+int asdr_set_pool_priority(int level) {   // 0 normal, 1 highest (default), 2 lowest; before the process' first batch
+  if (level < 0 || level > 2) return fail("asdr_set_pool_priority: 0 = normal, 1 = highest, 2 = lowest");
+  if (g_pool_created) return fail("asdr_set_pool_priority: the stream pool exists already (call it before the first asdr_create)");
+  g_pool_priority = level;
+  return 0;
+}
 int asdr_host_autopin(int on) { std::lock_guard<std::mutex> lk(g_autopin.m); const int was = g_autopin.on() ? 1 : 0; if (on >= 0) g_autopin.enabled = on ? 1 : 0; return was; }
 void asdr_host_autopin_clear(void) { g_autopin.clear(); }
 int asdr_host_autopin_info(long out[4]) {
@@ -2029,16 +2057,16 @@ long asdr_lane_calls(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_lane_calls; return t; }
   return b ? b->stat_lane_calls : -1;
 }
-int asdr_lanes_overlap_probe(asdr_batch_t *b) {   // what the create-time probe of the batch's device found (see lanes_overlap_probe)
+int asdr_lanes_overlap_probe(asdr_batch_t *b) {   // the last verdict of the probe on the batch's device (see lanes_overlap_probe; -1: no lane-sized call has probed yet)
   if (!b) return -1;
   if (is_sharded(b)) { int r = 1; for (asdr_batch *sh : b->shards) { const int v = asdr_lanes_overlap_probe(sh); if (v < r) r = v; } return r; }
-  return (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe[b->device] : -1;
+  return (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe_last[b->device] : -1;
 }
 int asdr_lanes_enabled(asdr_batch_t *b) {
   if (!b) return -1;
   if (is_sharded(b)) { for (asdr_batch *sh : b->shards) if (!asdr_lanes_enabled(sh)) return 0; return 1; }
   if (!b->lanes_enabled) return 0;
-  const int probe = (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe[b->device] : -1;
+  const int probe = (b->device >= 0 && b->device < kPoolDevices) ? g_lanes_probe_last[b->device] : -1;
   return (probe == 0 && !b->lanes_forced) ? 0 : 1;   // (what the next lane-sized call will do, as far as is known now)
 }
 long asdr_sam_chunk_calls(asdr_batch_t *b) {

@@ -1177,6 +1177,21 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
                           (ASDR_MW_ROT == 3) ? ((mw_b * 0x9E3779B1u) >> 30) : (ASDR_MW_ROT == 4) ? ((mw_b >> 3) % 3u) : (mw_b >> 5);
   const int mw_rel = MW ? (int)(((uint32_t)wave - mw_rot) & (uint32_t)(WAVES - 1)) : 0;
   float *const mwx = lds_wg + WAVES * 8 * STRIDE;   // MW: [8 * WAVES][MWX] floats of hand-off scratch behind the rows
+#ifndef ASDR_MW_STRAGGLER_PRIO
+#define ASDR_MW_STRAGGLER_PRIO 0   /* experiment (round 6): at three points between the chain duty and the audio duty a wave that finds itself the LAST of its workgroup raises its priority */
+#endif
+  // (progress words of the four waves behind the hand-off scratch and the sine table)
+  int *const mw_prog = reinterpret_cast<int *>(lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 + 260);
+  if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) { if ((threadIdx.x & 63) == 0) mw_prog[wave] = 0; }
+  auto mw_straggler = [&](int point) {
+    if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) {
+      if ((threadIdx.x & 63) == 0) mw_prog[wave] = point;
+      const int4 pr = *reinterpret_cast<const int4 *>(mw_prog);
+      const int behind = (pr.x < point) + (pr.y < point) + (pr.z < point) + (pr.w < point);   // siblings that have not reached this point yet
+      const bool last = __builtin_amdgcn_readfirstlane(behind) == 0;
+      if (last) __builtin_amdgcn_s_setprio(ASDR_MW_STRAGGLER_PRIO); else __builtin_amdgcn_s_setprio(0);
+    }
+  };
   constexpr int MWX = 16;   // per channel: 0 blanker average in / out, 1 mixer phase in / "a phase sequence was computed" out, 2 increment, 3 flags, 4 phase after the block,
                             // 5 AGC quiet flag, 6 AM level, 7 gain after the block, 8 envelope in / out, 9 hang counter in / out, 10 gain in, 11..14 attack / release alpha, beta, 15 hang count
   // schedule slot / channel index of the workgroup's channel q (0 .. 8 * WAVES - 1), for the lanes that work on other waves' channels
@@ -1924,6 +1939,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     }
     WAVE_SYNC();
     TL(4);
+    mw_straggler(1);
     if (DO1) { TAP_ROW(ASDR_TAP_NB_I, W0); TAP_ROW(ASDR_TAP_NB_Q, W1); }
 
     // The IF pipeline's state and coefficients must be IN registers before the ring prefetches below are issued: memory waits
@@ -1994,6 +2010,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (C16 && lo_hit) store4(lds + (lane_i >> 4) * STRIDE + PH + ((4 * lane_i) & 63), lo4);   // word i of [cos | sin]: row i >> 6, place i & 63
     WAVE_SYNC();
     TL(5);
+    mw_straggler(2);
     if (DO1) { TAP_ROW(ASDR_TAP_IF_I, W0); TAP_ROW(ASDR_TAP_IF_Q, W1); }
     // A role's own status bits go back with atomics: the three roles of a channel group update one word
     auto store_status_bits = [&](uint32_t mask) {
@@ -2375,6 +2392,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
       WAVE_SYNC();
       TL(8);
+      mw_straggler(3);
       constexpr bool IDL_EARLY = (ROLE == 2);   // the pipeline's role 2 has the registers to request the delayed I before the FIR
       if (IDL_EARLY && is_ssb) {
 #pragma unroll
@@ -2538,6 +2556,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if constexpr ((MW_SHARE & 1) != 0) {
       if (ABL_ON(ABL_AF) && af_en) {   // (launch-uniform: all four waves or none)
         TL(21);
+        if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
         __syncthreads();               // every wave's demodulated audio is in its W0 rows
         TL(22);
         if (mw_audio_duty) {           // 16 cascades x 4 stages: the whole wave works
@@ -3005,7 +3024,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_update_kernel_c16(Updat
 // = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
 #define ASDR_MW_WAVES 4
 extern "C" __global__ __launch_bounds__(64 * ASDR_MW_WAVES, ASDR_WAVES_PER_EU) void asdr_update_kernel_mw(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260];   // rows | hand-off scratch | sine table
+  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260 + 4];   // rows | hand-off scratch | sine table | progress words
   asdr_update_body<ASDR_STRIDE, false, false, true, ASDR_MW_WAVES, 0, true>(a, lds);
 }
 // SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
@@ -3132,7 +3151,7 @@ extern "C" __global__ __launch_bounds__(64, ASDR_ALS_K_WAVES_PER_EU) void asdr_a
     const float lam = Pp->als_lambda;
     const uint32_t as = (a.als_phase + (uint32_t)blk) & 1u;
     const float *gx_cur = a.als_x + (size_t)ch * (2 * ASDR_N) + as * ASDR_N + kF, *gx_prev = a.als_x + (size_t)ch * (2 * ASDR_N) + (as ^ 1u) * ASDR_N + kF;
-    if (a.als_stage != nullptr) {   // ALS role streams: this block's and the previous block's rows wait in the three-slot stage (the ring's slots belong to the chain launches running ahead)
+    if (a.als_stage != nullptr) {   // ALS role streams: this block's and the previous block's rows wait in the stage (ASDR_ALS_STAGE_SLOTS = 32 slots per channel; the ring's slots belong to the chain launches running ahead)
       const uint32_t sc = (a.als_stage_cur + (uint32_t)blk) % ASDR_ALS_STAGE_SLOTS, sp = (a.als_stage_prev + (uint32_t)blk) % ASDR_ALS_STAGE_SLOTS;
       gx_cur = a.als_stage + (size_t)ch * (ASDR_ALS_STAGE_SLOTS * ASDR_N) + sc * ASDR_N + kF; gx_prev = a.als_stage + (size_t)ch * (ASDR_ALS_STAGE_SLOTS * ASDR_N) + sp * ASDR_N + kF;
     }

@@ -147,16 +147,21 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
  * batch (in waves of 8 channels, default 1024) that uses them; environment ASDR_NO_LANES=1 at asdr_create time = default off.
  * Since round 5 the pool's streams are created at the HIGHEST stream priority: the runtime keeps hardware queues per priority level, so the
  * pool does not share queues with streams the application creates at the default priority (measured: what follows, gone; environment
- * ASDR_POOL_PRIORITY=normal restores the default level, =low picks the lowest).
+ * ASDR_POOL_PRIORITY=normal restores the default level, =low picks the lowest; asdr_set_pool_priority(0 normal / 1 highest / 2 lowest) does the
+ * same from code, BEFORE the process' first asdr_create).  The price: every kernel the library launches on its own streams (lanes, role streams,
+ * the host path's copies) is scheduled in front of the application's default-priority work on that device -- an application with
+ * latency-critical kernels of its own beside the receiver bank may prefer the default level and shared hardware queues.
  * WHAT THE LANES REST ON, and what breaks them.  The batch's own streams come from ONE pool of three non-blocking streams per device and
  * process, shared by every batch of the process on that device (asdr_synchronize / the host path of one batch therefore also waits for
  * other batches' work on those streams; device ordinals 0..15).  HIP maps the streams a process uses onto a few hardware queues (four by
  * default: the null stream + the pool's three); two streams that share a queue run strictly one after the other, and every further
  * stream in the process -- the application's, a framework's -- can re-map the pool's streams onto a shared queue (measured: one
  * back-to-back kernel stream that shares its queue, 0.122 -> 0.153 ms per 65,536-channel step).  The first call that would use the lanes
- * therefore PROBES the pool, once per device and process (two 30-us spin kernels on the pool's first two streams: they end together, or
- * one after the other), and a batch whose pool streams do not overlap stays on the ordinary path unless asdr_set_lanes(b, on > 0) asked
- * for the lanes; asdr_lanes_overlap_probe() = 1 concurrent / 0 serialised / -1 not probed yet (or ASDR_NO_LANES_PROBE=1, or the probe
+ * therefore PROBES the pool (a 30-us spin kernel alone on the pool's first stream, then one on each of its first two streams behind a common
+ * marker: the pair ends within 1.5 x the lone spin, or one after the other; three rounds, majority), and a batch whose pool streams do not
+ * overlap stays on the ordinary path unless asdr_set_lanes(b, on > 0) asked for the lanes.  "Concurrent" is kept for the device and process;
+ * "serialised" holds for the batch that asked -- the next batch's first lane-sized call probes again, and only the third such verdict is kept.
+ * asdr_lanes_overlap_probe() = the last verdict: 1 concurrent / 0 serialised / -1 not probed yet (or ASDR_NO_LANES_PROBE=1, or the probe
  * failed: defaults kept), asdr_lanes_enabled() = what the batch's next lane-sized call will do.  (Not at asdr_create: a process that only
  * ever calls on its own streams never creates the pool's lane streams -- two application streams driving two shards of one GPU lost 25 %
  * to a probe at create time, round 5.)  The probe sees the stream population at that moment; an application that creates many streams
@@ -164,6 +169,7 @@ int asdr_update_device_strided(asdr_batch_t *b, const int16_t *dI, const int16_t
  * ~10 % slower for large one-group batches). */
 #define ASDR_STREAM_BATCH ((void *)(intptr_t)-1)
 int asdr_lanes_overlap_probe(asdr_batch_t *b);
+int asdr_set_pool_priority(int level);
 int asdr_lanes_enabled(asdr_batch_t *b);
 int asdr_order_after(asdr_batch_t *b, void *stream);
 int asdr_order_before(asdr_batch_t *b, void *stream);
@@ -180,10 +186,14 @@ long asdr_sam_role_calls(asdr_batch_t *b);
  * Environment ASDR_NO_SAM_CHUNKS=1 keeps the per-block form. */
 long asdr_sam_chunk_calls(asdr_batch_t *b);
 /* ALS role streams (round 5): a SMALL bank whose whole schedule is one settings group of channels with a short ALS filter (taps <= 64,
- * delay + taps <= 65; a known mode; below the one-launch-per-block size) runs a multi-block call as two launches per block -- the chain up to
- * the AGC | the filter + output -- on two event-chained streams, the filter of block b beside the chain of block b + 1, through a three-slot
- * stage of post-AGC rows in HBM (1.5 KB per channel, allocated at the first such call).  Bit-identical to the block loop; not taken for in-place
- * calls or with stage taps.  asdr_als_role_calls() = calls that ran that way; environment ASDR_NO_ALS_ROLE_STREAMS=1 turns it off. */
+ * delay + taps <= 65; a known mode; below the one-launch-per-block size) runs a multi-block call as launches of 8 blocks per role on
+ * event-chained streams -- by default THREE stages on three streams: front half (scale, blanker, IF band-pass) | back half (mixer .. AGC) | the
+ * filter + output; ASDR_ALS_ROLE_STAGES=2: the chain up to the AGC | the filter + output on two --, a role's chunk beside the next role's
+ * previous chunk.  The rows cross in HBM: a stage of 32 post-AGC rows per channel (16 KB per channel: 64 MB at 4,096 channels, allocated at
+ * the first such call; a chain role may run up to two chunks ahead of the filter role) and, in the three-stage form, 32 tile sets between the
+ * chain's halves (32 KB per channel: 128 MB at 4,096 channels, shared with the chunked SAM role streams).  Bit-identical to the block loop; not
+ * taken for in-place calls or with stage taps.  asdr_als_role_calls() = calls that ran that way; environment ASDR_NO_ALS_ROLE_STREAMS=1 turns
+ * it off. */
 long asdr_als_role_calls(asdr_batch_t *b);
 int asdr_set_lanes(asdr_batch_t *b, int on, int min_waves);
 int asdr_synchronize(asdr_batch_t *b);

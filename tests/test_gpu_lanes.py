@@ -207,7 +207,7 @@ def test_host_rows_call_behind_running_lanes(gpu):
 
 def test_lanes_with_foreign_streams_alive_and_the_overlap_probe(gpu):
     """Round 5: the lanes rest on the pool's streams running concurrently, which every other stream of the process can change (include/asdr.h,
-    "WHAT THE LANES REST ON").  With three torch streams alive and busy beside the batch: (1) asdr_create's probe has an answer for the device
+    "WHAT THE LANES REST ON").  With three torch streams alive and busy beside the batch: (1) the probe (run by the first lane-sized call) has an answer for the device
     (1 concurrent / 0 serialised; -1 only if switched off) and the batch's default follows it; (2) whatever the probe said, lane calls
     and ordinary calls give identical audio (the geometry is a speed matter, never a correctness one)."""
     import os
