@@ -1182,6 +1182,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #endif
   // (progress words of the four waves behind the hand-off scratch and the sine table)
   int *const mw_prog = reinterpret_cast<int *>(lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 + 260);
+  int *const mw_flags = mw_prog + 4;   // [0]: the AGC duty took the lean chain (this block)
   if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) { if ((threadIdx.x & 63) == 0) mw_prog[wave] = 0; }
   auto mw_straggler = [&](int point) {
     if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) {
@@ -2757,11 +2758,56 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         __syncthreads();
         TL(26);
         if (ASDR_MW_PRIO && mw_rel == 3) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
+#ifndef ASDR_AGC_LEAN
+#define ASDR_AGC_LEAN 1
+#endif
+        // Round 6, the LEAN chain.  When no hang counter of the duty wave's channels can run out inside the block (counter >= 128 at its start and a
+        // hang time of >= 128 samples: an attack re-arms it with that) nothing releases, and the only recurrence is the envelope itself:
+        //     attack = |x| > envelope;  envelope = attack ? alpha envelope + beta |x| : envelope        (AudioSDR.cpp:412-420)
+        // -- four instructions on the chain per sample instead of eight.  The duty wave leaves the envelope AFTER every sample in the row; which
+        // sample attacked (|x|[u] > envelope after sample u - 1), from where on the governing value exists at all, the hang counter and the gain after
+        // the block are functions of that row and are formed in parallel by the channels' own waves behind the barrier (below).
+        constexpr bool LEAN_OK = (ASDR_AGC_LEAN != 0) && (ASDR_MW_OWN_STORES != 0);
         if (mw_rel == 3 && lane_i < 8 * WAVES) {
           const int q = lane_i;
-          if (__float_as_int(mwx[MWX * q + 5]) == 0) {
+          const bool active = (__float_as_int(mwx[MWX * q + 5]) == 0);
+          float4 i0 = make_float4(0.f, 0.f, 0.f, 0.f), i1 = i0;
+          if (ASDR_MW_OWN_STORES && active) { i0 = *reinterpret_cast<const float4 *>(mwx + MWX * q + 8); i1 = *reinterpret_cast<const float4 *>(mwx + MWX * q + 12); }
+          const bool lean = LEAN_OK && !is_am && __all(!active || (__float_as_uint(i0.y) >= 128u && __float_as_uint(i1.w) >= 128u));
+          if (q == 0) mw_flags[0] = lean ? 1 : 0;
+          if (lean) {
+            if (active) {
+              float *Lc = lds_wg + q * STRIDE;
+              float old_abs = i0.x;
+              const float al_a = i0.w, be_a = i1.x;
+              float x_[8];
+              load8(Lc + AGC_GV, x_);
+#pragma unroll 1
+              for (int i2 = 0; i2 < ASDR_N; i2 += 16) {
+                float xn_[8];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                  const int i = i2 + 8 * half;
+                  float *x = half ? xn_ : x_, *xn = half ? x_ : xn_;
+                  load8(Lc + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);
+                  float pb[8], ov[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) pb[u] = be_a * x[u];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    const float pa = al_a * old_abs;
+                    const float v_new = pa + pb[u];
+                    old_abs = (x[u] > old_abs) ? v_new : old_abs;
+                    ov[u] = old_abs;
+                  }
+                  store8(Lc + AGC_GV + i, ov);
+                }
+              }
+              mwx[MWX * q + 8] = old_abs;
+            }
+          } else
+          if (active) {
             if (ASDR_MW_OWN_STORES) {
-              const float4 i0 = *reinterpret_cast<const float4 *>(mwx + MWX * q + 8), i1 = *reinterpret_cast<const float4 *>(mwx + MWX * q + 12);
               mwx[MWX * q + 7] = agc_chain(std::true_type{}, lds_wg + q * STRIDE, nullptr, i0.x, __float_as_uint(i0.y), i0.z, i0.w, i1.x, i1.y, i1.z, __float_as_uint(i1.w), is_am, mwx[MWX * q + 6]);
               mwx[MWX * q + 8] = agc_old_end; mwx[MWX * q + 9] = __uint_as_float(agc_hc_end);
             } else {
@@ -2777,6 +2823,54 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         TL(27);
         __syncthreads();
         TL(28);
+        const bool lean_done = LEAN_OK && (__builtin_amdgcn_readfirstlane(mw_flags[0]) != 0);
+        if (lean_done && !agc_quiet && agc_en) {
+          // The lean chain left the envelope after every sample in the row.  Sample u attacked iff |x|[u] > the envelope after sample u - 1 (carried in for
+          // u = 0); before the block's first attack the governing value does not exist (-1: the gain carried in applies); the counter after the block is
+          // hang - (127 - last attack), or the carried one less 128; the gain after the block is the compressor at the last envelope, if anything attacked.
+          int first = 128, last = -1;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float ov[8];
+            load8(L + AGC_GV + kA + 64 * h, ov);
+            const int p0 = kA + 64 * h;
+            float before = (p0 == 0) ? agc_old0 : L[AGC_GV + ((p0 == 0) ? 0 : p0 - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const bool att = av16[8 * h + j] > before;
+              first = (att && p0 + j < first) ? p0 + j : first;
+              last = att ? p0 + j : last;
+              before = ov[j];
+            }
+          }
+          // over the channel's eight lanes: minimum of `first`, maximum of `last` (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror: as the block maximum above)
+          { const int t = __builtin_amdgcn_update_dpp(0, first, 0xB1, 0xF, 0xF, true); first = t < first ? t : first; }
+          { const int t = __builtin_amdgcn_update_dpp(0, first, 0x4E, 0xF, 0xF, true); first = t < first ? t : first; }
+          { const int t = __builtin_amdgcn_update_dpp(0, first, 0x141, 0xF, 0xF, true); first = t < first ? t : first; }
+          { const int t = __builtin_amdgcn_update_dpp(0, last, 0xB1, 0xF, 0xF, true); last = t > last ? t : last; }
+          { const int t = __builtin_amdgcn_update_dpp(0, last, 0x4E, 0xF, 0xF, true); last = t > last ? t : last; }
+          { const int t = __builtin_amdgcn_update_dpp(0, last, 0x141, 0xF, 0xF, true); last = t > last ? t : last; }
+          WAVE_SYNC();   // (every lane has read the envelopes it compares with before anybody overwrites a row entry)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {   // the rows as the general chain leaves them: -1 in front of the first attack
+            const int p0 = kA + 64 * h;
+            if (p0 < first) {
+              float ov[8];
+              load8(L + AGC_GV + p0, ov);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) ov[j] = (p0 + j < first) ? -1.0f : ov[j];
+              store8(L + AGC_GV + p0, ov);
+            }
+          }
+          if (lead) {
+            const float old_end = mwx[MWX * (wave * 8 + c8) + 8];
+            const float g_end = (last < 0) ? gain_in : agc_compress(tab, old_end);
+            status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
+            S->agc_old_abs = old_end;
+            S->agc_hang_counter = (last < 0) ? agc_hc0 - 128u : agc_hang - (uint32_t)(127 - last);
+            S->agc_gain = g_end;
+          }
+        } else
         if (!agc_quiet && lead) {
           const float *mq = mwx + MWX * (wave * 8 + c8);
           const float g_end = mq[7]; status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
@@ -3024,7 +3118,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_update_kernel_c16(Updat
 // = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
 #define ASDR_MW_WAVES 4
 extern "C" __global__ __launch_bounds__(64 * ASDR_MW_WAVES, ASDR_WAVES_PER_EU) void asdr_update_kernel_mw(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260 + 4];   // rows | hand-off scratch | sine table | progress words
+  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260 + 8];   // rows | hand-off scratch | sine table | progress words | flags
   asdr_update_body<ASDR_STRIDE, false, false, true, ASDR_MW_WAVES, 0, true>(a, lds);
 }
 // SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
