@@ -2561,13 +2561,16 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         __syncthreads();               // every wave's demodulated audio is in its W0 rows
         TL(22);
         if (mw_audio_duty) {           // 16 cascades x 4 stages: the whole wave works
-          if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
+#ifndef ASDR_MW_PRIO_AUDIO
+#define ASDR_MW_PRIO_AUDIO ASDR_MW_PRIO   /* the audio-cascade duty's priority (experiments: 0 = only the short chain duties are raised) */
+#endif
+          if (ASDR_MW_PRIO_AUDIO) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO_AUDIO);
           const int st = pl_st;
           float sv[4];
           sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
           biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + mw_casc) * STRIDE + W0, true, st, af_cf, sv);
           *reinterpret_cast<float4 *>(&mw_af_S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
-          if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(0);
+          if (ASDR_MW_PRIO_AUDIO) __builtin_amdgcn_s_setprio(0);
         }
         TL(23);
         __syncthreads();

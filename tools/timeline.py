@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "audiosdr_amd", "variants", "libasdr_timeline.so")
+LIB = os.environ.get("TIMELINE_LIB") or os.path.join(ROOT, "audiosdr_amd", "variants", "libasdr_timeline.so")
 NAMES = ["prologue+load", "NB: store ring, envelopes", "NB: sequential average/threshold", "NB: mask, ramp, carry, output",
          "IF pipeline", "mixer phase recurrence", "mixer multiply", "Hilbert: stage history", "Hilbert: FIR", "sideband combine",
          "audio pipeline", "AGC: table to LDS", "AGC: sequential envelope", "AGC: apply", "output + status"]
