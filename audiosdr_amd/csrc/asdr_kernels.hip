@@ -44,6 +44,17 @@
 #ifndef ASDR_AGC_QUIET_PATH
 #define ASDR_AGC_QUIET_PATH 1   /* 0: every block through the chunk loop (measurements) */
 #endif
+#ifndef ASDR_MW_OWN_STORES
+#define ASDR_MW_OWN_STORES 1   /* the four-wave form: a chain's results go back to HBM from the channel's OWN wave (its lead lanes: stores beside its other state), not from the duty wave's 32 lanes */
+#endif
+#ifndef ASDR_AGC_LEAN
+#define ASDR_AGC_LEAN 1   /* the four-wave form's AGC duty: the envelope-only chain when no hang counter can run out inside the block (see the duty) */
+#endif
+#ifndef ASDR_MW_AGC_PIPELINED
+#define ASDR_MW_AGC_PIPELINED 0   /* ... and that chain BESIDE the audio duty, a chunk behind the cascades, while the bank attacks (see the audio duty).  Built, bit-exact, measured
+                                     (round 6): the workgroup's timeline gets 3.5 k cycles shorter in a fresh bank, the launch does not get faster (driver window +0...2.8 %,
+                                     steady state +2.3 %: the early decision, the progress words and the extra waves' instructions cost what the parking saved) -- off */
+#endif
 #ifndef ASDR_ONEBLK
 #define ASDR_ONEBLK 1   /* one-block launches of the plain / short-ALS uniform kernels take their loop-free twins (asdr_launch_update); 0: the looped kernels (measurements) */
 #endif
@@ -210,6 +221,8 @@ __device__ __forceinline__ float cos_f32(const float *sine, float phase, float t
 // interpolations.  Written lookup by lookup the compiler waits for every gather right behind its issue -- one exposed L1 round
 // trip per lookup.  Same operations per value as sin_f32 / cos_f32 above.
 typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;
+typedef __attribute__((address_space(3))) int *lds_int_ptr;
+typedef int v2i __attribute__((ext_vector_type(2)));
 // LDS_TAB: `sine` is the workgroup's LDS copy of the table (named as an LDS pointer: through the generic `sine ? sine : c_sine` the compiler emits FLAT
 // loads, which wait for the outstanding global loads as well -- see sincos_pll).
 template <int NP, bool LDS_TAB = false>
@@ -363,8 +376,10 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 #ifndef ASDR_PIPE_BANK_SELECT
 #define ASDR_PIPE_BANK_SELECT 0   /* the stage-0 select of the pipelines as a bank-masked DPP move (see the step); 0: round 5's v_cndmask_b32_dpp on VCC */
 #endif
-template <bool PK = false>
-__device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const float *cf, float *sv) {
+// SIGNAL (round 6, the four-wave form's audio duty): after every step that wrote a chunk back, the lane `sig` publishes the number of
+// chunks of the row that are final in *prog (release at workgroup scope) -- the AGC duty wave follows one chunk behind.
+template <bool PK = false, bool SIGNAL = false>
+__device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const float *cf, float *sv, int *prog = nullptr, bool sig = false) {
   constexpr int C = ASDR_PIPE_CHUNK, NSTEP = ASDR_N / C + 3;
   const float b0 = cf[0], b1 = cf[1], b2 = cf[2], a1 = cf[3], a2 = cf[4];
   float x1 = sv[0], x2 = sv[1], y1 = sv[2], y2 = sv[3];
@@ -375,6 +390,8 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
   for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
   const bool s0 = (st == 0);
   const unsigned long long s0m = __ballot(s0);   // EXEC is full here
+  uint32_t prog_lds = 0u;
+  if constexpr (SIGNAL) prog_lds = (uint32_t)(uintptr_t)(lds_int_ptr)prog;
   auto step = [&](auto edge_tag, const int c) {
     constexpr bool EDGE = decltype(edge_tag)::value;   // a step of the systolic fill / drain: some stages have no chunk
     const int cn = c - st;
@@ -413,6 +430,14 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
       const int nc = (c + 1 < ASDR_N / C) ? c + 1 : ASDR_N / C - 1;
 #pragma unroll
       for (int q = 0; q < C / 4; ++q) { const float4 t = reinterpret_cast<const float4 *>(row)[nc * (C / 4) + q]; xn[4 * q] = t.x; xn[4 * q + 1] = t.y; xn[4 * q + 2] = t.z; xn[4 * q + 3] = t.w; }
+    }
+    const uint32_t prog_lds_ = prog_lds;   // (named outside the `if constexpr`: a generic lambda does not capture from inside it)
+    if constexpr (SIGNAL) {
+      // The chunks the PREVIOUS steps wrote back are final: c - 3 of them.  Published here, at the top of the step, so that the wait in front of the
+      // next step's select has a step's arithmetic between it and this write (at the end of the step it sat out the write: +60 cycles per step).  No
+      // release fence: the LDS executes a wave's operations in the order issued, and the "memory" clobber keeps the compiler from moving the row
+      // stores of the previous step below this one.
+      if (c >= 4 && sig) asm volatile("ds_write_b32 %0, %1" :: "v"(prog_lds_), "v"(c - 3) : "memory");
     }
 #if ASDR_PIPE_PREFETCH_FENCE
     // Round 5: the two LDS reads stay HERE, at the top of the step.  Left alone the scheduler sinks them to the step's last dozen
@@ -477,6 +502,7 @@ __device__ __forceinline__ void biquad_pipe(float *row, bool on, int st, const f
 #pragma unroll 1
   for (int c = 16; c < NSTEP; ++c) step(std::true_type{}, c);
 #endif
+  if constexpr (SIGNAL) { if (sig) asm volatile("ds_write_b32 %0, %1" :: "v"(prog_lds), "v"(ASDR_N / C) : "memory"); }   // ... and the last one
   sv[0] = x1; sv[1] = x2; sv[2] = y1; sv[3] = y2;
 }
 
@@ -1182,7 +1208,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
 #endif
   // (progress words of the four waves behind the hand-off scratch and the sine table)
   int *const mw_prog = reinterpret_cast<int *>(lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 + 260);
-  int *const mw_flags = mw_prog + 4;   // [0]: the AGC duty took the lean chain (this block)
+  int *const mw_flags = mw_prog + 4;   // [0]: the AGC duty took the lean chain (this block); [1]: chunks whose |x| and beta |x| are in the rows, [2], [3]: chunks the audio duty waves have finished (the AGC duty beside the audio duty)
+  constexpr bool PIPE_AGC = MW && WAVES == 4 && (MW_SHARE & 7) == 7 && (ASDR_MW_AGC_PIPELINED != 0) && (ASDR_AGC_LEAN != 0) && (ASDR_MW_OWN_STORES != 0) && ABL_ON(ABL_AGC) && ABL_ON(ABL_AF) && ABL_ON(ABL_NB);
+  if constexpr (PIPE_AGC) { if (threadIdx.x < 3) mw_flags[1 + threadIdx.x] = 0; }   // (five barriers in front of the first reader)
   if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) { if ((threadIdx.x & 63) == 0) mw_prog[wave] = 0; }
   auto mw_straggler = [&](int point) {
     if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) {
@@ -1396,10 +1424,14 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     uint32_t mkc[5] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};   // defined on every path
     const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
     float g_oi = gain_i, g_oq = gain_q, g_mi = 0.0f, g_mq = 0.0f, nb_avg0 = 0.0f;
+    uint32_t agc_hc_early = 0u, agc_hang_early = 0u;
+    bool agc_piped = false;   // (the four-wave form: the AGC duty runs the lean chain beside the audio duty: see the audio filter)
     if (nb_wave && nb_en) {
       // the gains first: they are converted right away, and a wait for the oldest loads leaves all the others in flight
       g_oi = S->nb_gain[ns][0]; g_oq = S->nb_gain[ns][1]; g_mi = S->nb_gain[ns_mid][0]; g_mq = S->nb_gain[ns_mid][1];
       nb_avg0 = S->nb_avg;
+      if constexpr (PIPE_AGC) { agc_hc_early = S->agc_hang_counter; agc_hang_early = P.agc_hang_count; }   // (for the decision "AGC chain beside the audio duty", published with the blanker chain's inputs)
+   // (for the decision "AGC chain beside the audio duty", published with the blanker chain's inputs)
       const int4 *old4 = reinterpret_cast<const int4 *>(hist + ns * 256 + kA), *mid4 = reinterpret_cast<const int4 *>(hist + ns_mid * 256 + kA);
 #if ASDR_NT_LOADS >= 2
       rmi[0].v = mid4[0]; rmi[1].v = mid4[8]; rmq[0].v = mid4[16]; rmq[1].v = mid4[24];   // (the middle block comes back once more: temporal)
@@ -1723,6 +1755,15 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if constexpr ((MW_SHARE & 2) != 0) {
         // every channel's lead lane publishes its chain inputs; the duty wave (rel 0) runs the chains of all 8 * WAVES channels, one per lane
         if (lead) *reinterpret_cast<float4 *>(mwx + MWX * (wave * 8 + c8)) = make_float4(nb_avg0, mphase, minc, __int_as_float((chain_phase_own ? 1 : 0) | ((mix_early && !lo_hit) ? 2 : 0)));
+        if constexpr (PIPE_AGC) {
+          // bit 0: this channel's AGC is off or in the lean regime (no hang counter can run out inside the block); bit 1: it attacked in the PREVIOUS block
+          // (an attack at sample u leaves the counter at hang - (127 - u)).  See the audio filter: the AGC chain beside the audio duty.
+          if (lead) {
+            const bool capable = af_en && nb_en && (!agc_en || (!is_am && agc_hc_early >= 128u && agc_hang_early >= 128u));
+            const bool recent = agc_en && (agc_hang_early - agc_hc_early <= 127u);
+            mwx[MWX * (wave * 8 + c8) + 7] = __int_as_float((capable ? 1 : 0) | (recent ? 2 : 0));
+          }
+        }
         TL(17);
         __syncthreads();
         TL(18);
@@ -1736,10 +1777,17 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           mwx[MWX * q + 4] = pe;
           if (ASDR_MW_OWN_STORES) { mwx[MWX * q] = nb_avg_end; mwx[MWX * q + 1] = __int_as_float(any_phase ? 1 : 0); }
         }
-        if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(0);
+#ifndef ASDR_MW_PRIO_REL0_TAIL
+#define ASDR_MW_PRIO_REL0_TAIL 0   /* experiments: the priority the blanker-chain duty wave keeps up to the audio barrier (the timeline's straggler there) */
+#endif
+        if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO_REL0_TAIL);
         TL(19);
         __syncthreads();
         TL(20);
+        if constexpr (PIPE_AGC) {   // (every wave forms the decision from the 32 channels' words; nothing waits for this read before the audio barrier)
+          const int fl = __float_as_int(mwx[MWX * (lane_i & (8 * WAVES - 1)) + 7]);
+          agc_piped = __all((fl & 1) != 0) && __any((fl & 2) != 0);
+        }
         if (lead) {
           mphase_end = mwx[MWX * (wave * 8 + c8) + 4];
           if (ASDR_MW_OWN_STORES) {   // the chain's results back to the channel's state row, from its own wave
@@ -2556,8 +2604,21 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // ---- audio IIR filter, AudioSDR.cpp:149, 280-286: lanes s8 = 0..3 are the four stages ---------------------
     if constexpr ((MW_SHARE & 1) != 0) {
       if (ABL_ON(ABL_AF) && af_en) {   // (launch-uniform: all four waves or none)
+        // Round 6: the AGC duty BESIDE the audio duty.  While the blocks of a bank attack (a fresh bank's first ~150 blocks, any bank after a level step)
+        // the AGC's envelope chain (6 k cycles for which three waves parked) follows the audio cascades on the two waves that would otherwise sit out
+        // the audio duty at the barrier: the blanker-duty wave (rel 0) takes the filtered samples from the rows as the cascades' last stage leaves
+        // them (progress words of the two audio waves in LDS), forms |x| and beta |x| for all 32 channels, four samples per lane; the AGC-duty wave
+        // (rel 3) follows IT with the lean chain (below): envelope after every sample, 32 channels on 32 lanes.  Taken when every channel of the
+        // workgroup is in the lean regime and some channel attacked in the PREVIOUS block (decided behind the blanker chain's barrier, from words
+        // published in front of it): a steady bank, whose blocks are quiet, does not pay for chains nobody needs.
+        if constexpr (PIPE_AGC) {
+          if (agc_piped && lead && agc_en) {
+            float *mq = mwx + MWX * (wave * 8 + c8);
+            mq[8] = agc_old0; mq[11] = agc_al_a; mq[12] = agc_be_a;
+          }
+        }
         TL(21);
-        if constexpr (MW && ASDR_MW_STRAGGLER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr (MW && (ASDR_MW_STRAGGLER_PRIO != 0 || ASDR_MW_PRIO_REL0_TAIL != 0)) __builtin_amdgcn_s_setprio(0);
         __syncthreads();               // every wave's demodulated audio is in its W0 rows
         TL(22);
         if (mw_audio_duty) {           // 16 cascades x 4 stages: the whole wave works
@@ -2568,9 +2629,100 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           const int st = pl_st;
           float sv[4];
           sv[0] = af_s4.x; sv[1] = af_s4.y; sv[2] = af_s4.z; sv[3] = af_s4.w;
-          biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + mw_casc) * STRIDE + W0, true, st, af_cf, sv);
+          if (PIPE_AGC && agc_piped) biquad_pipe<PIPE_PK, PIPE_AGC>(lds_wg + (16 * (mw_rel - 1) + mw_casc) * STRIDE + W0, true, st, af_cf, sv, mw_flags + 1 + mw_rel, lane_i == 0);
+          else biquad_pipe<PIPE_PK>(lds_wg + (16 * (mw_rel - 1) + mw_casc) * STRIDE + W0, true, st, af_cf, sv);   // (a steady bank: the cascades as they were)
           *reinterpret_cast<float4 *>(&mw_af_S->af_state[4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
           if (ASDR_MW_PRIO_AUDIO) __builtin_amdgcn_s_setprio(0);
+        } else if constexpr (PIPE_AGC) {
+          if (agc_piped) {
+            // Progress words are read with explicit ds_read + s_waitcnt (a `volatile` access is completed on the spot by the compiler, and through a generic
+            // pointer it takes the flat path): the poll for a chunk is in flight during the previous chunk's arithmetic, and a chunk's operands are
+            // requested a chunk ahead whenever the producer is known to be that far (two dependent LDS round trips per chunk -- poll, then operands --
+            // are longer than the chunk's arithmetic under load).  The compiler does not count these reads in its own s_waitcnt operands: it then
+            // waits for MORE than it needs, never for less.
+            if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
+            if (mw_rel == 0) {
+              // |x| clamped to 1.0 (:410-411; NaN-preserving like the owners' pass) -> [256 + ..), beta |x| -> [AGC_GV + ..): lane = (channel, half chunk)
+              const int q = lane_i >> 1;
+              float *Lc = lds_wg + q * STRIDE + 4 * (lane_i & 1);
+              const float be_a = mwx[MWX * q + 12];
+              const uint32_t src_lds = (uint32_t)(uintptr_t)(lds_int_ptr)(mw_flags + 2), dst_lds = (uint32_t)(uintptr_t)(lds_int_ptr)(mw_flags + 1);
+              v2i pr;
+              auto poll_issue = [&]() { asm volatile("ds_read_b64 %0, %1" : "=v"(pr) : "v"(src_lds) : "memory"); };
+              auto poll_value = [&]() -> int {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr) :: "memory");   // (and no row read moves above the poll it depends on)
+                return __builtin_amdgcn_readfirstlane(pr.x < pr.y ? pr.x : pr.y);
+              };
+              poll_issue();
+              int known = poll_value();
+              while (known < 1) { __builtin_amdgcn_s_sleep(2); poll_issue(); known = poll_value(); }
+              float xr[4];
+              load4(Lc + W0, xr);
+#pragma unroll 1
+              for (int c = 0; c < ASDR_N / 8; ++c) {
+                const int nc = (c + 1 < ASDR_N / 8) ? c + 1 : c;
+                const bool pre = known > nc;   // (wave-uniform)
+                float xn[4];
+                if (pre) load4(Lc + W0 + 8 * nc, xn);
+                poll_issue();   // (consumed behind the chunk)
+                float ax[4], pb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const float t = fabsf(xr[u]); ax[u] = (t > 1.0f) ? 1.0f : t; pb[u] = be_a * ax[u]; }
+                store4(Lc + 256 + 8 * c, ax); store4(Lc + AGC_GV + 8 * c, pb);
+                if (lane_i == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(dst_lds), "v"(c + 1) : "memory");   // (the LDS executes a wave's operations in order)
+                known = poll_value();
+                if (!pre) {
+                  while (known <= nc) { __builtin_amdgcn_s_sleep(1); poll_issue(); known = poll_value(); }
+                  load4(Lc + W0 + 8 * nc, xn);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xr[u] = xn[u];
+              }
+            } else if (lane_i < 8 * WAVES) {   // rel 3
+              const int q = lane_i;
+              float *Lc = lds_wg + q * STRIDE;
+              float old_abs = mwx[MWX * q + 8];
+              const float al_a = mwx[MWX * q + 11];
+              const uint32_t src_lds = (uint32_t)(uintptr_t)(lds_int_ptr)(mw_flags + 1);
+              int pr;
+              auto poll_issue = [&]() { asm volatile("ds_read_b32 %0, %1" : "=v"(pr) : "v"(src_lds) : "memory"); };
+              auto poll_value = [&]() -> int {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr) :: "memory");
+                return __builtin_amdgcn_readfirstlane(pr);
+              };
+              poll_issue();
+              int known = poll_value();
+              while (known < 1) { __builtin_amdgcn_s_sleep(2); poll_issue(); known = poll_value(); }
+              float ax[8], pb[8];
+              load8(Lc + 256, ax); load8(Lc + AGC_GV, pb);
+#pragma unroll 1
+              for (int c = 0; c < ASDR_N / 8; ++c) {
+                const int nc = (c + 1 < ASDR_N / 8) ? c + 1 : c;
+                const bool pre = known > nc;
+                float axn[8], pbn[8];
+                if (pre) { load8(Lc + 256 + 8 * nc, axn); load8(Lc + AGC_GV + 8 * nc, pbn); }
+                poll_issue();
+                float ov[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const float pa = al_a * old_abs;
+                  const float v_new = pa + pb[u];
+                  old_abs = (ax[u] > old_abs) ? v_new : old_abs;
+                  ov[u] = old_abs;
+                }
+                store8(Lc + AGC_GV + 8 * c, ov);
+                known = poll_value();
+                if (!pre) {
+                  while (known <= nc) { __builtin_amdgcn_s_sleep(1); poll_issue(); known = poll_value(); }
+                  load8(Lc + 256 + 8 * nc, axn); load8(Lc + AGC_GV + 8 * nc, pbn);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ax[u] = axn[u]; pb[u] = pbn[u]; }
+              }
+              mwx[MWX * q + 8] = old_abs;
+            }
+            if (ASDR_MW_PRIO) __builtin_amdgcn_s_setprio(0);
+          }
         }
         TL(23);
         __syncthreads();
@@ -2628,12 +2780,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       const float am_clamped = (am_level > 1.0f) ? 1.0f : am_level;
       // (AM: twice the carrier level stands in for |x| of every sample, :407-409 -- the lead lane holds it)
       const bool agc_quiet = ASDR_AGC_QUIET_PATH && __all(!(agc_en && lead) || (agc_hc0 >= 128u && agc_hang >= 8u && !((is_am ? am_clamped : blockmax) > agc_old0)));
+      // (the four-wave form, round 6: the AGC duty wave ran the lean chain beside the audio duty -- the envelope rows are there already; behind barrier 4)
       if (agc_en && !agc_quiet) {   // stage the channel's gain table and the |x| rows in LDS
         if constexpr (!C16) {
 #pragma unroll
         for (int r = 0; r < 5; ++r) { const int q = s8 + 8 * r; if (q < 33) *reinterpret_cast<float4 *>(L + AGC_TAB + 4 * q) = agc_t4[r]; }
         }
-        store8(L + AGC_GV + kA, av16); store8(L + AGC_GV + kA + 64, av16 + 8);
+        if (!agc_piped) { store8(L + AGC_GV + kA, av16); store8(L + AGC_GV + kA + 64, av16 + 8); }
       }
       if (!agc_quiet) WAVE_SYNC();
       TL(12);
@@ -2749,6 +2902,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       if constexpr ((MW_SHARE & 4) != 0) {
         // MW: every wave says whether its block is quiet; the AGC-duty wave (rel 3) runs the chains of the other waves' channels, one per lane
         // (the |x| rows and the gain tables are in the channels' LDS rows; the scalars come from the channels' state / parameter rows)
+        constexpr bool LEAN_OK = (ASDR_AGC_LEAN != 0) && (ASDR_MW_OWN_STORES != 0);
+        if (!agc_piped) {
         if (lead) {
           float *mq = mwx + MWX * (wave * 8 + c8);
           mq[5] = __int_as_float(agc_quiet ? 1 : 0); mq[6] = am_clamped;
@@ -2761,16 +2916,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         __syncthreads();
         TL(26);
         if (ASDR_MW_PRIO && mw_rel == 3) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
-#ifndef ASDR_AGC_LEAN
-#define ASDR_AGC_LEAN 1
-#endif
         // Round 6, the LEAN chain.  When no hang counter of the duty wave's channels can run out inside the block (counter >= 128 at its start and a
         // hang time of >= 128 samples: an attack re-arms it with that) nothing releases, and the only recurrence is the envelope itself:
         //     attack = |x| > envelope;  envelope = attack ? alpha envelope + beta |x| : envelope        (AudioSDR.cpp:412-420)
         // -- four instructions on the chain per sample instead of eight.  The duty wave leaves the envelope AFTER every sample in the row; which
         // sample attacked (|x|[u] > envelope after sample u - 1), from where on the governing value exists at all, the hang counter and the gain after
         // the block are functions of that row and are formed in parallel by the channels' own waves behind the barrier (below).
-        constexpr bool LEAN_OK = (ASDR_AGC_LEAN != 0) && (ASDR_MW_OWN_STORES != 0);
         if (mw_rel == 3 && lane_i < 8 * WAVES) {
           const int q = lane_i;
           const bool active = (__float_as_int(mwx[MWX * q + 5]) == 0);
@@ -2826,7 +2977,8 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         TL(27);
         __syncthreads();
         TL(28);
-        const bool lean_done = LEAN_OK && (__builtin_amdgcn_readfirstlane(mw_flags[0]) != 0);
+        } else { TL(25); TL(26); TL(27); TL(28); }
+        const bool lean_done = LEAN_OK && (agc_piped || __builtin_amdgcn_readfirstlane(mw_flags[0]) != 0);
         if (lean_done && !agc_quiet && agc_en) {
           // The lean chain left the envelope after every sample in the row.  Sample u attacked iff |x|[u] > the envelope after sample u - 1 (carried in for
           // u = 0); before the block's first attack the governing value does not exist (-1: the gain carried in applies); the counter after the block is
