@@ -1258,7 +1258,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const bool is_ssb = DO2 && ((mode == ASDR_USBmode) || (mode == ASDR_LSBmode) || (mode == ASDR_CW_USBmode) ||
                               (mode == ASDR_CW_LSBmode) || (mode == ASDR_WSPRmode));
   // the host launches SAM channels with the SAM (or ALS) instantiation only: the plain one carries no PLL code
-  const bool is_am = !C16 && (mode == ASDR_AMmode), is_sam = (HAS_SAM || ROLE >= 4) && (mode == ASDR_SAMmode);
+#ifndef ASDR_MW_NO_AM
+#define ASDR_MW_NO_AM 0   /* experiment: the four-wave form compiled without the AM paths (code size) */
+#endif
+  const bool is_am = !C16 && !(MW && ASDR_MW_NO_AM) && (mode == ASDR_AMmode), is_sam = (HAS_SAM || ROLE >= 4) && (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
   const bool nb_en = DO1 && (pflags & ASDR_F_NB_EN), af_en = DO3 && (pflags & ASDR_F_AF_EN), agc_en = DO3 && (pflags & ASDR_F_AGC_EN);
   const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
