@@ -1699,7 +1699,7 @@ bool is_pinned_host(const void *p, size_t bytes) {
 #define ASDR_AUTOPIN_BYTES ((size_t)2 << 30)
 #endif
 struct AutoPin {
-  struct Ent { const void *p; size_t bytes; unsigned long last_use; int seen; bool registered; };
+  struct Ent { const void *p; size_t bytes; unsigned long last_use; int seen; bool registered; int in_use; };   // in_use: asdr_update calls (other threads': shard workers, other batches) copying through the registration right now
   std::mutex m;
   std::vector<Ent> ents;
   unsigned long tick = 0;
@@ -1711,7 +1711,12 @@ struct AutoPin {
     if (ents[i].registered) { if (hipHostUnregister(const_cast<void *>(ents[i].p)) != hipSuccess) (void)hipGetLastError(); stat_evicted++; }
     ents.erase(ents.begin() + (long)i);
   }
-  void clear() { std::lock_guard<std::mutex> lk(m); while (!ents.empty()) drop(ents.size() - 1); }
+  void clear() { std::lock_guard<std::mutex> lk(m); for (size_t i = ents.size(); i-- > 0;) if (ents[i].in_use == 0) drop(i); }   // (a range a call is copying through stays until a later clear)
+  // a call starts / has finished copying through the registration of (p, bytes): such a range is never evicted under it
+  void hold(const void *p, size_t bytes, int d) {
+    std::lock_guard<std::mutex> lk(m);
+    for (Ent &e : ents) if (e.p == p && e.bytes == bytes && e.registered) { e.in_use += d; if (e.in_use < 0) e.in_use = 0; return; }
+  }
   // a pageable range was handed to asdr_update: note it; true = it has just been registered (the caller re-reads its attributes)
   bool sighting(const void *p, size_t bytes) {
     std::lock_guard<std::mutex> lk(m);
@@ -1727,8 +1732,8 @@ struct AutoPin {
         for (const Ent &o : ents) if (o.registered) { total += o.bytes; n_reg++; }
         while ((total > ASDR_AUTOPIN_BYTES || n_reg > ASDR_AUTOPIN_ENTRIES) && n_reg > 1) {   // make room: least recently used registered range out
           size_t lru = ents.size();
-          for (size_t k = 0; k < ents.size(); k++) if (ents[k].registered && (lru == ents.size() || ents[k].last_use < ents[lru].last_use)) lru = k;
-          if (lru == ents.size()) break;
+          for (size_t k = 0; k < ents.size(); k++) if (ents[k].registered && ents[k].in_use == 0 && (lru == ents.size() || ents[k].last_use < ents[lru].last_use)) lru = k;
+          if (lru == ents.size()) return false;   // (everything registered is being copied through right now: this range stays on the staged path)
           total -= ents[lru].bytes; n_reg--;
           drop(lru);
         }
@@ -1741,14 +1746,14 @@ struct AutoPin {
       }
       // an entry that overlaps this range without being it: the application's buffers have moved -- forget the old one
       const char *a0 = static_cast<const char *>(e.p), *a1 = a0 + e.bytes, *b0 = static_cast<const char *>(p), *b1 = b0 + bytes;
-      if (a0 < b1 && b0 < a1) { drop(i); i--; }
+      if (a0 < b1 && b0 < a1 && e.in_use == 0) { drop(i); i--; }
     }
     if (ents.size() >= 4 * ASDR_AUTOPIN_ENTRIES) {   // the table itself is bounded: the oldest unregistered sighting goes
       size_t old = ents.size();
       for (size_t k = 0; k < ents.size(); k++) if (!ents[k].registered && (old == ents.size() || ents[k].last_use < ents[old].last_use)) old = k;
       if (old != ents.size()) drop(old);
     }
-    ents.push_back(Ent{p, bytes, tick, 1, false});
+    ents.push_back(Ent{p, bytes, tick, 1, false, 0});
     return false;
   }
 };
@@ -1817,6 +1822,12 @@ int host_update(asdr_batch *b, const int16_t *I, const int16_t *Q, int16_t *out,
   if (!pin_q && g_autopin.sighting(Q, row_bytes_all)) pin_q = is_pinned_host(Q, row_bytes_all);
   if (!pin_o && g_autopin.sighting(out, row_bytes_all)) pin_o = is_pinned_host(out, row_bytes_all);
   const bool pinned = pin_i && pin_q && pin_o;
+  // (ranges registered by AutoPin are held for the length of the call: another thread's registration must not evict them under the copies)
+  struct PinHold {
+    const void *p[3]; size_t bytes; bool on;
+    ~PinHold() { if (on) for (int i = 0; i < 3; i++) g_autopin.hold(p[i], bytes, -1); }
+  } pin_hold{{I, Q, out}, row_bytes_all, pinned};
+  if (pinned) for (int i = 0; i < 3; i++) g_autopin.hold(pin_hold.p[i], row_bytes_all, +1);
   if (!pinned && count > b->h_io_cap) {   // the pinned staging area, one row set per call
     b->h_io_cap = 0;
     for (int i = 0; i < 3; i++) {

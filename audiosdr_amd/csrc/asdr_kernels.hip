@@ -3632,11 +3632,14 @@ static const char *const k_kernel_names[] = {
 };
 #define ASDR_N_KERNEL_NAMES ((int)(sizeof k_kernel_names / sizeof k_kernel_names[0]))
 static unsigned long long g_kernel_launches[ASDR_N_KERNEL_NAMES];
-static inline void count_launch(const char *name) {
+static inline int kernel_name_index(const char *name) {
   for (int i = 0; i < ASDR_N_KERNEL_NAMES; ++i)
-    if (strcmp(k_kernel_names[i], name) == 0) { __atomic_fetch_add(&g_kernel_launches[i], 1ull, __ATOMIC_RELAXED); return; }
+    if (strcmp(k_kernel_names[i], name) == 0) return i;
+  return -1;
 }
-#define ASDR_LAUNCH(kernel, ...) do { count_launch(#kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
+static inline void count_launch(int i) { if (i >= 0) __atomic_fetch_add(&g_kernel_launches[i], 1ull, __ATOMIC_RELAXED); }
+// (the name is looked up once per launch site: a function-local static)
+#define ASDR_LAUNCH(kernel, ...) do { static const int site_index_ = kernel_name_index(#kernel); count_launch(site_index_); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
 extern "C" int asdr_kernels_count(void) { return ASDR_N_KERNEL_NAMES; }
 extern "C" const char *asdr_kernels_name(int i) { return (i >= 0 && i < ASDR_N_KERNEL_NAMES) ? k_kernel_names[i] : nullptr; }
 extern "C" unsigned long long asdr_kernels_launches(int i) { return (i >= 0 && i < ASDR_N_KERNEL_NAMES) ? __atomic_load_n(&g_kernel_launches[i], __ATOMIC_RELAXED) : 0ull; }

@@ -99,9 +99,10 @@ int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *ou
  *   asdr_host_path_info(b, out)               out[0] = chunks of the last asdr_update, out[1] = 1 if it used the caller's buffers directly
  * Pageable buffers that RECUR can be pinned for the caller (round 6, OPT-IN): with asdr_host_autopin(1) the second time asdr_update is
  * handed the same (address, length) of ordinary memory it registers the range in place, and every later call DMA-copies straight from /
- * into it -- an application that reuses its buffers, as the reference's audio library does, pays the staging copies once (C2: 1.4 ->
- * 0.94 ms per call).  At most 12 ranges / 2 GiB are kept registered (least recently used first out); all of them are released when the
- * process' last batch is destroyed.  THE CONTRACT that makes it opt-in: a buffer the cache holds must not be freed (unmapped) behind the
+ * into it -- an application that reuses its buffers, as the reference's audio library does, pays the staging copies once (C2: 1.29 ->
+ * 1.06 ms per call).  At most 12 ranges / 2 GiB are kept registered (least recently used first out -- never a range that a call, of any thread, is copying
+ * through at that moment: a call holds its ranges for its length, and a new range that finds nothing evictable stays on the staged path);
+ * all of them are released when the process' last batch is destroyed.  THE CONTRACT that makes it opt-in: a buffer the cache holds must not be freed (unmapped) behind the
  * library's back -- a DMA through a registration whose range was unmapped and mapped again aborts the process (measured), and nothing
  * tells a library that its caller unmapped a range.  Call asdr_host_autopin_clear() before freeing buffers you have passed in.
  *   asdr_host_autopin(on)                     1 / 0 switches the behaviour on / off for the process (default off; environment ASDR_HOST_AUTOPIN=1: on),

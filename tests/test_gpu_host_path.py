@@ -133,6 +133,52 @@ def test_recurring_pageable_buffers_are_pinned_from_the_second_call(gpu):
     gpu.binding.host_autopin(0)                                      # the default
 
 
+def test_autopin_eviction_never_takes_a_range_another_call_is_copying_through(gpu):
+    """Two threads, each with its own batch and ten recurring buffer triples: 60 ranges compete for the cache's 12 places, so every registration
+    evicts -- but never a range that the OTHER thread's call is copying through at that moment (a call holds its ranges for its length).  Every
+    result is the device path's."""
+    import threading
+    from audiosdr_amd.synth import make_iq
+    n, T, reps, ntri = 512, 1, 3, 10
+    I, Q = make_iq(n, reps * ntri, fc=6290.0, A=0.25)
+    wants = []
+    for t in range(2):
+        w, _ = _device_reference(gpu, n, "usb", I, Q, (T,) * (reps * ntri))
+        wants.append(w)
+    gpu.binding.host_autopin_clear()
+    gpu.binding.host_autopin(1)
+    errs = []
+
+    def worker(t):
+        try:
+            b = gpu.AudioSDRBatch(n)
+            _mix(b, n, "usb")
+            tris = [[np.zeros((n, T, 128), np.int16) for _ in range(3)] for _ in range(ntri)]
+            k = 0
+            for rep in range(reps):
+                for tri in tris:
+                    tri[0][:] = I[:, k:k + 1]; tri[1][:] = Q[:, k:k + 1]; tri[2][:] = 0x2222
+                    b.update_into(*tri)
+                    if not np.array_equal(tri[2], wants[t][k]):
+                        errs.append("thread %d call %d: %d samples differ" % (t, k, int((tri[2] != wants[t][k]).sum())))
+                    k += 1
+            b.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append("thread %d: %r" % (t, e))
+
+    keep = gpu.AudioSDRBatch(8)   # (the process' last batch takes the registrations with it: not before both threads are done)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    info = gpu.binding.host_autopin_info()
+    keep.close()
+    gpu.binding.host_autopin(0)
+    assert not errs, errs[:3]
+    assert info["registered_now"] <= 12 and info["registrations"] >= 12, info
+
+
 def test_a_freed_and_reallocated_buffer_is_read_through_its_new_pages(gpu):
     """The hazard of pinning for the caller: the application frees a buffer and gets the same address back for new data.  A range is mapped at a
     fixed address, used twice, unmapped, mapped AGAIN at the same address with other samples, used again: the call must see the new samples and
