@@ -1230,16 +1230,23 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   float *const lds = lds_wg + wave * 8 * STRIDE;            // this wave's 8 channel rows
   const int lane = threadIdx.x & 63, c8 = lane >> 3, s8_ = lane & 7;
 #ifndef ASDR_MW_SINE_LDS
-#define ASDR_MW_SINE_LDS 0   /* measured (round 6): divergent mixer phases -1.3 %, steady state +0.3 % (the fill and its barrier): off */
+#define ASDR_MW_SINE_LDS 0   /* 1: filled at the top of every workgroup (measured: divergent mixer phases -1.3 %, steady state +0.3 %: the fill and its barrier);
+                                  2: filled between the blanker chain's two barriers, by the three waves that park there, and only in a workgroup one of whose waves
+                                  carries different mixer phases (each wave says so in a word of its own in front of the first barrier; the wave-uniform lookups keep
+                                  the constant table): divergent phases -0.4 %, steady state +0.3 %.  Off */
 #endif
   // Round 6: the four-wave form keeps a copy of the sine table in LDS as well (1 KB per workgroup of 32 channels: 3 workgroups per CU still fit) --
   // waves whose channels carry DIFFERENT mixer phases (receivers tuned at different times: 2 x 16 lookups per lane) read it through the LDS
   // instead of gathering from the constant table through L1; one barrier at the top of the kernel.
   constexpr bool MW_SINE = MW && (ASDR_MW_SINE_LDS != 0);
-  constexpr bool SINE_LDS = HAS_SAM || MW_SINE;
-  float *const sine = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : (MW_SINE ? lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 : nullptr);
-  if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine[i] = c_sine[i];
-  if (MW_SINE) { for (int i = (int)threadIdx.x; i < ASDR_SINE_TABLE_LEN; i += 64 * WAVES) sine[i] = c_sine[i]; __syncthreads(); }
+  constexpr bool MW_SINE_LAZY = MW_SINE && (ASDR_MW_SINE_LDS == 2) && (MW_SHARE & 2) != 0 && WAVES == 4;   // (the table exists where a wave needs it: the per-channel lookups; the wave-uniform ones read the constant table)
+  constexpr bool SINE_LDS = HAS_SAM || (MW_SINE && !MW_SINE_LAZY);   // the wave-uniform lookups (two per lane) and the oscillator cache's writer
+  constexpr bool SINE_LDS_PC = HAS_SAM || MW_SINE;                   // the per-channel lookups (16 per lane)
+  float *const sine_tab = HAS_SAM ? lds_wg + WAVES * 8 * STRIDE : (MW_SINE ? lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 : nullptr);
+  float *const sine = SINE_LDS ? sine_tab : nullptr;
+  int *const mw_sflag = reinterpret_cast<int *>(lds_wg + WAVES * 8 * STRIDE + 8 * WAVES * 16 + 260) + 8;   // MW_SINE_LAZY: per wave "my channels carry different mixer phases"
+  if (HAS_SAM) for (int i = lane; i < ASDR_SINE_TABLE_LEN; i += 64) sine_tab[i] = c_sine[i];
+  if (MW_SINE && !MW_SINE_LAZY) { for (int i = (int)threadIdx.x; i < ASDR_SINE_TABLE_LEN; i += 64 * WAVES) sine_tab[i] = c_sine[i]; __syncthreads(); }
 
   int4 slot = make_int4(a.n_channels, 0, 0, 0);
   const bool mw_pad = MW && (wave_g * 8 >= a.n_sched);   // a wave behind the sub-range's last one: works on the dummy channel, stores nothing outside it
@@ -1264,6 +1271,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   const bool is_am = !C16 && !(MW && ASDR_MW_NO_AM) && (mode == ASDR_AMmode), is_sam = (HAS_SAM || ROLE >= 4) && (mode == ASDR_SAMmode);
   const bool sub_q = (mode == ASDR_USBmode) || (mode == ASDR_CW_USBmode) || (mode == ASDR_WSPRmode);
   const bool nb_en = DO1 && (pflags & ASDR_F_NB_EN), af_en = DO3 && (pflags & ASDR_F_AF_EN), agc_en = DO3 && (pflags & ASDR_F_AGC_EN);
+  if constexpr (MW_SINE_LAZY) {
+    if (!(ABL_ON(ABL_NB) && __any(nb_en))) {   // no blanker in this launch (launch-uniform in the four-wave form), hence no chain barriers: the table is filled here
+      for (int i = (int)threadIdx.x; i < ASDR_SINE_TABLE_LEN; i += 64 * WAVES) sine_tab[i] = c_sine[i];
+      __syncthreads();
+    }
+  }
   const bool als_en = HAS_ALS && (pflags & ASDR_F_ALS_EN);
   const bool muted = pflags & ASDR_F_MUTED;
   const float two_pi = K.two_pi_f;
@@ -1767,9 +1780,21 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
             mwx[MWX * (wave * 8 + c8) + 7] = __int_as_float((capable ? 1 : 0) | (recent ? 2 : 0));
           }
         }
+        if constexpr (MW_SINE_LAZY) {
+          const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mphase)), i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(minc));
+          const bool differ = mix_early && !__all(__float_as_uint(mphase) == p1 && __float_as_uint(minc) == i1);
+          if (lane_i == 0) mw_sflag[wave] = differ ? 1 : 0;
+        }
         TL(17);
         __syncthreads();
         TL(18);
+        if constexpr (MW_SINE_LAZY) {
+          const int4 sf = *reinterpret_cast<const int4 *>(mw_sflag);
+          if (__builtin_amdgcn_readfirstlane(sf.x | sf.y | sf.z | sf.w) != 0 && mw_rel != 0) {   // the three waves that would park now fill the table (visible behind the second barrier)
+#pragma unroll 1
+            for (int i = (mw_rel - 1) * 64 + lane_i; i < ASDR_SINE_TABLE_LEN; i += 192) { sine_tab[i] = c_sine[i]; asm volatile("" ::: "memory"); }   // (one entry in flight: this is the kernel's register peak)
+          }
+        }
         if (ASDR_MW_PRIO && mw_rel == 0) __builtin_amdgcn_s_setprio(ASDR_MW_PRIO);
         if (mw_rel == 0 && lane_i < 8 * WAVES) {
           const int q = lane_i;
@@ -2288,7 +2313,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           float ph[4];
           load4(L + PH + kF + 32 * m, ph);
 #ifndef ASDR_MIX_SERIAL_LOOKUPS
-          sincos_batch<4, SINE_LDS>(sine, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
+          sincos_batch<4, SINE_LDS_PC>(SINE_LDS_PC ? sine_tab : nullptr, ph, cc, sn, two_pi, SinIndexK{K.inv_two_pi_d, K.sin_index_scale_d}, K.half_pi_d);
 #else
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -3276,7 +3301,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void asdr_update_kernel_c16(Updat
 // = 12 waves per CU as before; direct launches (one settings group of consecutive channels) of one block
 #define ASDR_MW_WAVES 4
 extern "C" __global__ __launch_bounds__(64 * ASDR_MW_WAVES, ASDR_WAVES_PER_EU) void asdr_update_kernel_mw(UpdateArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260 + 8];   // rows | hand-off scratch | sine table | progress words | flags
+  __shared__ __attribute__((aligned(16))) float lds[ASDR_MW_WAVES * 8 * ASDR_STRIDE + ASDR_MW_WAVES * 8 * 16 + 260 + 12];   // rows | hand-off scratch | sine table | progress words | flags
   asdr_update_body<ASDR_STRIDE, false, false, true, ASDR_MW_WAVES, 0, true>(a, lds);
 }
 // SAM: 4 waves = 32 channels per workgroup (50,704 B of LDS -> 3 workgroups = 12 waves per CU), general form only
