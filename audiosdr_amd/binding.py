@@ -54,7 +54,7 @@ _GETTERS_I = ["getMute", "getAudioFilter", "ALSfilterIsEnabled", "ALSfilterIsNot
 # every symbol include/asdr.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = (["asdr_create", "asdr_destroy", "asdr_last_error", "asdr_n_channels", "asdr_update", "asdr_update_device",
             "asdr_synchronize", "asdr_setDemodMode", "asdr_getDemodMode", "asdr_setALSfilterParams", "asdr_getAGClookup",
-            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_set_exact_unknown_mode", "asdr_get_exact_unknown_mode", "asdr_stream_pipeline_recoveries", "asdr_stream_pipeline_max_groups", "asdr_set_stream_pipeline", "asdr_set_sam_launch_form", "asdr_set_als_launch_form", "asdr_debug_set_stream_spin_limit", "asdr_debug_set_stream_max_groups", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
+            "asdr_read_status", "asdr_control_plane_flush", "asdr_get_chain_constants", "asdr_stream_pipeline_launches", "asdr_schedule_layout", "asdr_set_exact_unknown_mode", "asdr_get_exact_unknown_mode", "asdr_stream_pipeline_recoveries", "asdr_stream_pipeline_max_groups", "asdr_set_stream_fir_helpers", "asdr_stream_pipeline_h3_calls", "asdr_set_stream_pipeline", "asdr_set_sam_launch_form", "asdr_set_als_launch_form", "asdr_debug_set_stream_spin_limit", "asdr_debug_set_stream_max_groups", "asdr_enable_taps", "asdr_read_taps", "asdr_last_kernel_ms", "asdr_version",
             "asdr_kernel_timing_begin", "asdr_kernel_timing_end", "asdr_set_launch_timing", "asdr_region_timing_begin", "asdr_region_timing_end", "asdr_update_device_strided", "asdr_capture_open",
             "asdr_capture_close", "asdr_capture_capacity", "asdr_capture_position", "asdr_capture_rewind",
             "asdr_capture_device_ptr", "asdr_capture_update_device", "asdr_capture_read",
@@ -159,6 +159,9 @@ def load_library(path=None):
     if path is None or hasattr(L, "asdr_set_stream_pipeline"):
         L.asdr_stream_pipeline_recoveries.argtypes = [vp]; L.asdr_stream_pipeline_recoveries.restype = C.c_long
         L.asdr_stream_pipeline_max_groups.argtypes = [vp]; L.asdr_stream_pipeline_max_groups.restype = _i
+        if hasattr(L, "asdr_set_stream_fir_helpers"):
+            L.asdr_set_stream_fir_helpers.argtypes = [vp, _i]; L.asdr_set_stream_fir_helpers.restype = _i
+            L.asdr_stream_pipeline_h3_calls.argtypes = [vp]; L.asdr_stream_pipeline_h3_calls.restype = C.c_long
         L.asdr_set_stream_pipeline.argtypes = [vp, _i]; L.asdr_set_stream_pipeline.restype = _i
         L.asdr_set_sam_launch_form.argtypes = [vp, _i, _i]; L.asdr_set_sam_launch_form.restype = _i
         if hasattr(L, "asdr_set_als_launch_form"):
@@ -401,6 +404,14 @@ class AudioSDRBatch:
 
     def stream_pipeline_max_groups(self):
         return int(self._L.asdr_stream_pipeline_max_groups(self._h))
+
+    def set_stream_fir_helpers(self, mode):
+        """-1: three FIR helper waves per role-2 workgroup of the block pipeline while every workgroup has a compute unit to itself (default);
+        0: always one; 1: three wherever they are resident (asdr.h)."""
+        self._chk(self._L.asdr_set_stream_fir_helpers(self._h, int(mode)))
+
+    def stream_pipeline_h3_calls(self):
+        return int(self._L.asdr_stream_pipeline_h3_calls(self._h))
 
     def set_stream_pipeline(self, on=True):
         self._chk(self._L.asdr_set_stream_pipeline(self._h, 1 if on else 0))

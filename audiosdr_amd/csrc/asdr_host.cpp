@@ -54,8 +54,8 @@
 #ifndef ASDR_STREAM_SIDE_WAVES
 #define ASDR_STREAM_SIDE_WAVES 64   /* waves of other kernel kinds / remainders a pipeline call may carry beside it (on the in-kernel block loop) */
 #endif
-extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream);
-extern "C" int asdr_stream_capacity(int device, int *compute_units);
+extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream, int fir_helpers);
+extern "C" int asdr_stream_capacity(int device, int *compute_units, int fir_helpers);
 extern "C" int asdr_launch_stream_snapshot(const UpdateArgs *a, void *snap, int restore, hipStream_t stream);
 extern "C" int asdr_launch_stream_ack(uint32_t *err, hipStream_t stream);
 extern "C" int asdr_kernels_upload_tables(void);
@@ -304,6 +304,9 @@ struct asdr_batch {
   int stream_query_waves = 0;       // ... as the occupancy query of asdr_create answered (the debug hook cannot go beyond it)
   int stream_max_waves = 0;         // channel groups the pipeline may hold: 3 w + 1 workgroups must be co-resident, one per compute unit
   int stream_cap_workgroups = 0;    // the occupancy query's answer itself (resident workgroups of the pipeline kernel on this device)
+  int stream_cap_h3 = 0, stream_cus = 0;   // ... of its three-helper form (256 threads per workgroup), and the device's compute units: that form is taken while every workgroup has one to itself
+  int stream_h3 = -1;               // -1: by the rule above; 0 / 1: forced (ASDR_STREAM_H3, asdr_set_stream_fir_helpers: measurements, tests)
+  long stat_stream_h3_calls = 0;
   uint32_t stream_spin_limit = ASDR_STREAM_SPIN_LIMIT;
   void *d_stream_snap = nullptr;    // snapshot of the state a pipeline call advances (asdr_kernels.hip "the pipeline as a transaction")
   long stat_stream_recoveries = 0;  // pipeline calls that gave up and were re-run on the in-kernel block loop (read back at synchronisation points)
@@ -967,7 +970,10 @@ asdr_batch_t *asdr_create(int n_channels, int device) {
       // Measured with several workgroups per compute unit (tools/stream_sizes.py): 6.9 us per block up to 84 groups, 7.3 at 128,
       // 8.4 at 256, 11.0 at 512 -- against 18.9-20.2 us for the in-kernel block loop at every one of those sizes.
       int cus = 0;
-      const int cap = asdr_stream_capacity(device, &cus);
+      const int cap = asdr_stream_capacity(device, &cus, 1);
+      const int cap3 = asdr_stream_capacity(device, nullptr, 3);
+      b->stream_cap_h3 = cap3 > 0 ? cap3 : 0; b->stream_cus = cus;
+      { const char *e = getenv("ASDR_STREAM_H3"); if (e) b->stream_h3 = atoi(e) != 0 ? 1 : 0; }
       b->stream_cap_workgroups = cap > 0 ? cap : 0;
       b->stream_max_waves = cap >= 3 ? cap / 3 : 0;
       if (b->stream_max_waves > ASDR_STREAM_MAX_WAVES) b->stream_max_waves = ASDR_STREAM_MAX_WAVES;
@@ -1264,7 +1270,12 @@ static int update_device_part(asdr_batch_t *b, const int16_t *dI, const int16_t 
     a.stream_waves = w; a.lo_ring = b->d_lo_ring; a.stream_spin_limit = b->stream_spin_limit;
     if (e0) HIPCHK(hipEventRecord(e0, stream));
     if (asdr_launch_stream_snapshot(&a, b->d_stream_snap, 0, stream) != 0) return fail("stream snapshot launch failed");
-    if (asdr_launch_stream(&a, stream) != 0) return fail("stream kernel launch failed");
+    // three FIR helper waves per role-2 workgroup while every pipeline workgroup has a compute unit to itself (and the residency arithmetic above holds
+    // for the 256-thread form too); otherwise the two-wave form
+    const bool h3 = b->stream_h3 != 0 && b->stream_cap_h3 > 0 && 3 * w + other_waves + ASDR_STREAM_SIDE_MARGIN <= b->stream_cap_h3 &&
+                    (b->stream_h3 == 1 || 3 * w <= b->stream_cus);
+    if (h3) b->stat_stream_h3_calls++;
+    if (asdr_launch_stream(&a, stream, h3 ? 3 : 1) != 0) return fail("stream kernel launch failed");
     if (asdr_launch_stream_snapshot(&a, b->d_stream_snap, 1, stream) != 0) return fail("stream restore launch failed");
     {   // the same call on the in-kernel block loop, gated on the error word: its waves return at once when the pipeline completed
       UpdateArgs f = a;
@@ -2455,6 +2466,17 @@ long asdr_stream_pipeline_alloc_failures(asdr_batch_t *b) {
 long asdr_stream_pipeline_headroom_refusals(asdr_batch_t *b) {
   if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_stream_headroom_refusals; return t; }
   return b ? b->stat_stream_headroom_refusals : -1;
+}
+long asdr_stream_pipeline_h3_calls(asdr_batch_t *b) {
+  if (is_sharded(b)) { long t = 0; for (asdr_batch *sh : b->shards) t += sh->stat_stream_h3_calls; return t; }
+  return b ? b->stat_stream_h3_calls : -1;
+}
+int asdr_set_stream_fir_helpers(asdr_batch_t *b, int mode) {
+  if (!b) return fail("null batch");
+  FOR_SHARDS(b, asdr_set_stream_fir_helpers(sh_, mode));
+  if (mode < -1 || mode > 1) return fail("bad mode (-1 = by the rule, 0 = always one helper wave, 1 = three wherever they are resident)");
+  b->stream_h3 = mode;
+  return 0;
 }
 int asdr_stream_pipeline_max_groups(asdr_batch_t *b) {   // (per shard: every shard is a launch of its own)
   if (is_sharded(b)) { int m = 0x7fffffff; for (asdr_batch *sh : b->shards) m = std::min(m, sh->stream_max_waves); return m; }

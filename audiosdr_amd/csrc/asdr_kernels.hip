@@ -365,7 +365,8 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // through DPP row_shr:1, stage 3 writes back in place (ds_write_b128).  The y-independent part
 // p = (b0*x + b1*x1) + b2*x2 of all four samples is off the critical path; the recurrence is 3 dependent ops/sample.
 #ifndef ASDR_PIPE_PK_MASK
-#define ASDR_PIPE_PK_MASK 0   /* which kernel kinds run the pipelines' y-independent products packed (see PIPE_PK in the body) */
+#define ASDR_PIPE_PK_MASK 8   /* which kernel kinds run the pipelines' y-independent products packed (see PIPE_PK in the body): the block pipeline's role waves (alone on their
+                                  SIMDs, where a packed instruction costs an issue slot like any other: C5 share -1 %); everywhere else measured equal or slower */
 #endif
 #ifndef ASDR_PIPE_PREFETCH_FENCE
 #define ASDR_PIPE_PREFETCH_FENCE 0   /* measured: no gain (profiles/README.md, round 5) */
@@ -866,7 +867,8 @@ __device__ __forceinline__ void hilbert_fir(const float *Lrow, int p0, v2f *acc2
 }
 // Second wave of a role-2 workgroup of the streaming pipeline: nothing but the other half of the FIR, in step with the first
 // wave's three barriers per block (history staged | all reads done | both halves in W1).
-template <int STRIDE>
+// E0, NE: this wave's output pairs (round 6: asdr_stream_kernel_h3 runs THREE helper waves beside the role wave, two pairs each).
+template <int STRIDE, int E0 = 4, int NE = 4>
 __device__ __forceinline__ void asdr_stream_fir_helper(const UpdateArgs &a, float *lds) {
   const int lane = threadIdx.x & 63, c8 = lane >> 3, s8 = lane & 7, k0 = 16 * s8;
   float *L = lds + c8 * STRIDE;
@@ -875,14 +877,14 @@ __device__ __forceinline__ void asdr_stream_fir_helper(const UpdateArgs &a, floa
   if (((a.direct_ch0 >= 0) ? a.direct_mode : a.sched[wave_g * 8].mode) == ASDR_AMmode) return;
 #pragma unroll 1
   for (int blk = 0; blk < a.n_blocks; ++blk) {
-    v2f acc2[4];
+    v2f acc2[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc2[e] = (v2f){0.0f, 0.0f};
+    for (int e = 0; e < NE; ++e) acc2[e] = (v2f){0.0f, 0.0f};
     __syncthreads();
-    if (ABL_ON(ABL_HIL)) hilbert_fir<4, 4>(L, k0 >> 1, acc2);
+    if (ABL_ON(ABL_HIL)) hilbert_fir<E0, NE>(L, k0 >> 1, acc2);
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 8 + 2 * e) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
+    for (int e = 0; e < NE; e += 2) *reinterpret_cast<float4 *>(L + W1 + k0 + 2 * (E0 + e)) = make_float4(acc2[e][0], acc2[e][1], acc2[e + 1][0], acc2[e + 1][1]);
     __syncthreads();
   }
 }
@@ -916,6 +918,15 @@ __device__ __forceinline__ void stream_signal(uint32_t *p, uint32_t value, int l
   if (lane == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // four 16-byte pieces (p + 32 m floats, m = 0..3) of an exchange row, `sc1`; the loads are waited for inside
+// 16 bytes another workgroup wrote during this launch, as two relaxed agent-scope loads (`sc1`, like xch_load4x4) that the COMPILER tracks: the value may be
+// asked for long before it is used (role 2's prefetch of the next block's rows), which inline assembly cannot promise (a register it defines counts as written at once).
+__device__ __forceinline__ v4f ld_sc1_v4(const float *p) {
+  const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v4f r;
+  r[0] = __uint_as_float((uint32_t)lo); r[1] = __uint_as_float((uint32_t)(lo >> 32)); r[2] = __uint_as_float((uint32_t)hi); r[3] = __uint_as_float((uint32_t)(hi >> 32));
+  return r;
+}
 __device__ __forceinline__ void xch_store4x4(float *p, v4f v0, v4f v1, v4f v2, v4f v3) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:128 sc1\n\t"
                "global_store_dwordx4 %0, %3, off offset:256 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:384 sc1\n\t"
@@ -1155,7 +1166,7 @@ __device__ __forceinline__ void als_compute(float *L, bool als_en, bool adaptive
 // call of a large schedule block by block -- and always the SAM / two-launch ALS roles).  The block loop below is then no loop at all:
 // nothing is loop-invariant, so nothing is hoisted in front of the body and kept in registers across all of it (lane masks, cache-entry
 // addresses, flag words: the plain kernel's 66 SGPR spills and 8 of its VGPRs were exactly that).
-template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0, bool ONEBLK_ = false>
+template <int STRIDE, bool HAS_ALS, bool HAS_SAM, bool UNIFORM, int WAVES, int ROLE = 0, bool ONEBLK_ = false, int FIR_HELPERS = 1>
 __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds_wg) {
   // ROLE 4 / 5: the SAM sub-range as three launches -- 4 = everything in front of the PLL (scale, blanker, IF filter), then the
   // stand-alone PLL kernel (asdr_sam_pll_kernel: one LANE per channel, 64 channels per wave -- the PLL is a 128-step dependent chain
@@ -1288,6 +1299,26 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // stores still happen: HBM holds the state after the call): mixer phase, frequency shift, Hilbert ring parity
   float carry_phase = 0.0f, carry_fsh = 0.0f;
   uint32_t carry_hs = 0u;
+#ifndef ASDR_STREAM_PREFETCH_IN
+#define ASDR_STREAM_PREFETCH_IN 1   /* the block pipeline's role 1 requests the NEXT block's input rows at the top of a block (its one HBM round trip per block otherwise sits in front of the scale) */
+#endif
+  int4 pf_in[4] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};   // ROLE 1: the next block's input pieces (I, I + 64, Q, Q + 64)
+#ifndef ASDR_STREAM_R2_ONE_TRIP
+#define ASDR_STREAM_R2_ONE_TRIP 1   /* role 2 asks for everything another workgroup wrote for this block -- oscillator key, its 2 x 128 pairs, the IF rows -- in ONE round trip */
+#endif
+#ifndef ASDR_STREAM_R2_PREFETCH
+#define ASDR_STREAM_R2_PREFETCH 1   /* role 2 of the three-helper form asks for block k + 1's oscillator pairs and IF rows in front of block k's FIR, when both producers are known to be that far */
+#endif
+  constexpr bool R2_ONE_TRIP = (ROLE == 2) && (FIR_HELPERS == 3) && (ASDR_STREAM_R2_ONE_TRIP != 0);   // (68 registers in flight: the three-helper form has them -- one workgroup per compute unit --, the two-wave form spills with it)
+  constexpr bool R2_PREFETCH = R2_ONE_TRIP && (ASDR_STREAM_R2_PREFETCH != 0);
+  v4f r2n_key = (v4f){0.f, 0.f, 0.f, 0.f}, r2n_c4[4], r2n_s4[4], r2n_vi[4], r2n_vq[4];
+  bool r2_pref = false;
+  uint32_t r2_look_in = 0u, r2_look_lo = 0u;
+#ifndef ASDR_STREAM_R1_CARRY
+#define ASDR_STREAM_R1_CARRY 0   /* role 1 keeping its IF cascade's state and coefficients (and the input gains) in registers from block to block: measured +1.5 % (C5 share 4.025 vs 3.96 ms), off */
+#endif
+  float4 r1_if_s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float r1_if_cf[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, r1_gain_i = 0.f, r1_gain_q = 0.f;
   uint32_t *const my_prog = STREAM ? a.stream_prog + (ROLE - 1) * a.stream_waves + wave_g : nullptr;
 
   // (The ALS instantiations' loop-free builds failed the ALS parity tests until the guard of the tap store-back was taken from an opaque copy
@@ -1410,10 +1441,32 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     const LoEntry *lo_rd = (ROLE == 2) ? a.lo_ring + (blk % ASDR_LO_RING) : a.lo_cache + (a.lo_parity & 1u) * ASDR_LO_ENTRIES + lo_e;
     uint32_t lo_kp, lo_ki;
     float lo_end;
+    v4f r2_c4[4], r2_s4[4], r2_vi[4], r2_vq[4];
     if (ROLE == 2) {
-      if (seen_lo < (uint32_t)blk + 1u) { seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves, (uint32_t)blk + 1u, a.stream_err, a.stream_spin_limit); if (seen_lo == ASDR_STREAM_FAIL) break; }
       v4f key;
+      if (R2_PREFETCH && r2_pref) {   // asked for during the previous block (both producers had published this one by then)
+        key = r2n_key;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { r2_c4[m] = r2n_c4[m]; r2_s4[m] = r2n_s4[m]; r2_vi[m] = r2n_vi[m]; r2_vq[m] = r2n_vq[m]; }
+        r2_pref = false;
+      } else {
+      if (seen_lo < (uint32_t)blk + 1u) { seen_lo = stream_wait(a.stream_prog + 3 * a.stream_waves, (uint32_t)blk + 1u, a.stream_err, a.stream_spin_limit); if (seen_lo == ASDR_STREAM_FAIL) break; }
+      if (R2_ONE_TRIP) {
+        // Round 6: the key, the pairs and the rows used to be four `sc1` round trips one behind the other (each waited for where it was issued: ~1 k cycles
+        // apiece for a wave that is alone on its SIMD); both producers have published this block (the waits above and at the top of the block).
+        const float *lp = lo_rd->c + 4 * s8_, *xp = a.xch_a + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)(blk % ASDR_STREAM_DEPTH)) * (2 * ASDR_N) + 4 * s8_;
+        asm volatile("global_load_dwordx4 %0, %17, off sc1\n\t"
+                     "global_load_dwordx4 %1, %18, off sc1\n\tglobal_load_dwordx4 %2, %18, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %18, off offset:256 sc1\n\tglobal_load_dwordx4 %4, %18, off offset:384 sc1\n\t"
+                     "global_load_dwordx4 %5, %18, off offset:512 sc1\n\tglobal_load_dwordx4 %6, %18, off offset:640 sc1\n\tglobal_load_dwordx4 %7, %18, off offset:768 sc1\n\tglobal_load_dwordx4 %8, %18, off offset:896 sc1\n\t"
+                     "global_load_dwordx4 %9, %19, off sc1\n\tglobal_load_dwordx4 %10, %19, off offset:128 sc1\n\tglobal_load_dwordx4 %11, %19, off offset:256 sc1\n\tglobal_load_dwordx4 %12, %19, off offset:384 sc1\n\t"
+                     "global_load_dwordx4 %13, %19, off offset:512 sc1\n\tglobal_load_dwordx4 %14, %19, off offset:640 sc1\n\tglobal_load_dwordx4 %15, %19, off offset:768 sc1\n\tglobal_load_dwordx4 %16, %19, off offset:896 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(key), "=&v"(r2_c4[0]), "=&v"(r2_c4[1]), "=&v"(r2_c4[2]), "=&v"(r2_c4[3]), "=&v"(r2_s4[0]), "=&v"(r2_s4[1]), "=&v"(r2_s4[2]), "=&v"(r2_s4[3]),
+                       "=&v"(r2_vi[0]), "=&v"(r2_vi[1]), "=&v"(r2_vi[2]), "=&v"(r2_vi[3]), "=&v"(r2_vq[0]), "=&v"(r2_vq[1]), "=&v"(r2_vq[2]), "=&v"(r2_vq[3])
+                     : "v"(lo_rd), "v"(lp), "v"(xp) : "memory");
+      } else
       asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(key) : "v"(lo_rd) : "memory");
+      }
       lo_kp = __float_as_uint(key[0]); lo_ki = __float_as_uint(key[1]); lo_end = key[2];
     } else {
       lo_kp = lo_rd->key_phase; lo_ki = lo_rd->key_inc; lo_end = lo_rd->phase_end;
@@ -1438,7 +1491,9 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     ri[0].v = ri[1].v = rq[0].v = rq[1].v = make_int4(0, 0, 0, 0);
     roi[0].v = roi[1].v = roq[0].v = roq[1].v = rmi[0].v = rmi[1].v = rmq[0].v = rmq[1].v = make_int4(0, 0, 0, 0);
     uint32_t mkc[5] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};   // defined on every path
-    const float gain_i = P.in_gain_i, gain_q = P.in_gain_q;
+    float gain_i, gain_q;
+    if (ROLE == 1 && ASDR_STREAM_R1_CARRY && blk > 0) { gain_i = r1_gain_i; gain_q = r1_gain_q; }
+    else { gain_i = P.in_gain_i; gain_q = P.in_gain_q; if (ROLE == 1) { r1_gain_i = gain_i; r1_gain_q = gain_q; } }
     float g_oi = gain_i, g_oq = gain_q, g_mi = 0.0f, g_mq = 0.0f, nb_avg0 = 0.0f;
     uint32_t agc_hc_early = 0u, agc_hang_early = 0u;
     bool agc_piped = false;   // (the four-wave form: the AGC duty runs the lean chain beside the audio duty: see the audio filter)
@@ -1469,11 +1524,19 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (DO1 && valid) {
       const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io);
       const int4 *pq = reinterpret_cast<const int4 *>(a.in_q + io);
+      if constexpr (ROLE == 1 && ASDR_STREAM_PREFETCH_IN != 0) {
+        // the pipeline's role 1: this block's rows were requested a block ago; the next block's are requested now (a role wave is alone on its
+        // SIMD: nothing hides the round trip for it)
+        if (blk == 0) { ri[0].v = load_int4_nt(pi); ri[1].v = load_int4_nt(pi + 8); rq[0].v = load_int4_nt(pq); rq[1].v = load_int4_nt(pq + 8); }
+        else { ri[0].v = pf_in[0]; ri[1].v = pf_in[1]; rq[0].v = pf_in[2]; rq[1].v = pf_in[3]; }
+        // (the next block's rows are requested in front of the IF pipeline, behind the late signal: its wait must not sit out these loads)
+      } else {
 #if ASDR_NT_LOADS >= 1
       ri[0].v = load_int4_nt(pi); ri[1].v = load_int4_nt(pi + 8); rq[0].v = load_int4_nt(pq); rq[1].v = load_int4_nt(pq + 8);
 #else
       ri[0].v = pi[0]; ri[1].v = pi[8]; rq[0].v = pq[0]; rq[1].v = pq[8];   // int4 #8 = 64 samples on
 #endif
+      }
     }
     // mixer increment (AudioSDR.h:508-512) and the local-oscillator cache test (asdr_device.h LoEntry): hit = every channel of the
     // wave starts this block with exactly the cached phase and increment -> no recurrence, no table lookups, the pairs are read
@@ -2023,6 +2086,12 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     // count loads in order, and a wait for these values placed after the (conditional) prefetches would be a wait for everything
     // -- the first pipeline step would sit out the prefetches' HBM latency (it did: vmcnt(0) inside the pipeline loop).
     auto load_if_rows = [&]() {
+      if (ROLE == 1 && ASDR_STREAM_R1_CARRY && blk > 0) {   // (a call's settings are fixed; the state is what the previous block's pipeline left -- it is stored every block as well)
+        if_s4 = r1_if_s4;
+#pragma unroll
+        for (int z = 0; z < 5; ++z) if_cf[z] = r1_if_cf[z];
+        return;
+      }
       if_s4 = *reinterpret_cast<const float4 *>(&Sp->if_state[pl_iq][4 * pl_st]);
       const float *cf = &c_bq_pool[Ppl->if_table][5 * pl_st];
 #pragma unroll
@@ -2062,7 +2131,10 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
     if (!C16 && RING_PREFETCH && lo_hit) {
       if (ROLE == 2) {   // written by another workgroup during this launch: `sc1` loads
         v4f c4[4], s4[4];
-        xch_load4x4(lo_rd->c + kF, c4[0], c4[1], c4[2], c4[3]); xch_load4x4(lo_rd->s + kF, s4[0], s4[1], s4[2], s4[3]);
+        if (R2_ONE_TRIP) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { c4[m] = r2_c4[m]; s4[m] = r2_s4[m]; }
+        } else { xch_load4x4(lo_rd->c + kF, c4[0], c4[1], c4[2], c4[3]); xch_load4x4(lo_rd->s + kF, s4[0], s4[1], s4[2], s4[3]); }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -2074,6 +2146,13 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       }
     }
     // ---- IF band-pass, AudioSDR.cpp:77-78: 2 x 4-stage cascade, 64 lanes = 8 ch x {I,Q} x 4 stages -------
+    if (ROLE == 1 && sig_pending) { stream_signal(my_prog, sig_pending, lane); sig_pending = 0u; }   // the previous block's rows have left by now (they were stored a prologue and a scale ago)
+    if constexpr (ROLE == 1 && ASDR_STREAM_PREFETCH_IN != 0) {
+      if (DO1 && valid && blk + 1 < a.n_blocks) {   // the next block's input rows: they arrive during the pipeline
+        const int4 *pi = reinterpret_cast<const int4 *>(a.in_i + io) + ASDR_N / 8, *pq = reinterpret_cast<const int4 *>(a.in_q + io) + ASDR_N / 8;
+        pf_in[0] = load_int4_nt(pi); pf_in[1] = load_int4_nt(pi + 8); pf_in[2] = load_int4_nt(pq); pf_in[3] = load_int4_nt(pq + 8);
+      }
+    }
     if (DO1 && ABL_ON(ABL_IF)) {
       const int iq = pl_iq, st = pl_st;
       float sv[4];
@@ -2083,6 +2162,11 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       biquad_pipe<PIPE_PK>(Lp + (iq ? W1 : W0), true, st, if_cf, sv);
       CHAIN_PRIO_OFF();
       *reinterpret_cast<float4 *>(&Sp->if_state[iq][4 * st]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+      if (ROLE == 1 && ASDR_STREAM_R1_CARRY) {
+        r1_if_s4 = make_float4(sv[0], sv[1], sv[2], sv[3]);
+#pragma unroll
+        for (int z = 0; z < 5; ++z) r1_if_cf[z] = if_cf[z];
+      }
     }
     if (C16 && lo_hit) store4(lds + (lane_i >> 4) * STRIDE + PH + ((4 * lane_i) & 63), lo4);   // word i of [cos | sin]: row i >> 6, place i & 63
     WAVE_SYNC();
@@ -2101,15 +2185,27 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         for (int m = 0; m < 4; ++m) { vi[m] = *reinterpret_cast<const v4f *>(L + W0 + kF + 32 * m); vq[m] = *reinterpret_cast<const v4f *>(L + W1 + kF + 32 * m); }
         xch_store4x4(xa, vi[0], vi[1], vi[2], vi[3]); xch_store4x4(xa + ASDR_N, vq[0], vq[1], vq[2], vq[3]);
         store_status_bits(ASDR_S_NB_DETECTED);
-        stream_signal(a.stream_prog + wave_g, (uint32_t)blk + 1u, lane);
+#ifndef ASDR_STREAM_LATE_SIGNAL
+#define ASDR_STREAM_LATE_SIGNAL 1   /* role 1 publishes block k in front of block k + 1's IF pipeline (the stores' round trip used to sit at the end of every block: ~1.7 k cycles) */
+#endif
+        if (ASDR_STREAM_LATE_SIGNAL) sig_pending = (uint32_t)blk + 1u;   // (published below, in front of the next block's IF pipeline; in front of any wait; behind the last block)
+        else stream_signal(a.stream_prog + wave_g, (uint32_t)blk + 1u, lane);
         continue;
       } else {
         v4f vi[4], vq[4];
-        xch_load4x4(xa, vi[0], vi[1], vi[2], vi[3]); xch_load4x4(xa + ASDR_N, vq[0], vq[1], vq[2], vq[3]);
+        if (R2_ONE_TRIP) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { vi[m] = r2_vi[m]; vq[m] = r2_vq[m]; }
+          if (sig_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's stores of the previous block have left: they were issued in front of the loads above, which have returned)
+        } else { xch_load4x4(xa, vi[0], vi[1], vi[2], vi[3]); xch_load4x4(xa + ASDR_N, vq[0], vq[1], vq[2], vq[3]); }
         if (sig_pending) { if (lane == 0) __hip_atomic_store(my_prog, sig_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sig_pending = 0u; }   // (vmcnt(0) inside the loads)
 #pragma unroll
         for (int m = 0; m < 4; ++m) { *reinterpret_cast<v4f *>(L + W0 + kF + 32 * m) = vi[m]; *reinterpret_cast<v4f *>(L + W1 + kF + 32 * m) = vq[m]; }
         WAVE_SYNC();
+        if constexpr (R2_PREFETCH) {   // how far the two producers are: read in front of the Hilbert FIR (the prefetch of the next block's rows)
+          r2_look_in = __hip_atomic_load(a.stream_prog + wave_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          r2_look_lo = __hip_atomic_load(a.stream_prog + 3 * a.stream_waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
 
@@ -2470,14 +2566,35 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
       WAVE_SYNC();
       TL(8);
       mw_straggler(3);
+      if constexpr (R2_PREFETCH) {
+        // The NEXT block's oscillator entry and IF rows, if both producers are known to have published it (the counters as last polled: a producer that is
+        // ahead is polled once for several blocks): the round trip of ~1.9 k cycles runs under the FIR.  Ring slots (blk + 1) % depth are this wave's to read
+        // until it publishes block blk + 1 itself.
+        const uint32_t b2 = (uint32_t)blk + 2u;
+        if (blk + 1 < a.n_blocks && (seen_in < b2 || seen_lo < b2)) {   // one look at the two counters, asked for behind this block's rows (no waiting: a producer that is not there yet is waited for at the top of the next block)
+          const uint32_t ui = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2_look_in), ul = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2_look_lo);
+          asm volatile("" ::: "memory");   // (no load of the published rows moves in front of the look)
+          if (ui != ASDR_STREAM_FAIL && ui > seen_in) seen_in = ui;
+          if (ul != ASDR_STREAM_FAIL && ul > seen_lo) seen_lo = ul;
+        }
+        if (blk + 1 < a.n_blocks && seen_in != ASDR_STREAM_FAIL && seen_lo != ASDR_STREAM_FAIL && seen_in >= b2 && seen_lo >= b2) {
+          const LoEntry *ln = a.lo_ring + ((blk + 1) % ASDR_LO_RING);
+          const float *lp = ln->c + kF, *xp = a.xch_a + ((size_t)ch * ASDR_STREAM_DEPTH + (size_t)((blk + 1) % ASDR_STREAM_DEPTH)) * (2 * ASDR_N) + kF;
+          r2n_key = ld_sc1_v4(reinterpret_cast<const float *>(ln));
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { r2n_c4[m] = ld_sc1_v4(lp + 32 * m); r2n_s4[m] = ld_sc1_v4(lp + ASDR_N + 32 * m); r2n_vi[m] = ld_sc1_v4(xp + 32 * m); r2n_vq[m] = ld_sc1_v4(xp + ASDR_N + 32 * m); }
+          r2_pref = true;
+        }
+      }
       constexpr bool IDL_EARLY = (ROLE == 2);   // the pipeline's role 2 has the registers to request the delayed I before the FIR
       if (IDL_EARLY && is_ssb) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) load4(hi_ring + (hs ^ 1u) * 128 + 32 * m, idl + 4 * m);
       }
-      // In the pipeline's role 2 the FIR is shared with the workgroup's second wave (asdr_stream_fir_helper): this wave computes the
-      // output pairs 0..3 of every lane, the helper 4..7, between two workgroup barriers.
-      constexpr int FIR_NE = (ROLE == 2) ? 4 : 8;
+      // In the pipeline's role 2 the FIR is shared with the workgroup's other waves (asdr_stream_fir_helper): this wave computes the
+      // output pairs 0..3 of every lane and ONE helper 4..7 (asdr_stream_kernel), or 0, 1 and THREE helpers two pairs each
+      // (asdr_stream_kernel_h3), between two workgroup barriers.
+      constexpr int FIR_NE = (ROLE == 2) ? 8 / (FIR_HELPERS + 1) : 8;   // (one helper: pairs 0..3 here; three helpers: pairs 0, 1)
       v2f acc2[FIR_NE];
 #pragma unroll
       for (int e = 0; e < FIR_NE; ++e) acc2[e] = (v2f){0.0f, 0.0f};
@@ -2927,6 +3044,54 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         else { Sc->agc_old_abs = old_abs; Sc->agc_hang_counter = hc; Sc->agc_gain = g_end; }
         return g_end;
       };
+      // What the LEAN chain (below: the four-wave form's duty, or the wave's own lead lanes) leaves to be done, by all eight lanes of a channel.
+      auto agc_lean_finish = [&](float old_end_lead) {
+        // The lean chain left the envelope after every sample in the row.  Sample u attacked iff |x|[u] > the envelope after sample u - 1 (carried in for
+        // u = 0); before the block's first attack the governing value does not exist (-1: the gain carried in applies); the counter after the block is
+        // hang - (127 - last attack), or the carried one less 128; the gain after the block is the compressor at the last envelope, if anything attacked.
+        int first = 128, last = -1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float ov[8];
+          load8(L + AGC_GV + kA + 64 * h, ov);
+          const int p0 = kA + 64 * h;
+          float before = (p0 == 0) ? agc_old0 : L[AGC_GV + ((p0 == 0) ? 0 : p0 - 1)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool att = av16[8 * h + j] > before;
+            first = (att && p0 + j < first) ? p0 + j : first;
+            last = att ? p0 + j : last;
+            before = ov[j];
+          }
+        }
+        // over the channel's eight lanes: minimum of `first`, maximum of `last` (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror: as the block maximum above)
+        { const int t = __builtin_amdgcn_update_dpp(0, first, 0xB1, 0xF, 0xF, true); first = t < first ? t : first; }
+        { const int t = __builtin_amdgcn_update_dpp(0, first, 0x4E, 0xF, 0xF, true); first = t < first ? t : first; }
+        { const int t = __builtin_amdgcn_update_dpp(0, first, 0x141, 0xF, 0xF, true); first = t < first ? t : first; }
+        { const int t = __builtin_amdgcn_update_dpp(0, last, 0xB1, 0xF, 0xF, true); last = t > last ? t : last; }
+        { const int t = __builtin_amdgcn_update_dpp(0, last, 0x4E, 0xF, 0xF, true); last = t > last ? t : last; }
+        { const int t = __builtin_amdgcn_update_dpp(0, last, 0x141, 0xF, 0xF, true); last = t > last ? t : last; }
+        WAVE_SYNC();   // (every lane has read the envelopes it compares with before anybody overwrites a row entry)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // the rows as the general chain leaves them: -1 in front of the first attack
+          const int p0 = kA + 64 * h;
+          if (p0 < first) {
+            float ov[8];
+            load8(L + AGC_GV + p0, ov);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (p0 + j < first) ? -1.0f : ov[j];
+            store8(L + AGC_GV + p0, ov);
+          }
+        }
+        if (lead) {
+          const float old_end = old_end_lead;
+          const float g_end = (last < 0) ? gain_in : agc_compress(tab, old_end);
+          status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
+          S->agc_old_abs = old_end;
+          S->agc_hang_counter = (last < 0) ? agc_hc0 - 128u : agc_hang - (uint32_t)(127 - last);
+          S->agc_gain = g_end;
+        }
+      };
       if constexpr ((MW_SHARE & 4) != 0) {
         // MW: every wave says whether its block is quiet; the AGC-duty wave (rel 3) runs the chains of the other waves' channels, one per lane
         // (the |x| rows and the gain tables are in the channels' LDS rows; the scalars come from the channels' state / parameter rows)
@@ -3008,51 +3173,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
         } else { TL(25); TL(26); TL(27); TL(28); }
         const bool lean_done = LEAN_OK && (agc_piped || __builtin_amdgcn_readfirstlane(mw_flags[0]) != 0);
         if (lean_done && !agc_quiet && agc_en) {
-          // The lean chain left the envelope after every sample in the row.  Sample u attacked iff |x|[u] > the envelope after sample u - 1 (carried in for
-          // u = 0); before the block's first attack the governing value does not exist (-1: the gain carried in applies); the counter after the block is
-          // hang - (127 - last attack), or the carried one less 128; the gain after the block is the compressor at the last envelope, if anything attacked.
-          int first = 128, last = -1;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            float ov[8];
-            load8(L + AGC_GV + kA + 64 * h, ov);
-            const int p0 = kA + 64 * h;
-            float before = (p0 == 0) ? agc_old0 : L[AGC_GV + ((p0 == 0) ? 0 : p0 - 1)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const bool att = av16[8 * h + j] > before;
-              first = (att && p0 + j < first) ? p0 + j : first;
-              last = att ? p0 + j : last;
-              before = ov[j];
-            }
-          }
-          // over the channel's eight lanes: minimum of `first`, maximum of `last` (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror: as the block maximum above)
-          { const int t = __builtin_amdgcn_update_dpp(0, first, 0xB1, 0xF, 0xF, true); first = t < first ? t : first; }
-          { const int t = __builtin_amdgcn_update_dpp(0, first, 0x4E, 0xF, 0xF, true); first = t < first ? t : first; }
-          { const int t = __builtin_amdgcn_update_dpp(0, first, 0x141, 0xF, 0xF, true); first = t < first ? t : first; }
-          { const int t = __builtin_amdgcn_update_dpp(0, last, 0xB1, 0xF, 0xF, true); last = t > last ? t : last; }
-          { const int t = __builtin_amdgcn_update_dpp(0, last, 0x4E, 0xF, 0xF, true); last = t > last ? t : last; }
-          { const int t = __builtin_amdgcn_update_dpp(0, last, 0x141, 0xF, 0xF, true); last = t > last ? t : last; }
-          WAVE_SYNC();   // (every lane has read the envelopes it compares with before anybody overwrites a row entry)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {   // the rows as the general chain leaves them: -1 in front of the first attack
-            const int p0 = kA + 64 * h;
-            if (p0 < first) {
-              float ov[8];
-              load8(L + AGC_GV + p0, ov);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) ov[j] = (p0 + j < first) ? -1.0f : ov[j];
-              store8(L + AGC_GV + p0, ov);
-            }
-          }
-          if (lead) {
-            const float old_end = mwx[MWX * (wave * 8 + c8) + 8];
-            const float g_end = (last < 0) ? gain_in : agc_compress(tab, old_end);
-            status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
-            S->agc_old_abs = old_end;
-            S->agc_hang_counter = (last < 0) ? agc_hc0 - 128u : agc_hang - (uint32_t)(127 - last);
-            S->agc_gain = g_end;
-          }
+          agc_lean_finish(lead ? mwx[MWX * (wave * 8 + c8) + 8] : 0.0f);
         } else
         if (!agc_quiet && lead) {
           const float *mq = mwx + MWX * (wave * 8 + c8);
@@ -3060,7 +3181,46 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
           if (ASDR_MW_OWN_STORES && agc_en) { S->agc_old_abs = mq[8]; S->agc_hang_counter = __float_as_uint(mq[9]); S->agc_gain = g_end; }
         }
       } else {
+#ifndef ASDR_AGC_LEAN1
+#define ASDR_AGC_LEAN1 1   /* the lean chain for the forms whose waves run their own channels' chains too (one lane per channel) */
+#endif
+        // The lean chain (see the four-wave form's AGC duty above) on the wave's own lead lanes: no channel of the wave can run out of its hang counter
+        // inside the block (and none is AM: twice the carrier level stands in for |x| there) -- the envelope recurrence alone, half the general form's
+        // instructions per sample; what the block leaves behind is formed in parallel by agc_lean_finish.
+        constexpr bool LEAN1_OK = (ASDR_AGC_LEAN1 != 0) && !C16 && !(ROLE == 0 && WAVES == 1 && !ONEBLK_ && !HAS_ALS && !HAS_SAM && UNIFORM);   // (the looped plain kernel spills with it)
+        const bool lean1 = LEAN1_OK && !agc_quiet && __all(!(agc_en && lead) || (!is_am && agc_hc0 >= 128u && agc_hang >= 128u));
         if (!agc_quiet) CHAIN_PRIO_ON();
+        if (lean1) {
+          float old_abs = agc_old0;
+          if (agc_en && lead) {
+            const float al_a = agc_al_a, be_a = agc_be_a;
+            float x_[8];
+            load8(L + AGC_GV, x_);
+#pragma unroll 1
+            for (int i2 = 0; i2 < ASDR_N; i2 += 16) {
+              float xn_[8];
+#pragma unroll
+              for (int half = 0; half < 2; ++half) {
+                const int i = i2 + 8 * half;
+                float *x = half ? xn_ : x_, *xn = half ? x_ : xn_;
+                load8(L + AGC_GV + ((i + 8 < ASDR_N) ? i + 8 : i), xn);
+                float pb[8], ov[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pb[u] = be_a * x[u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const float pa = al_a * old_abs;
+                  const float v_new = pa + pb[u];
+                  old_abs = (x[u] > old_abs) ? v_new : old_abs;
+                  ov[u] = old_abs;
+                }
+                store8(L + AGC_GV + i, ov);
+              }
+            }
+          }
+          WAVE_SYNC();
+          if (agc_en) agc_lean_finish(old_abs);
+        } else
         if (!agc_quiet && agc_en && lead) {
           const float g_end = agc_chain(std::false_type{}, L, S, agc_old0, agc_hc0, gain_in, agc_al_a, agc_be_a, agc_al_r, agc_be_r, agc_hang, is_am, am_clamped);
           status = (status & ~ASDR_S_AGC_ACTIVE) | (((double)g_end < 0.99) ? ASDR_S_AGC_ACTIVE : 0u);
@@ -3619,6 +3779,28 @@ extern "C" __global__ __launch_bounds__(128, ASDR_WAVES_PER_EU) void asdr_stream
   else asdr_update_body<ASDR_STRIDE, false, false, true, 1, 3>(a, lds);
 }
 
+// Round 6: the same pipeline with THREE helper waves in a role-2 workgroup (256 threads per workgroup): the Hilbert FIR in quarters.  The roles
+// are balanced at ~15 k cycles per block (profiles/r03_timeline_stream_roles.txt) and role 2 carries 5.8 k of half a FIR; the chip is three
+// quarters idle at the bank sizes the pipeline serves best, so the extra waves are free.  Taken by the host while every workgroup has a
+// compute unit to itself (3 w <= compute units); larger banks keep the two-wave form, whose workgroups pack six to a compute unit.
+extern "C" __global__ __launch_bounds__(256, 1) void asdr_stream_kernel_h3(UpdateArgs a) {   // (no register cap: one workgroup per compute unit is all this form asks for)
+  __shared__ __attribute__((aligned(16))) float lds[8 * ASDR_STRIDE];
+  __shared__ __attribute__((aligned(16))) float lo_scratch[ASDR_N];
+  const int role = (int)blockIdx.x / a.stream_waves;   // workgroup-uniform
+  const int hw = (int)threadIdx.x >> 6;
+  if (hw != 0) {
+    if (role == 1) {
+      if (hw == 1) asdr_stream_fir_helper<ASDR_STRIDE, 2, 2>(a, lds);
+      else if (hw == 2) asdr_stream_fir_helper<ASDR_STRIDE, 4, 2>(a, lds);
+      else asdr_stream_fir_helper<ASDR_STRIDE, 6, 2>(a, lds);
+    } else if (blockIdx.x == 0 && hw == 1) asdr_stream_lo_role(a, lo_scratch);
+    return;
+  }
+  if (role == 0) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 1>(a, lds);
+  else if (role == 1) asdr_update_body<ASDR_STRIDE, false, false, true, 1, 2, false, 3>(a, lds);
+  else asdr_update_body<ASDR_STRIDE, false, false, true, 1, 3>(a, lds);
+}
+
 // ---- launch census (round 6): every kernel launch of this file goes through ASDR_LAUNCH, which counts it under the kernel's name -- so that a
 // measurement can say WHICH instantiation it timed (bench.py's `roofline.kernel` was a hard-coded string that had gone stale).  The table is the
 // list of this file's kernels: tests/test_build_properties.py checks it against the __global__ definitions and the launch sites.
@@ -3641,6 +3823,7 @@ static const char *const k_kernel_names[] = {
   "asdr_spin_kernel",
   "asdr_stream_ack_kernel",
   "asdr_stream_kernel",
+  "asdr_stream_kernel_h3",
   "asdr_stream_restore_kernel",
   "asdr_stream_snapshot_kernel",
   "asdr_update_kernel",
@@ -3670,18 +3853,20 @@ extern "C" const char *asdr_kernels_name(int i) { return (i >= 0 && i < ASDR_N_K
 extern "C" unsigned long long asdr_kernels_launches(int i) { return (i >= 0 && i < ASDR_N_KERNEL_NAMES) ? __atomic_load_n(&g_kernel_launches[i], __ATOMIC_RELAXED) : 0ull; }
 extern "C" void asdr_kernels_launches_reset(void) { for (int i = 0; i < ASDR_N_KERNEL_NAMES; ++i) __atomic_store_n(&g_kernel_launches[i], 0ull, __ATOMIC_RELAXED); }
 
-extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream) {
+extern "C" int asdr_launch_stream(const UpdateArgs *a, hipStream_t stream, int fir_helpers) {
   if (a->stream_waves <= 0) return 0;
-  ASDR_LAUNCH(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(128), 0, stream, *a);
+  if (fir_helpers == 3) ASDR_LAUNCH(asdr_stream_kernel_h3, dim3(3 * a->stream_waves), dim3(256), 0, stream, *a);
+  else ASDR_LAUNCH(asdr_stream_kernel, dim3(3 * a->stream_waves), dim3(128), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // How many workgroups of the pipeline kernel the device can hold at once (occupancy x compute units): the pipeline's roles wait
 // for each other, so all 3 W + 1 of them must be resident together.  -1 = the runtime could not tell.
-extern "C" int asdr_stream_capacity(int device, int *compute_units) {
+extern "C" int asdr_stream_capacity(int device, int *compute_units, int fir_helpers) {
   int per_cu = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, asdr_stream_kernel, 128, 0) != hipSuccess) return -1;
+  if ((fir_helpers == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, asdr_stream_kernel_h3, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, asdr_stream_kernel, 128, 0)) != hipSuccess) return -1;
   if (compute_units) *compute_units = prop.multiProcessorCount;
   return per_cu * prop.multiProcessorCount;
 }

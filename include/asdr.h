@@ -353,6 +353,14 @@ long asdr_stream_pipeline_launches(asdr_batch_t *b);
  * asdr_set_stream_pipeline(b, 0) opts a batch out of the pipeline altogether (default on; environment ASDR_NO_STREAM_PIPELINE=1
  * at asdr_create time = default off). */
 long asdr_stream_pipeline_recoveries(asdr_batch_t *b);
+/* Round 6: the pipeline's role-2 workgroup shares the Hilbert FIR between its role wave and ONE helper wave (asdr_stream_kernel, 128 threads per
+ * workgroup, six of them per compute unit) or THREE (asdr_stream_kernel_h3, 256 threads: the FIR in quarters).  The three-helper form is taken
+ * while every pipeline workgroup has a compute unit to itself (3 x channel groups <= compute units: the bank sizes the pipeline serves best,
+ * where three quarters of the chip idle) and the residency arithmetic holds for it.  asdr_set_stream_fir_helpers(b, -1 | 0 | 1): by that rule
+ * (default) | always one helper | three wherever they are resident (environment ASDR_STREAM_H3=0|1 at asdr_create time);
+ * asdr_stream_pipeline_h3_calls() = calls that took the three-helper form.  Results are bit-identical either way. */
+int asdr_set_stream_fir_helpers(asdr_batch_t *b, int mode);
+long asdr_stream_pipeline_h3_calls(asdr_batch_t *b);
 /* The pipeline's exchange rings, progress counters and snapshot (about 9 KB per channel) are allocated at its first use.  If that
  * allocation fails the batch opts itself out of the pipeline and keeps the in-kernel block loop -- the call still succeeds; this
  * counts such events.  A call whose output rows overlap its input rows (in-place use, the reference's own convention:

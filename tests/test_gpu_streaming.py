@@ -281,6 +281,32 @@ def test_block_pipeline_sizes(gpu, ao, n_ch, T, pipelined):
     hip.free_all(); batch.close()
 
 
+@pytest.mark.parametrize("mode,n_ch", [(0, 64), (1, 64), (-1, 64), (1, 1600), (-1, 1600)])
+def test_block_pipeline_fir_helper_forms(gpu, ao, mode, n_ch):
+    """The role-2 workgroup's Hilbert FIR with ONE helper wave (128-thread workgroups) and with THREE (asdr_stream_kernel_h3: the FIR in quarters),
+    forced either way and by the rule (three while every pipeline workgroup has a compute unit to itself: 64 channels yes, 1,600 no -- not even
+    forced: that form is resident one workgroup per compute unit): every block
+    of the sampled channels equals the oracle, LSB / USB alternating between the groups so that both sideband signs pass through every helper."""
+    from audiosdr_amd.synth import make_iq
+    T = 12
+    I, Q = make_iq(n_ch, T, fc=6290.0, A=0.25, noise=0.02, impulse_every=500)
+    batch, orcs = _mk(gpu, ao, n_ch, [S("setDemodMode", 1), S("enableAudioFilter"), S("setNoiseBlankerThresholdDb", 10.0)])
+    batch.set_stream_fir_helpers(mode)
+    hip = Hip()
+    dI, dQ = hip.upload(I), hip.upload(Q)
+    dO = hip.malloc(n_ch * T * 256)
+    batch.update_device(dI, dQ, dO, T)
+    batch.synchronize()
+    got = hip.download(dO, (n_ch, T, 128), np.int16)
+    for c in sorted(set(list(range(0, 16)) + [n_ch // 2, n_ch - 9, n_ch - 1])):
+        want = orcs[c].update(I[c], Q[c]).reshape(T, 128)
+        assert np.array_equal(got[c], want), "ch %d" % c
+    assert batch.stream_pipeline_launches() == 1 and batch.stream_pipeline_recoveries() == 0
+    three = mode != 0 and n_ch == 64   # (1,600 channels = 600 pipeline workgroups: more than the three-helper form's one workgroup per compute unit, forced or not)
+    assert batch.stream_pipeline_h3_calls() == (1 if three else 0)
+    hip.free_all(); batch.close()
+
+
 @pytest.mark.parametrize("limit", [1, 40])
 def test_block_pipeline_timeout_is_recovered_in_stream(gpu, ao, limit):
     """The pipeline as a transaction (asdr.h, asdr_kernels.hip): with the poll limit of the bounded waits shrunk to `limit` the
