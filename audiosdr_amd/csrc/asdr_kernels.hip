@@ -1324,7 +1324,7 @@ __device__ __forceinline__ void asdr_update_body(const UpdateArgs &a, float *lds
   // (The ALS instantiations' loop-free builds failed the ALS parity tests until the guard of the tap store-back was taken from an opaque copy
   // of the flag word: a compiler issue, see there.)
   constexpr bool ONEBLK = (!HAS_ALS || ASDR_ONEBLK_ALS) && (ONEBLK_ || (ROLE >= 4 && !LOOPED_ROLE && ASDR_ONEBLK_ROLES));
-  constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ONEBLK && (ROLE == 0);
+  constexpr bool UNIT_OK = (ASDR_UNIT_SCALE != 0) && ((ONEBLK && ROLE == 0) || ROLE == 1);   // (round 6: the block pipeline's role 1 too -- its scale was 1.3 k cycles of binary64 per block on a wave that is alone on its SIMD)
   // C16 (round 5, asdr_update_kernel_c16): the same chain on 320-float rows and <= 128 VGPRs -- 10,240 B of LDS per wave, FOUR waves per
   // SIMD = 16 per CU.  Direct one-block launches of ONE SSB-class settings group without stage taps (the launcher's choice: mode and
   // flags are launch-uniform scalars, the AM / SAM / unknown-mode paths are compiled out).  What fits 320 floats and 128 registers:

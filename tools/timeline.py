@@ -209,6 +209,10 @@ def stream(T=256, n_ch=512):
         for nm, v in zip(names, med):
             if v > 0 and v < 10 * cyc:
                 print("   %-36s %8.0f cycles" % (nm, v))
+        if os.environ.get("TIMELINE_RAW"):
+            # the marks this role passed, in time order: cycles since the block start (marks a role does not pass hold another block's clock)
+            off = np.median(a_[:, :16] - a_[:, 16:17], axis=0)
+            print("   marks in time order (TL index: cycles since the block start): " + "  ".join("%d:%d" % (i, v) for v, i in sorted((v, i) for i, v in enumerate(off) if 0 <= v < 2 * cyc)))
     L.asdr_destroy(h)
 
 
