@@ -105,6 +105,11 @@ int asdr_update(asdr_batch_t *b, const int16_t *I, const int16_t *Q, int16_t *ou
  * all of them are released when the process' last batch is destroyed.  THE CONTRACT that makes it opt-in: a buffer the cache holds must not be freed (unmapped) behind the
  * library's back -- a DMA through a registration whose range was unmapped and mapped again aborts the process (measured), and nothing
  * tells a library that its caller unmapped a range.  Call asdr_host_autopin_clear() before freeing buffers you have passed in.
+ * AND A WARNING beyond the contract (round 6, measured): a long-lived process that had registered and correctly released many SMALL ordinary allocations
+ * this way (heap blocks that share pages with their neighbours) and then went on allocating, freeing and copying other memory aborted inside the
+ * runtime in a later, unrelated copy -- about every second run of this repository's GPU suite, until the tests that switch this on were given
+ * processes of their own.  Use it for large, long-lived, page-exclusive buffers (the case it was built for: a receiver bank's I/Q rows) or pin them
+ * yourself (asdr_host_alloc / asdr_host_register), which has no such history.
  *   asdr_host_autopin(on)                     1 / 0 switches the behaviour on / off for the process (default off; environment ASDR_HOST_AUTOPIN=1: on),
  *                                             -1 only asks; returns the previous setting
  *   asdr_host_autopin_clear()                 unregister everything the cache holds
