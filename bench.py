@@ -371,18 +371,22 @@ def other_configs(np, torch, dev, local_rank):
             extra["lock_fraction"] = float(batch.read_status()["sam_locked"].mean())
         if capture:
             batch.capture_rewind()
+        A.binding.kernels_launched(reset=True)   # (the launch census names the instantiations the measured region ran)
         ms_fresh = measure_region(batch, step, stream, 0, timed)   # blocks warm .. warm + timed - 1 of a FRESH bank (AGC attacking, locks settling)
         ms = ms_fresh
         if settle > 0:   # ... and the same region again once the bank has run `settle` more steps (what the C2 line calls its steady state)
             for i in range(settle):
                 step(i)
+            A.binding.kernels_launched(reset=True)
             ms = measure_region(batch, step, stream, 0, timed)
+        launched = A.binding.kernels_launched()
         ach = algo * n_ch * T / (ms * 1e-3) / 1e9
         d = {"workload": what, "channels": n_ch, "blocks_per_step": T, "ms_per_step": round(ms, 5), "Msamples_per_s": round(n_ch * T * BLOCK / ms / 1e3, 1),
              "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_channel_block": round(algo, 1), "dominant_kernel": kernel,
              "steps_timed": timed, "steps_untimed": warm + (timed + settle if settle > 0 else 0), "fresh_bank_ms_per_step": round(ms_fresh, 5),
              "fresh_bank_region": "steps %d..%d of the bank" % (warm, warm + timed - 1), "lane_calls": batch.lane_calls() - lc0,
-             "oracle_spot_check": {"channel": check_ch, "blocks": int(want.shape[0]) if capture else T, "bit_exact": ok}}
+             "oracle_spot_check": {"channel": check_ch, "blocks": int(want.shape[0]) if capture else T, "bit_exact": ok},
+             "kernels_launched_in_the_measured_region": launched}
         if capture:
             d["times_real_time"] = round(T * BLOCK / 44100.0 / (ms * 1e-3), 1)
             d["calls_run_as_block_pipeline"] = batch.stream_pipeline_launches()
@@ -403,7 +407,7 @@ def other_configs(np, torch, dev, local_rank):
         C4_ALGO_BYTES_PER_BLOCK, "asdr_update_kernel_als_small_one (+ the SAM pre | PLL | post-with-ALS launches and the remainders' launch beside it)",
         "C4: one GPU's share (131,072 of 1,048,576 channels) of the mixed-mode batch: mode = channel mod 7, ALS notch, blanker at 10 dB; 1 block/step", settle=300)
     run("c5_share", 512, C5_T, 1, 512, dict(fc=6890.0, A=0.02, noise=0.05), configure_c5, lambda o, c: configure_c5(o), 511, 2, 8,
-        C5_ALGO_BYTES_PER_BLOCK, "asdr_stream_kernel (block pipeline)",
+        C5_ALGO_BYTES_PER_BLOCK, "asdr_stream_kernel_h3 (block pipeline, three FIR helper waves: the launch census beside this says which form ran)",
         "C5: one GPU's share (512 of 4,096 WSPR receivers, BareBonesWSPR.ino settings); one step = a 646-block call into the capture sink", capture=True)
     return res
 
